@@ -1,0 +1,248 @@
+/*
+ * t2s.h -- C ABI of libt2s_hip.so: the MI355X (gfx950) implementation of the
+ * T2S diffusion hot path of Bill9125/T2MS.
+ *
+ * The reference has no FFI layer: its boundary is a set of Python classes
+ * (SURVEY.md section 8b).  The host-side mirrors of those classes live in
+ * t2ms_amd/model/... and call the entry points below through ctypes; each
+ * entry point cites the reference interface it replaces (paths relative to
+ * the reference repo root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *     tensors are dense, row-major fp32 in exactly the reference's layout;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *     no entry point synchronises the device or allocates in the launch path
+ *     (so callers may capture them into a hipGraph); only *_create/_destroy
+ *     allocate / free;
+ *   - return value: 0 on success, negative T2S_E_* on failure, with a
+ *     human-readable message available from t2s_last_error();
+ *   - the caller owns every buffer it passes in; the library owns only its
+ *     packed weight copies, workspaces and hipGraph handles;
+ *   - handles are not thread-safe; one process per GPU.
+ */
+#ifndef T2S_H
+#define T2S_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T2S_OK 0
+#define T2S_E_INVALID (-1)  /* bad argument (shape, NULL, range)          */
+#define T2S_E_HIP (-2)      /* a HIP runtime call failed                  */
+#define T2S_E_STATE (-3)    /* handle not in a state that allows the call */
+
+#define T2S_D_MODEL 128
+#define T2S_N_TOK 480  /* (30/2) * (64/2) patches, transformer.py:132-136 */
+#define T2S_N_HEADS 4
+#define T2S_HEAD_DIM 32
+#define T2S_N_BLOCKS 4
+#define T2S_LAT_C 64
+#define T2S_LAT_W 30
+#define T2S_LAT_ELEMS (T2S_LAT_C * T2S_LAT_W)
+
+const char* t2s_last_error(void);
+/* library build id + the gfx arch it was compiled for, e.g. "t2s 0.1 gfx950" (host string) */
+const char* t2s_version(void);
+
+/* ------------------------------------------------------------------------ *
+ * DiT denoiser: model/denoiser/transformer.py:128-193 (Transformer),
+ * :94-124 (Transformerlayer), timm 1.0.11 Attention/Mlp call sites :104-105.
+ * ------------------------------------------------------------------------ */
+typedef struct t2s_dit t2s_dit;
+
+/* Device pointers to the reference state-dict tensors. */
+typedef struct t2s_dit_block_weights {
+    const float* qkv_w;  /* layers.i.attn.qkv.weight            (384,128) */
+    const float* qkv_b;  /* layers.i.attn.qkv.bias              (384)     */
+    const float* proj_w; /* layers.i.attn.proj.weight           (128,128) */
+    const float* proj_b; /* layers.i.attn.proj.bias             (128)     */
+    const float* fc1_w;  /* layers.i.mlp.fc1.weight             (256,128) */
+    const float* fc1_b;  /* layers.i.mlp.fc1.bias               (256)     */
+    const float* fc2_w;  /* layers.i.mlp.fc2.weight             (128,256) */
+    const float* fc2_b;  /* layers.i.mlp.fc2.bias               (128)     */
+    const float* ada_w;  /* layers.i.adaLN_modulation.1.weight  (768,128) */
+    const float* ada_b;  /* layers.i.adaLN_modulation.1.bias    (768)     */
+} t2s_dit_block_weights;
+
+typedef struct t2s_dit_weights {
+    const float* conv_w;    /* conv.weight                (4,1,2,2) */
+    const float* conv_b;    /* conv.bias                  (4)       */
+    const float* patch_w;   /* patch_emb.weight           (128,4)   */
+    const float* patch_b;   /* patch_emb.bias             (128)     */
+    const float* pos_embed; /* pos_embed                  (1,480,128) */
+    const float* ln_w;      /* ln.weight                  (128)     */
+    const float* ln_b;      /* ln.bias                    (128)     */
+    const float* out_w;     /* linear_emb_to_patch.weight (4,128)   */
+    const float* out_b;     /* linear_emb_to_patch.bias   (4)       */
+    const float* time_freqs; /* 10000^linspace(0,1,64), transformer.py:34 (64) */
+    t2s_dit_block_weights blk[T2S_N_BLOCKS];
+} t2s_dit_weights;
+
+/* Create a denoiser able to run up to `max_seqs` sequences per call (a CFG
+ * sampling step over a batch of B series uses 2*B sequences).  Packs the
+ * weights into the kernels' MFMA-fragment layout (synchronous). */
+int t2s_dit_create(const t2s_dit_weights* w, int max_seqs, t2s_dit** out);
+/* Re-pack after the caller changed the weights (load_state_dict, optimizer step). */
+int t2s_dit_update_weights(t2s_dit* h, const t2s_dit_weights* w, void* stream);
+void t2s_dit_destroy(t2s_dit* h);
+int t2s_dit_max_seqs(const t2s_dit* h);
+
+/* TimeEmbedding.forward, transformer.py:30-40.  t: (B) fp32 (int64 timesteps are
+ * converted to fp32 by the host mirror exactly as `t * 100.0` promotes them);
+ * out: (B,128) = [sin(100 t / f) | cos(100 t / f)]. */
+int t2s_time_embedding(const t2s_dit* h, const float* t, float* out, int B, void* stream);
+
+/* Transformer.forward, transformer.py:158-193.
+ *   x    (B,64,30)   latent
+ *   temb (temb_rows,128), temb_rows in {1,B}: output of t2s_time_embedding
+ *   text (B,128) or NULL (text_input=None -> unconditional)
+ *   out  (B,64,30)
+ * B <= max_seqs. */
+int t2s_dit_forward(t2s_dit* h, const float* x, const float* temb, int temb_rows,
+                    const float* text, float* out, int B, void* stream);
+
+/* Both classifier-free-guidance branches of one sampling step in ONE pass
+ * (infer.py:79-80 / 85-86): sequences [0,B) are the unconditional branch
+ * (c = temb), [B,2B) the conditional one (c = temb + text); both read x[b].
+ *   temb (1,128); out_uncond, out_cond (B,64,30).  2*B <= max_seqs. */
+int t2s_dit_forward_cfg(t2s_dit* h, const float* x, const float* temb, const float* text,
+                        float* out_uncond, float* out_cond, int B, void* stream);
+
+/* Test tap: copy out the residual stream (S,480,128) the last forward left in the
+ * workspace (post block 3, before the final LayerNorm).  Used by tests to bisect. */
+int t2s_dit_read_stream(const t2s_dit* h, float* out, int S, void* stream);
+
+/* Fused softmax(q k^T / sqrt(32)) v for N=480, head_dim=32 (timm Attention.forward
+ * core; call site transformer.py:116).  q,k,v: (BH,480,32); o: (BH,480,32). */
+int t2s_attn_fwd(const float* q, const float* k, const float* v, float* o, int BH, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Diffusion backbones: model/backbone/DDPM.py, model/backbone/rectified_flow.py
+ * ------------------------------------------------------------------------ */
+/* DDPM.p_sample (DDPM.py:28-36) fused with the CFG combine (infer.py:87):
+ *   pred = u + cfg*(c-u);  x <- coef[t][0]*(x - coef[t][1]*pred) + coef[t][2]*z
+ * coef: (T,3) = {1/sqrt(alpha), (1-alpha)/sqrt(1-alpha_bar), sqrt(beta)} (host-built
+ * with the reference's own fp32 ops); t_index in [0,T).
+ * z = noise[n] if noise != NULL, else the library's Philox N(0,1) stream
+ * (seed, stream_id, row0 + row) -- see t2s_philox_normal.
+ * eps_c may be NULL (then pred = eps_u and cfg is ignored).  In-place on x. */
+int t2s_ddpm_step(float* x, const float* eps_u, const float* eps_c, const float* noise,
+                  const float* coef, int t_index, float cfg, uint64_t seed, uint32_t stream_id,
+                  uint32_t row0, int B, void* stream);
+/* DDPM.p_sample as the class exposes it (DDPM.py:28-36): per-row timestep t (B) int32,
+ * injected draws `noise` (B,64,30) (the host mirror supplies torch.randn like DDPM.py:35),
+ * out of place. */
+int t2s_ddpm_p_sample(const float* xt, const float* eps_hat, const int32_t* t, const float* noise,
+                      const float* coef, float* out, int B, void* stream);
+/* DDPM.loss / RectifiedFlow.loss = F.mse_loss(a, b) (DDPM.py:37-38, rectified_flow.py:13-16):
+ * mean over n elements into out[0]; fixed summation order (deterministic). */
+int t2s_mse(const float* a, const float* b, float* out, uint64_t n, void* stream);
+/* RectifiedFlow.euler (rectified_flow.py:5-7) fused with the CFG combine (infer.py:81-82):
+ *   x <- x + (u + cfg*(c-u)) * dt */
+int t2s_rf_step(float* x, const float* v_u, const float* v_c, float cfg, float dt, int B,
+                void* stream);
+/* DDPM.q_sample (DDPM.py:19-27): out = sqrt_ab[t[b]]*x0 + sqrt_1mab[t[b]]*eps.
+ * sqrt_ab, sqrt_1mab: (T) host-built tables; t: (B) int32. */
+int t2s_ddpm_q_sample(const float* x0, const float* eps, const int32_t* t, const float* sqrt_ab,
+                      const float* sqrt_1mab, float* out, int B, void* stream);
+/* RectifiedFlow.create_flow (rectified_flow.py:8-12): out = t*x1 + (1-t)*x0, t: (B) fp32. */
+int t2s_rf_create_flow(const float* x1, const float* x0, const float* t, float* out, int B,
+                       void* stream);
+/* N(0,1) draws, Philox4x32-10 + Box-Muller: element e of GLOBAL row r uses counter
+ * (e/4, r, stream_id, 0), key = seed; identical for any sharding of rows over GPUs.
+ * out: (n_rows,row_elems), row_elems % 4 == 0.  (replaces torch.randn at
+ * DDPM.py:35 / infer.py:75 in perf mode; parity mode injects noise instead.) */
+int t2s_philox_normal(float* out, uint64_t seed, uint32_t stream_id, uint32_t row0, int n_rows,
+                      int row_elems, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * LA-VAE codec: model/pretrained/vqvae.py:36-105 (Encoder, Decoder)
+ * ------------------------------------------------------------------------ */
+typedef struct t2s_vae t2s_vae;
+
+typedef struct t2s_vae_stack_weights { /* ResidualStack, vqvae.py:7-33 */
+    const float* conv3_w[4]; /* _layers.i._block.1.weight (res_hidden,hidden,3), no bias */
+    const float* conv1_w[4]; /* _layers.i._block.3.weight (hidden,res_hidden,1), no bias */
+} t2s_vae_stack_weights;
+
+typedef struct t2s_vae_weights {
+    int hidden;       /* block_hidden_size (128)   */
+    int res_hidden;   /* res_hidden_size (256)     */
+    int n_res_layers; /* num_residual_layers (2), <= 4 */
+    int emb;          /* embedding_dim (64)        */
+    /* decoder.* (may all be NULL for an encode-only handle) */
+    const float* dec_conv1_w; /* (hidden,emb,3) */
+    const float* dec_conv1_b;
+    t2s_vae_stack_weights dec_stack;
+    const float* dec_ct1_w; /* ConvTranspose1d (hidden,hidden/2,4) */
+    const float* dec_ct1_b;
+    const float* dec_ct2_w; /* ConvTranspose1d (hidden/2,1,4) */
+    const float* dec_ct2_b;
+    /* encoder.* (may all be NULL for a decode-only handle) */
+    const float* enc_conv1_w; /* (hidden/2,1,4) */
+    const float* enc_conv1_b;
+    const float* enc_conv2_w; /* (hidden,hidden/2,4) */
+    const float* enc_conv2_b;
+    const float* enc_conv3_w; /* (hidden,hidden,3) */
+    const float* enc_conv3_b;
+    t2s_vae_stack_weights enc_stack;
+    const float* enc_prevq_w; /* (emb,hidden,1) */
+    const float* enc_prevq_b;
+} t2s_vae_weights;
+
+int t2s_vae_create(const t2s_vae_weights* w, t2s_vae** out);
+void t2s_vae_destroy(t2s_vae* h);
+/* Decoder.forward, vqvae.py:97-105: z (B,64,30) -> recon (B,L), after (B,64,L/4) (may be NULL).
+ * L in {4..128}, L % 4 == 0.  (The host mirror applies torch.squeeze's shape rule.) */
+int t2s_vae_decode(t2s_vae* h, const float* z, float* recon, float* after, int B, int L,
+                   void* stream);
+/* Encoder.forward, vqvae.py:57-71: x (B,L) -> z (B,64,30), before (B,64,L/4) (may be NULL). */
+int t2s_vae_encode(t2s_vae* h, const float* x, float* z, float* before, int B, int L,
+                   void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Fused sampling loop: infer.py:75-95 (x_T -> steps x [2 DiT forwards + CFG +
+ * sampler update] -> LA-VAE decode), one hipGraph per step replayed `steps`
+ * times with a device-side step counter.
+ * ------------------------------------------------------------------------ */
+typedef struct t2s_sampler t2s_sampler;
+
+#define T2S_MODE_DDPM 0
+#define T2S_MODE_RF 1
+
+typedef struct t2s_sample_config {
+    int mode;            /* T2S_MODE_DDPM | T2S_MODE_RF                                  */
+    int steps;           /* infer.py --total_step                                         */
+    float cfg_scale;     /* infer.py --cfg_scale                                          */
+    int batch;           /* series per call on this GPU (2*batch <= dit max_seqs)         */
+    int length;          /* decoded series length L (24/48/96)                            */
+    int use_graph;       /* 1: capture one step into a hipGraph and replay it             */
+    uint64_t seed;       /* Philox key (perf mode)                                        */
+    uint32_t row0;       /* global index of this shard's first series (multi-GPU)         */
+    const float* ddpm_coef; /* HOST (steps,3), see t2s_ddpm_step; NULL for RF             */
+    const float* t_values;  /* HOST (steps): the t passed to the denoiser at loop index j:
+                               DDPM steps-1-j (infer.py:84), RF round(j/steps*steps)/steps (:78) */
+} t2s_sample_config;
+
+int t2s_sampler_create(t2s_dit* dit, t2s_vae* vae /* may be NULL: no decode */,
+                       const t2s_sample_config* cfg, t2s_sampler** out);
+void t2s_sampler_destroy(t2s_sampler* s);
+/* Run the whole loop.
+ *   x      (B,64,30) in: x_T (perf mode: fill it with t2s_philox_normal, stream_id 0xFFFFFFFF);
+ *          out: final latent
+ *   text   (B,128)
+ *   noise  (steps,B,64,30) injected per-step draws (parity mode) or NULL (Philox, perf mode)
+ *   series (B,L) decoded output, or NULL
+ *   trace0 (steps,L) or NULL: decode of row 0 after every step (infer.py:90-93)
+ */
+int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, const float* noise,
+                    float* series, float* trace0, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T2S_H */

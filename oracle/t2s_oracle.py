@@ -381,7 +381,7 @@ def device_normal(seed: int, stream: int, row0: int, n_rows: int, row_elems: int
     element e (0..row_elems) of GLOBAL row r draws from
       ctr = (e // 4, r, stream, 0), key = (seed_lo, seed_hi); lane = e % 4;
     lanes (0,1) and (2,3) are Box-Muller pairs:
-      u1 = (x_a + 1) * 2^-32   in (0,1],  u2 = x_b * 2^-32  in [0,1)
+      u1 = ((x_a >> 8) + 1) * 2^-24   in (0,1],  u2 = (x_b >> 8) * 2^-24  in [0,1)
       r = sqrt(-2 ln u1);  z_a = r cos(2 pi u2);  z_b = r sin(2 pi u2)
     ``stream`` is the sampling step index (x_T uses stream = 0xFFFFFFFF), so the
     draw is independent of how rows are sharded over GPUs.
@@ -398,12 +398,10 @@ def device_normal(seed: int, stream: int, row0: int, n_rows: int, row_elems: int
     key[..., 1] = np.uint32((seed >> 32) & 0xFFFFFFFF)
     x = philox4x32_10(ctr, key)
     out = np.empty((n_rows, q, 4), dtype=np.float32)
-    two_m32 = np.float32(2.3283064365386963e-10)
     for a, b in ((0, 1), (2, 3)):
-        u1 = (x[..., a].astype(np.float64) + 1.0) * 2.0 ** -32
-        u2 = x[..., b].astype(np.float64) * 2.0 ** -32
+        u1 = ((x[..., a] >> np.uint32(8)).astype(np.float64) + 1.0) * 2.0 ** -24
+        u2 = (x[..., b] >> np.uint32(8)).astype(np.float64) * 2.0 ** -24
         rad = np.sqrt(-2.0 * np.log(u1))
         out[..., a] = (rad * np.cos(2.0 * np.pi * u2)).astype(np.float32)
         out[..., b] = (rad * np.sin(2.0 * np.pi * u2)).astype(np.float32)
-    del two_m32
     return out.reshape(n_rows, row_elems)

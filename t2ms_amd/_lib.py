@@ -1,0 +1,137 @@
+"""ctypes binding of libt2s_hip.so (C ABI: include/t2s.h).
+
+The HIP library IS the product: there is no CPU or PyTorch fallback.  If the
+shared object is missing, or a tensor is not on a GPU, the call fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libt2s_hip.so")
+
+N_BLOCKS = 4
+LAT_C, LAT_W, LAT = 64, 30, 1920
+D_MODEL, N_TOK = 128, 480
+
+c_float_p = C.c_void_p  # device pointers travel as opaque addresses
+
+
+class DitBlockWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ada_w", "ada_b")]
+
+
+class DitWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("conv_w", "conv_b", "patch_w", "patch_b", "pos_embed", "ln_w", "ln_b", "out_w", "out_b",
+                 "time_freqs")] + [("blk", DitBlockWeights * N_BLOCKS)]
+
+
+class VaeStackWeights(C.Structure):
+    _fields_ = [("conv3_w", C.c_void_p * 4), ("conv1_w", C.c_void_p * 4)]
+
+
+class VaeWeights(C.Structure):
+    _fields_ = [("hidden", C.c_int), ("res_hidden", C.c_int), ("n_res_layers", C.c_int), ("emb", C.c_int),
+                ("dec_conv1_w", C.c_void_p), ("dec_conv1_b", C.c_void_p), ("dec_stack", VaeStackWeights),
+                ("dec_ct1_w", C.c_void_p), ("dec_ct1_b", C.c_void_p), ("dec_ct2_w", C.c_void_p),
+                ("dec_ct2_b", C.c_void_p),
+                ("enc_conv1_w", C.c_void_p), ("enc_conv1_b", C.c_void_p), ("enc_conv2_w", C.c_void_p),
+                ("enc_conv2_b", C.c_void_p), ("enc_conv3_w", C.c_void_p), ("enc_conv3_b", C.c_void_p),
+                ("enc_stack", VaeStackWeights), ("enc_prevq_w", C.c_void_p), ("enc_prevq_b", C.c_void_p)]
+
+
+class SampleConfig(C.Structure):
+    _fields_ = [("mode", C.c_int), ("steps", C.c_int), ("cfg_scale", C.c_float), ("batch", C.c_int),
+                ("length", C.c_int), ("use_graph", C.c_int), ("seed", C.c_uint64), ("row0", C.c_uint32),
+                ("ddpm_coef", C.c_void_p), ("t_values", C.c_void_p)]
+
+
+MODE_DDPM, MODE_RF = 0, 1
+
+# every symbol include/t2s.h declares: (name, restype, argtypes)
+_VP, _I, _F, _U64, _U32 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32
+SYMBOLS = {
+    "t2s_last_error": (C.c_char_p, []),
+    "t2s_version": (C.c_char_p, []),
+    "t2s_dit_create": (_I, [C.POINTER(DitWeights), _I, C.POINTER(_VP)]),
+    "t2s_dit_update_weights": (_I, [_VP, C.POINTER(DitWeights), _VP]),
+    "t2s_dit_destroy": (None, [_VP]),
+    "t2s_dit_max_seqs": (_I, [_VP]),
+    "t2s_time_embedding": (_I, [_VP, _VP, _VP, _I, _VP]),
+    "t2s_dit_forward": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP]),
+    "t2s_dit_forward_cfg": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
+    "t2s_dit_read_stream": (_I, [_VP, _VP, _I, _VP]),
+    "t2s_attn_fwd": (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
+    "t2s_ddpm_step": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _F, _U64, _U32, _U32, _I, _VP]),
+    "t2s_ddpm_p_sample": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
+    "t2s_mse": (_I, [_VP, _VP, _VP, _U64, _VP]),
+    "t2s_rf_step": (_I, [_VP, _VP, _VP, _F, _F, _I, _VP]),
+    "t2s_ddpm_q_sample": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
+    "t2s_rf_create_flow": (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
+    "t2s_philox_normal": (_I, [_VP, _U64, _U32, _U32, _I, _I, _VP]),
+    "t2s_vae_create": (_I, [C.POINTER(VaeWeights), C.POINTER(_VP)]),
+    "t2s_vae_destroy": (None, [_VP]),
+    "t2s_vae_decode": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP]),
+    "t2s_vae_encode": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP]),
+    "t2s_sampler_create": (_I, [_VP, _VP, C.POINTER(SampleConfig), C.POINTER(_VP)]),
+    "t2s_sampler_destroy": (None, [_VP]),
+    "t2s_sampler_run": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class T2SError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load libt2s_hip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise T2SError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C t2ms_amd/csrc` (hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)  # AttributeError if the .so does not export it
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().t2s_last_error().decode("utf-8", "replace")
+        raise T2SError(f"{what or 't2s call'} failed (rc={rc}): {msg}")
+
+
+def dev_ptr(t: Optional[torch.Tensor], name: str = "tensor", dtype=torch.float32) -> Optional[int]:
+    """Raw device address of a contiguous CUDA(HIP) tensor; None passes NULL."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise T2SError(f"{name} must live on a GPU (got device {t.device}); the HIP path has no CPU fallback")
+    if t.dtype != dtype:
+        raise T2SError(f"{name} must be {dtype} (got {t.dtype})")
+    if not t.is_contiguous():
+        raise T2SError(f"{name} must be contiguous")
+    return t.data_ptr()
+
+
+def as_f32(t: torch.Tensor) -> torch.Tensor:
+    """fp32 contiguous view/copy on the tensor's own (GPU) device."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream

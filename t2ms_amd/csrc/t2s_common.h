@@ -1,0 +1,78 @@
+// Internal helpers shared by the HIP translation units of libt2s_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/t2s.h"
+
+namespace t2s {
+
+void set_error(const char* fmt, ...);
+
+#define T2S_HIP_CHECK(expr)                                                                    \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            ::t2s::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,  \
+                             __LINE__);                                                        \
+            return T2S_E_HIP;                                                                  \
+        }                                                                                      \
+    } while (0)
+
+#define T2S_REQUIRE(cond, ...)                                                                 \
+    do {                                                                                       \
+        if (!(cond)) {                                                                         \
+            ::t2s::set_error(__VA_ARGS__);                                                     \
+            return T2S_E_INVALID;                                                              \
+        }                                                                                      \
+    } while (0)
+
+#define T2S_LAUNCH_CHECK()                                                                     \
+    do {                                                                                       \
+        hipError_t _e = hipGetLastError();                                                     \
+        if (_e != hipSuccess) {                                                                \
+            ::t2s::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e),        \
+                             __FILE__, __LINE__);                                              \
+            return T2S_E_HIP;                                                                  \
+        }                                                                                      \
+    } while (0)
+
+constexpr int D = T2S_D_MODEL;      // 128
+constexpr int NTOK = T2S_N_TOK;     // 480
+constexpr int NH = T2S_N_HEADS;     // 4
+constexpr int DH = T2S_HEAD_DIM;    // 32
+constexpr int NBLK = T2S_N_BLOCKS;  // 4
+constexpr int LATC = T2S_LAT_C;     // 64
+constexpr int LATW = T2S_LAT_W;     // 30
+constexpr int LAT = T2S_LAT_ELEMS;  // 1920
+constexpr int MODW = 6 * D;         // 768 adaLN outputs per block
+constexpr int MODROW = NBLK * MODW; // 3072 per sequence: [blk][shift1,scale1,gate1,shift2,scale2,gate2][128]
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// v_mfma_f32_32x32x2_f32: D(32x32) += A(32x2) * B(2x32); lane l supplies A[l&31][l>>5] and
+// B[l>>5][l&31]; result register r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ float xhalf(float v) {  // value held by lane ^ 32
+    return __shfl_xor(v, 32, 64);
+}
+
+// Weight packing for the B operand (W is a torch Linear weight (N,K) row-major, the GEMM is
+// x @ W^T).  For n-tile nt (32 outputs) and k-group g (8 inputs) lane l owns the float4
+//   W[32*nt + (l&31)][8*g + 4*(l>>5) + 0..3]
+// stored at packed[((nt * (K/8)) + g) * 64 + l] so that one wave-level load is a contiguous
+// 1 KiB.  MFMA e (0..3) of the group then contracts k-pair {8g+e, 8g+4+e}; the A operand
+// uses the same assignment (float4 at A[row][8g + 4*(l>>5)]).
+__host__ __device__ inline size_t packed_index(int n, int k, int K) {
+    int nt = n >> 5, j = n & 31, g = k >> 3, h = (k >> 2) & 1, e = k & 3;
+    return ((((size_t)nt * (K >> 3) + g) * 64) + (h * 32 + j)) * 4 + e;
+}
+
+}  // namespace t2s

@@ -1,0 +1,415 @@
+// Diffusion backbones and the fused sampling loop for MI355X.
+//   DDPM.p_sample / q_sample      reference model/backbone/DDPM.py:19-36
+//   RectifiedFlow.euler / flow    reference model/backbone/rectified_flow.py:5-12
+//   CFG loop                      reference infer.py:75-95
+// One sampling step (2B-sequence DiT forward + CFG combine + sampler update) is captured once
+// into a hipGraph and replayed `steps` times; everything that changes from step to step
+// (time-embedding row, DDPM coefficients, noise stream / injected-noise slice) is looked up on
+// the device through a step counter that the last node of the graph advances.
+#include <vector>
+
+#include "t2s_common.h"
+
+struct t2s_dit;
+struct t2s_vae;
+
+namespace t2s {
+int dit_forward_cfg_step(t2s_dit* h, const float* x, const float* temb_table, const int* step_ptr,
+                         const float* text, float* out_u, float* out_c, int B, hipStream_t st);
+
+// ---------------------------------------------------------------- Philox4x32-10 + Box-Muller
+struct u32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
+        u32x4 n;
+        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+        n.y = (uint32_t)p1;
+        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+        n.w = (uint32_t)p0;
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// 4 N(0,1) draws for quad `quad` of global row `row` in stream `stream_id`
+__device__ __forceinline__ f32x4 normal4(uint64_t seed, uint32_t stream_id, uint32_t row, uint32_t quad) {
+    const u32x4 r = philox4x32_10(u32x4{quad, row, stream_id, 0u}, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float two_pi = 6.283185307179586f;
+    const float two_m24 = 1.0f / 16777216.0f;
+    // 24-bit uniforms (exact in fp32): u1 in (0,1], u2 in [0,1)
+    const float u1a = ((float)(r.x >> 8) + 1.0f) * two_m24;
+    const float u1b = ((float)(r.z >> 8) + 1.0f) * two_m24;
+    const float u2a = (float)(r.y >> 8) * two_m24;
+    const float u2b = (float)(r.w >> 8) * two_m24;
+    const float ra = sqrtf(-2.0f * logf(u1a));
+    const float rb = sqrtf(-2.0f * logf(u1b));
+    f32x4 z;
+    z.x = ra * cosf(two_pi * u2a);
+    z.y = ra * sinf(two_pi * u2a);
+    z.z = rb * cosf(two_pi * u2b);
+    z.w = rb * sinf(two_pi * u2b);
+    return z;
+}
+
+__global__ void philox_normal_kernel(float* __restrict__ out, uint64_t seed, uint32_t stream_id,
+                                     uint32_t row0, int n_rows, int quads_per_row) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * quads_per_row) return;
+    const int row = idx / quads_per_row, quad = idx - row * quads_per_row;
+    reinterpret_cast<f32x4*>(out)[idx] = normal4(seed, stream_id, row0 + (uint32_t)row, (uint32_t)quad);
+}
+
+// ---------------------------------------------------------------- sampler update kernels
+struct StepArgs {
+    float* x;             // (B,1920) in place
+    const float* eps_u;   // (B,1920)
+    const float* eps_c;   // (B,1920) or NULL
+    const float* noise;   // injected draws: (steps,B,1920) indexed by step, or (B,1920) if step_ptr NULL
+    const float* coef;    // DEVICE (T,3)
+    const int* step_ptr;  // device loop index j, or NULL (then t_index / stream_id are immediate)
+    int steps;            // T (t = steps-1-j when step_ptr != NULL)
+    int t_index;
+    float cfg;
+    uint64_t seed;
+    uint32_t stream_id;
+    uint32_t row0;
+    int B;
+};
+
+__global__ __launch_bounds__(256) void ddpm_step_kernel(const StepArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one float4 (quad) per thread
+    constexpr int QPR = LAT / 4;
+    if (idx >= a.B * QPR) return;
+    int t = a.t_index;
+    uint32_t sid = a.stream_id;
+    const float* noise = a.noise;
+    if (a.step_ptr) {
+        const int j = *a.step_ptr;
+        t = a.steps - 1 - j;
+        sid = (uint32_t)j;
+        if (noise) noise += (size_t)j * a.B * LAT;
+    }
+    const float c0 = a.coef[t * 3 + 0], c1 = a.coef[t * 3 + 1], c2 = a.coef[t * 3 + 2];
+    const f32x4 x = reinterpret_cast<const f32x4*>(a.x)[idx];
+    const f32x4 u = reinterpret_cast<const f32x4*>(a.eps_u)[idx];
+    f32x4 pred = u;
+    if (a.eps_c) {
+        const f32x4 c = reinterpret_cast<const f32x4*>(a.eps_c)[idx];
+        pred = u + a.cfg * (c - u);
+    }
+    f32x4 z;
+    if (noise) {
+        z = reinterpret_cast<const f32x4*>(noise)[idx];
+    } else {
+        const int row = idx / QPR, quad = idx - row * QPR;
+        z = normal4(a.seed, sid, a.row0 + (uint32_t)row, (uint32_t)quad);
+    }
+    const f32x4 mean = c0 * (x - c1 * pred);
+    reinterpret_cast<f32x4*>(a.x)[idx] = mean + c2 * z;
+}
+
+__global__ __launch_bounds__(256) void rf_step_kernel(float* __restrict__ x, const float* __restrict__ vu,
+                                                      const float* __restrict__ vc, float cfg, float dt,
+                                                      int n4) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n4) return;
+    const f32x4 u = reinterpret_cast<const f32x4*>(vu)[idx];
+    f32x4 pred = u;
+    if (vc) pred = u + cfg * (reinterpret_cast<const f32x4*>(vc)[idx] - u);
+    f32x4 xv = reinterpret_cast<f32x4*>(x)[idx];
+    reinterpret_cast<f32x4*>(x)[idx] = xv + pred * dt;
+}
+
+__global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ eps,
+                                                       const int32_t* __restrict__ t, const float* __restrict__ sab,
+                                                       const float* __restrict__ s1m, float* __restrict__ out, int B) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int QPR = LAT / 4;
+    if (idx >= B * QPR) return;
+    const int tt = t[idx / QPR];
+    const f32x4 a = reinterpret_cast<const f32x4*>(x0)[idx];
+    const f32x4 e = reinterpret_cast<const f32x4*>(eps)[idx];
+    reinterpret_cast<f32x4*>(out)[idx] = sab[tt] * a + s1m[tt] * e;
+}
+
+__global__ __launch_bounds__(256) void create_flow_kernel(const float* __restrict__ x1, const float* __restrict__ x0,
+                                                          const float* __restrict__ t, float* __restrict__ out, int B) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int QPR = LAT / 4;
+    if (idx >= B * QPR) return;
+    const float tt = t[idx / QPR];
+    const f32x4 a = reinterpret_cast<const f32x4*>(x1)[idx];
+    const f32x4 b = reinterpret_cast<const f32x4*>(x0)[idx];
+    reinterpret_cast<f32x4*>(out)[idx] = tt * a + (1.0f - tt) * b;
+}
+
+// DDPM.p_sample with a per-row timestep (the class API allows t to differ per row), out of place
+__global__ __launch_bounds__(256) void p_sample_rows_kernel(const float* __restrict__ xt, const float* __restrict__ eh,
+                                                            const int32_t* __restrict__ t, const float* __restrict__ noise,
+                                                            const float* __restrict__ coef, float* __restrict__ out, int B) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int QPR = LAT / 4;
+    if (idx >= B * QPR) return;
+    const int tt = t[idx / QPR];
+    const float c0 = coef[tt * 3 + 0], c1 = coef[tt * 3 + 1], c2 = coef[tt * 3 + 2];
+    const f32x4 x = reinterpret_cast<const f32x4*>(xt)[idx];
+    const f32x4 e = reinterpret_cast<const f32x4*>(eh)[idx];
+    const f32x4 z = reinterpret_cast<const f32x4*>(noise)[idx];
+    reinterpret_cast<f32x4*>(out)[idx] = c0 * (x - c1 * e) + c2 * z;
+}
+
+// F.mse_loss (mean over all elements): ONE workgroup, fixed summation order -> deterministic
+__global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                   float* __restrict__ out, size_t n) {
+    __shared__ float part[16];
+    float acc = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += 1024) {
+        const float d = a[i] - b[i];
+        acc += d * d;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < 16; ++i) s += part[i];
+        *out = s / (float)n;
+    }
+}
+
+__global__ void set_step_kernel(int* step, int value, int delta) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *step = delta ? *step + delta : value;
+}
+
+}  // namespace t2s
+
+using namespace t2s;
+
+extern "C" int t2s_time_embedding(const t2s_dit* h, const float* t, float* out, int B, void* stream);
+
+// ---------------------------------------------------------------- C ABI: single-step entry points
+extern "C" int t2s_philox_normal(float* out, uint64_t seed, uint32_t stream_id, uint32_t row0, int n_rows,
+                                 int row_elems, void* stream) {
+    T2S_REQUIRE(out && n_rows > 0 && row_elems > 0 && row_elems % 4 == 0,
+                "t2s_philox_normal: bad argument (n_rows=%d,row_elems=%d; row_elems %% 4 must be 0)", n_rows, row_elems);
+    const int q = row_elems / 4, total = n_rows * q;
+    philox_normal_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(out, seed, stream_id, row0, n_rows, q);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+extern "C" int t2s_ddpm_step(float* x, const float* eps_u, const float* eps_c, const float* noise,
+                             const float* coef, int t_index, float cfg, uint64_t seed, uint32_t stream_id,
+                             uint32_t row0, int B, void* stream) {
+    T2S_REQUIRE(x && eps_u && coef, "t2s_ddpm_step: NULL argument");
+    T2S_REQUIRE(B > 0 && t_index >= 0, "t2s_ddpm_step: B=%d t_index=%d", B, t_index);
+    StepArgs a{};
+    a.x = x; a.eps_u = eps_u; a.eps_c = eps_c; a.noise = noise; a.coef = coef; a.step_ptr = nullptr;
+    a.t_index = t_index; a.cfg = cfg; a.seed = seed; a.stream_id = stream_id; a.row0 = row0; a.B = B;
+    const int total = B * (LAT / 4);
+    ddpm_step_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(a);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+extern "C" int t2s_rf_step(float* x, const float* v_u, const float* v_c, float cfg, float dt, int B, void* stream) {
+    T2S_REQUIRE(x && v_u && B > 0, "t2s_rf_step: bad argument");
+    const int n4 = B * (LAT / 4);
+    rf_step_kernel<<<(n4 + 255) / 256, 256, 0, (hipStream_t)stream>>>(x, v_u, v_c, cfg, dt, n4);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+extern "C" int t2s_ddpm_q_sample(const float* x0, const float* eps, const int32_t* t, const float* sqrt_ab,
+                                 const float* sqrt_1mab, float* out, int B, void* stream) {
+    T2S_REQUIRE(x0 && eps && t && sqrt_ab && sqrt_1mab && out && B > 0, "t2s_ddpm_q_sample: bad argument");
+    const int total = B * (LAT / 4);
+    q_sample_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(x0, eps, t, sqrt_ab, sqrt_1mab, out, B);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+extern "C" int t2s_ddpm_p_sample(const float* xt, const float* eps_hat, const int32_t* t, const float* noise,
+                                 const float* coef, float* out, int B, void* stream) {
+    T2S_REQUIRE(xt && eps_hat && t && noise && coef && out && B > 0, "t2s_ddpm_p_sample: bad argument");
+    const int total = B * (LAT / 4);
+    p_sample_rows_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(xt, eps_hat, t, noise, coef, out, B);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+extern "C" int t2s_mse(const float* a, const float* b, float* out, uint64_t n, void* stream) {
+    T2S_REQUIRE(a && b && out && n > 0, "t2s_mse: bad argument");
+    mse_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(a, b, out, (size_t)n);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+extern "C" int t2s_rf_create_flow(const float* x1, const float* x0, const float* t, float* out, int B, void* stream) {
+    T2S_REQUIRE(x1 && x0 && t && out && B > 0, "t2s_rf_create_flow: bad argument");
+    const int total = B * (LAT / 4);
+    create_flow_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(x1, x0, t, out, B);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+// ---------------------------------------------------------------- fused sampling loop
+struct t2s_sampler {
+    t2s_dit* dit = nullptr;
+    t2s_vae* vae = nullptr;
+    t2s_sample_config cfg{};
+    float* temb_table = nullptr;  // (steps,128)
+    float* coef = nullptr;        // (steps,3)  DDPM only
+    float* eps_u = nullptr;       // (B,1920)
+    float* eps_c = nullptr;
+    float* tvals = nullptr;       // (steps)
+    int* step = nullptr;          // device loop index
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    // pointers the captured graph was built for
+    float* g_x = nullptr;
+    const float* g_text = nullptr;
+    const float* g_noise = nullptr;
+};
+
+namespace {
+
+int enqueue_step(t2s_sampler* s, float* x, const float* text, const float* noise, hipStream_t st) {
+    const t2s_sample_config& c = s->cfg;
+    int rc = dit_forward_cfg_step(s->dit, x, s->temb_table, s->step, text, s->eps_u, s->eps_c, c.batch, st);
+    if (rc != T2S_OK) return rc;
+    if (c.mode == T2S_MODE_DDPM) {
+        StepArgs a{};
+        a.x = x; a.eps_u = s->eps_u; a.eps_c = s->eps_c; a.noise = noise; a.coef = s->coef;
+        a.step_ptr = s->step; a.steps = c.steps; a.cfg = c.cfg_scale; a.seed = c.seed; a.row0 = c.row0;
+        a.B = c.batch;
+        const int total = c.batch * (LAT / 4);
+        ddpm_step_kernel<<<(total + 255) / 256, 256, 0, st>>>(a);
+    } else {
+        const int n4 = c.batch * (LAT / 4);
+        rf_step_kernel<<<(n4 + 255) / 256, 256, 0, st>>>(x, s->eps_u, s->eps_c, c.cfg_scale, 1.0f / (float)c.steps, n4);
+    }
+    T2S_LAUNCH_CHECK();
+    set_step_kernel<<<1, 64, 0, st>>>(s->step, 0, 1);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+void drop_graph(t2s_sampler* s) {
+    if (s->exec) (void)hipGraphExecDestroy(s->exec);
+    if (s->graph) (void)hipGraphDestroy(s->graph);
+    s->exec = nullptr;
+    s->graph = nullptr;
+}
+
+}  // namespace
+
+extern "C" int t2s_dit_max_seqs(const t2s_dit* h);
+
+extern "C" int t2s_sampler_create(t2s_dit* dit, t2s_vae* vae, const t2s_sample_config* cfg, t2s_sampler** out) {
+    T2S_REQUIRE(dit && cfg && out, "t2s_sampler_create: NULL argument");
+    T2S_REQUIRE(cfg->mode == T2S_MODE_DDPM || cfg->mode == T2S_MODE_RF, "t2s_sampler_create: mode=%d", cfg->mode);
+    T2S_REQUIRE(cfg->steps > 0 && cfg->steps <= 100000, "t2s_sampler_create: steps=%d", cfg->steps);
+    T2S_REQUIRE(cfg->batch > 0 && 2 * cfg->batch <= t2s_dit_max_seqs(dit),
+                "t2s_sampler_create: batch=%d needs 2*batch <= dit max_seqs=%d", cfg->batch, t2s_dit_max_seqs(dit));
+    T2S_REQUIRE(cfg->t_values, "t2s_sampler_create: t_values is NULL");
+    T2S_REQUIRE(cfg->mode != T2S_MODE_DDPM || cfg->ddpm_coef, "t2s_sampler_create: DDPM needs ddpm_coef");
+    T2S_REQUIRE(!vae || (cfg->length >= 4 && cfg->length % 4 == 0 && cfg->length <= 128),
+                "t2s_sampler_create: length=%d unsupported", cfg->length);
+    t2s_sampler* s = new t2s_sampler();
+    s->dit = dit; s->vae = vae; s->cfg = *cfg;
+    s->cfg.ddpm_coef = nullptr; s->cfg.t_values = nullptr;  // host pointers are not retained
+    const size_t B = (size_t)cfg->batch, T = (size_t)cfg->steps;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    alloc((void**)&s->temb_table, T * D * sizeof(float));
+    alloc((void**)&s->coef, T * 3 * sizeof(float));
+    alloc((void**)&s->eps_u, B * LAT * sizeof(float));
+    alloc((void**)&s->eps_c, B * LAT * sizeof(float));
+    alloc((void**)&s->tvals, T * sizeof(float));
+    alloc((void**)&s->step, 64);
+    if (e == hipSuccess) e = hipMemcpy(s->tvals, cfg->t_values, T * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && cfg->mode == T2S_MODE_DDPM)
+        e = hipMemcpy(s->coef, cfg->ddpm_coef, T * 3 * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        set_error("t2s_sampler_create: allocation/upload failed: %s", hipGetErrorString(e));
+        t2s_sampler_destroy(s);
+        return T2S_E_HIP;
+    }
+    // time-embedding table for every loop index (transformer.py:30-40 applied to t_values)
+    int rc = t2s_time_embedding(dit, s->tvals, s->temb_table, cfg->steps, nullptr);
+    if (rc == T2S_OK && hipStreamSynchronize(nullptr) != hipSuccess) {
+        set_error("t2s_sampler_create: time-embedding table failed");
+        rc = T2S_E_HIP;
+    }
+    if (rc != T2S_OK) {
+        t2s_sampler_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return T2S_OK;
+}
+
+extern "C" void t2s_sampler_destroy(t2s_sampler* s) {
+    if (!s) return;
+    drop_graph(s);
+    void* bufs[] = {s->temb_table, s->coef, s->eps_u, s->eps_c, s->tvals, s->step};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    delete s;
+}
+
+extern "C" int t2s_vae_decode(t2s_vae* h, const float* z, float* recon, float* after, int B, int L, void* stream);
+
+extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, const float* noise, float* series,
+                               float* trace0, void* stream) {
+    T2S_REQUIRE(s && x && text, "t2s_sampler_run: NULL argument");
+    T2S_REQUIRE(!series || s->vae, "t2s_sampler_run: series requested but the sampler has no VAE");
+    T2S_REQUIRE(!trace0 || s->vae, "t2s_sampler_run: trace requested but the sampler has no VAE");
+    hipStream_t st = (hipStream_t)stream;
+    const t2s_sample_config& c = s->cfg;
+    int rc;
+    set_step_kernel<<<1, 64, 0, st>>>(s->step, 0, 0);
+    T2S_LAUNCH_CHECK();
+    const bool graph_ok = c.use_graph && !trace0 && st != nullptr;
+    if (graph_ok) {
+        if (!s->exec || s->g_x != x || s->g_text != text || s->g_noise != noise) {
+            drop_graph(s);
+            T2S_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            rc = enqueue_step(s, x, text, noise, st);
+            hipError_t e = hipStreamEndCapture(st, &s->graph);
+            if (rc != T2S_OK) {
+                drop_graph(s);
+                return rc;
+            }
+            if (e != hipSuccess) {
+                set_error("t2s_sampler_run: hipStreamEndCapture failed: %s", hipGetErrorString(e));
+                drop_graph(s);
+                return T2S_E_HIP;
+            }
+            T2S_HIP_CHECK(hipGraphInstantiate(&s->exec, s->graph, nullptr, nullptr, 0));
+            s->g_x = x; s->g_text = text; s->g_noise = noise;
+        }
+        for (int j = 0; j < c.steps; ++j) T2S_HIP_CHECK(hipGraphLaunch(s->exec, st));
+    } else {
+        for (int j = 0; j < c.steps; ++j) {
+            if ((rc = enqueue_step(s, x, text, noise, st)) != T2S_OK) return rc;
+            if (trace0) {
+                // infer.py:90-93: decode row 0 of the first batch after every step
+                if ((rc = t2s_vae_decode(s->vae, x, trace0 + (size_t)j * c.length, nullptr, 1, c.length, st)) != T2S_OK)
+                    return rc;
+            }
+        }
+    }
+    if (series) {
+        if ((rc = t2s_vae_decode(s->vae, x, series, nullptr, c.batch, c.length, st)) != T2S_OK) return rc;
+    }
+    return T2S_OK;
+}

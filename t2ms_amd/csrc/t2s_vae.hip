@@ -1,0 +1,341 @@
+// LA-VAE codec (reference model/pretrained/vqvae.py:36-105) for MI355X.
+//
+// The codec runs once per batch (15-17 MFLOP per series against 1.95 TFLOP for the
+// 1000-step loop), so it is a single launch with ONE workgroup per series: the whole
+// activation stack of a series (<= 256 channels x <= 32 positions) stays in LDS from the
+// latent to the decoded samples, weights (2.7 MB fp32) stream from L2.  Exact fp32 VALU.
+#include "t2s_common.h"
+
+namespace t2s {
+
+constexpr int VAE_TMAX = 32;   // positions after the stride-4 stem: L/4 <= 32  (L <= 128)
+constexpr int VAE_CMAX = 256;  // res_hidden
+constexpr int VAE_THREADS = 256;
+
+struct VaeDev {  // device copies in the reference layouts
+    int hidden, res_hidden, n_res, emb;
+    const float *dec_conv1_w, *dec_conv1_b, *dec_ct1_w, *dec_ct1_b, *dec_ct2_w, *dec_ct2_b;
+    const float *dec_c3[4], *dec_c1[4];
+    const float *enc_conv1_w, *enc_conv1_b, *enc_conv2_w, *enc_conv2_b, *enc_conv3_w, *enc_conv3_b;
+    const float *enc_c3[4], *enc_c1[4];
+    const float *enc_prevq_w, *enc_prevq_b;
+};
+
+// out[co][t] (+)= b[co] + sum_{ci,kk} W[co][ci][kk] * in[ci][t*STRIDE + kk - pad]   (Conv1d)
+// Buffers are LDS, row stride `ld`.  RELU_OUT applies to the final value; ACCUM adds into out.
+template <int KS, int STRIDE, bool RELU_OUT, bool ACCUM>
+__device__ void conv1d_lds(const float* in, int Cin, int Tin, float* out, int Cout, int Tout,
+                           const float* __restrict__ W, const float* __restrict__ bias, int pad,
+                           int ld_in, int ld_out) {
+    for (int o = threadIdx.x; o < Cout * Tout; o += VAE_THREADS) {
+        const int co = o / Tout, t = o - co * Tout;
+        float acc = bias ? bias[co] : 0.f;
+        const float* w = W + (size_t)co * Cin * KS;
+        for (int ci = 0; ci < Cin; ++ci) {
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int ti = t * STRIDE + kk - pad;
+                if (ti >= 0 && ti < Tin) acc += w[ci * KS + kk] * in[ci * ld_in + ti];
+            }
+        }
+        if (ACCUM) acc += out[co * ld_out + t];
+        if (RELU_OUT) acc = fmaxf(acc, 0.f);
+        out[co * ld_out + t] = acc;
+    }
+}
+
+// ConvTranspose1d(k=4, stride=2, padding=1): W is (Cin, Cout, 4);
+// out[co][t] = b[co] + sum_{ci,kk : t = 2 i - 1 + kk} in[ci][i] * W[ci][co][kk]
+template <bool RELU_OUT>
+__device__ void convT1d_k4s2_lds(const float* in, int Cin, int Tin, float* out, int Cout,
+                                 const float* __restrict__ W, const float* __restrict__ bias,
+                                 int ld_in, int ld_out) {
+    const int Tout = 2 * Tin;
+    for (int o = threadIdx.x; o < Cout * Tout; o += VAE_THREADS) {
+        const int co = o / Tout, t = o - co * Tout;
+        float acc = bias[co];
+        // t+1-kk even  ->  kk has the parity of t+1
+        const int k0 = (t + 1) & 1;
+        for (int ci = 0; ci < Cin; ++ci) {
+#pragma unroll
+            for (int kk2 = 0; kk2 < 2; ++kk2) {
+                const int kk = k0 + 2 * kk2;
+                const int i = (t + 1 - kk) >> 1;
+                if (t + 1 - kk >= 0 && i < Tin) acc += in[ci * ld_in + i] * W[((size_t)ci * Cout + co) * 4 + kk];
+            }
+        }
+        if (RELU_OUT) acc = fmaxf(acc, 0.f);
+        out[co * ld_out + t] = acc;
+    }
+}
+
+// F.interpolate(mode='linear', align_corners=True) along the last axis, [C][Tin] -> [C][Tout]
+__device__ void interp_linear_ac(const float* in, int C, int Tin, int ld_in, float* out, int Tout,
+                                 int ld_out) {
+    const float scale = Tout > 1 ? (float)(Tin - 1) / (float)(Tout - 1) : 0.f;
+    for (int o = threadIdx.x; o < C * Tout; o += VAE_THREADS) {
+        const int c = o / Tout, t = o - c * Tout;
+        const float real = scale * (float)t;
+        const int i0 = (int)real;
+        const int i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
+        const float l1 = real - (float)i0;
+        const float l0 = 1.0f - l1;
+        out[c * ld_out + t] = l0 * in[c * ld_in + i0] + l1 * in[c * ld_in + i1];
+    }
+}
+
+__device__ void relu_inplace(float* x, int C, int T, int ld) {
+    for (int o = threadIdx.x; o < C * T; o += VAE_THREADS) {
+        const int c = o / T, t = o - c * T;
+        x[c * ld + t] = fmaxf(x[c * ld + t], 0.f);
+    }
+}
+
+// ResidualStack (vqvae.py:7-33).  nn.ReLU(True) mutates the block input in place, so the skip
+// path carries relu(x): x <- relu(x); x <- x + conv1x1(relu(conv3(x))); finally relu(x).
+__device__ void residual_stack(float* x, float* tmp, int hidden, int res_hidden, int n_res, int T,
+                               const float* const* c3, const float* const* c1, int ld) {
+    for (int l = 0; l < n_res; ++l) {
+        relu_inplace(x, hidden, T, ld);
+        __syncthreads();
+        conv1d_lds<3, 1, true, false>(x, hidden, T, tmp, res_hidden, T, c3[l], nullptr, 1, ld, ld);
+        __syncthreads();
+        conv1d_lds<1, 1, false, true>(tmp, res_hidden, T, x, hidden, T, c1[l], nullptr, 0, ld, ld);
+        __syncthreads();
+    }
+    relu_inplace(x, hidden, T, ld);
+    __syncthreads();
+}
+
+constexpr int LD = VAE_TMAX + 1;  // LDS row stride (floats)
+constexpr int VAE_LDS_FLOATS = 2 * VAE_CMAX * LD + 128 * 4 + 64 * 2 * VAE_TMAX;
+
+// Decoder.forward (vqvae.py:97-105)
+__global__ __launch_bounds__(VAE_THREADS) void vae_decode_kernel(const VaeDev w,
+                                                                 const float* __restrict__ z,
+                                                                 float* __restrict__ recon,
+                                                                 float* __restrict__ after, int L) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* bufA = smem;                   // [<=256][LD]
+    float* bufB = smem + VAE_CMAX * LD;   // [<=256][LD]
+    float* wide = bufB + VAE_CMAX * LD;   // [hidden/2][2T] for the first transposed conv
+    const int b = blockIdx.x;
+    const int T = L / 4;
+    // latent (64,30) -> bufB (row stride LD covers 30 <= 32)
+    for (int o = threadIdx.x; o < w.emb * LATW; o += VAE_THREADS) {
+        const int c = o / LATW, t = o - c * LATW;
+        bufB[c * LD + t] = z[(size_t)b * w.emb * LATW + o];
+    }
+    __syncthreads();
+    interp_linear_ac(bufB, w.emb, LATW, LD, bufA, T, LD);
+    __syncthreads();
+    if (after) {
+        for (int o = threadIdx.x; o < w.emb * T; o += VAE_THREADS) {
+            const int c = o / T, t = o - c * T;
+            after[(size_t)b * w.emb * T + o] = bufA[c * LD + t];
+        }
+    }
+    conv1d_lds<3, 1, false, false>(bufA, w.emb, T, bufB, w.hidden, T, w.dec_conv1_w, w.dec_conv1_b, 1,
+                                   LD, LD);
+    __syncthreads();
+    residual_stack(bufB, bufA, w.hidden, w.res_hidden, w.n_res, T, w.dec_c3, w.dec_c1, LD);
+    const int ldw = 2 * T;
+    convT1d_k4s2_lds<true>(bufB, w.hidden, T, wide, w.hidden / 2, w.dec_ct1_w, w.dec_ct1_b, LD, ldw);
+    __syncthreads();
+    // last transposed conv (hidden/2 -> 1) writes straight to global
+    {
+        const int Tin = 2 * T, Cin = w.hidden / 2;
+        for (int t = threadIdx.x; t < L; t += VAE_THREADS) {
+            float acc = w.dec_ct2_b[0];
+            const int k0 = (t + 1) & 1;
+            for (int ci = 0; ci < Cin; ++ci) {
+#pragma unroll
+                for (int kk2 = 0; kk2 < 2; ++kk2) {
+                    const int kk = k0 + 2 * kk2;
+                    const int i = (t + 1 - kk) >> 1;
+                    if (t + 1 - kk >= 0 && i < Tin) acc += wide[ci * ldw + i] * w.dec_ct2_w[ci * 4 + kk];
+                }
+            }
+            recon[(size_t)b * L + t] = acc;
+        }
+    }
+}
+
+// Encoder.forward (vqvae.py:57-71)
+__global__ __launch_bounds__(VAE_THREADS) void vae_encode_kernel(const VaeDev w,
+                                                                 const float* __restrict__ x,
+                                                                 float* __restrict__ z,
+                                                                 float* __restrict__ before, int L) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* bufA = smem;
+    float* bufB = smem + VAE_CMAX * LD;
+    float* wide = bufB + VAE_CMAX * LD;   // [hidden/2][L/2]
+    const int b = blockIdx.x;
+    const int T2 = L / 2, T = L / 4;
+    const int half_c = w.hidden / 2;
+    // conv_1: 1 -> hidden/2, k4 s2 p1, ReLU ; input straight from global
+    for (int o = threadIdx.x; o < half_c * T2; o += VAE_THREADS) {
+        const int co = o / T2, t = o - co * T2;
+        float acc = w.enc_conv1_b[co];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int ti = 2 * t + kk - 1;
+            if (ti >= 0 && ti < L) acc += w.enc_conv1_w[co * 4 + kk] * x[(size_t)b * L + ti];
+        }
+        wide[co * T2 + t] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    conv1d_lds<4, 2, true, false>(wide, half_c, T2, bufA, w.hidden, T, w.enc_conv2_w, w.enc_conv2_b, 1,
+                                  T2, LD);
+    __syncthreads();
+    conv1d_lds<3, 1, false, false>(bufA, w.hidden, T, bufB, w.hidden, T, w.enc_conv3_w, w.enc_conv3_b,
+                                   1, LD, LD);
+    __syncthreads();
+    residual_stack(bufB, bufA, w.hidden, w.res_hidden, w.n_res, T, w.enc_c3, w.enc_c1, LD);
+    conv1d_lds<1, 1, false, false>(bufB, w.hidden, T, bufA, w.emb, T, w.enc_prevq_w, w.enc_prevq_b, 0,
+                                   LD, LD);
+    __syncthreads();
+    if (before) {
+        for (int o = threadIdx.x; o < w.emb * T; o += VAE_THREADS) {
+            const int c = o / T, t = o - c * T;
+            before[(size_t)b * w.emb * T + o] = bufA[c * LD + t];
+        }
+    }
+    interp_linear_ac(bufA, w.emb, T, LD, bufB, LATW, LD);
+    __syncthreads();
+    for (int o = threadIdx.x; o < w.emb * LATW; o += VAE_THREADS) {
+        const int c = o / LATW, t = o - c * LATW;
+        z[(size_t)b * w.emb * LATW + o] = bufB[c * LD + t];
+    }
+}
+
+}  // namespace t2s
+
+using namespace t2s;
+
+struct t2s_vae {
+    VaeDev dev{};
+    float* arena = nullptr;
+    bool has_encoder = false;
+    bool has_decoder = false;
+};
+
+namespace {
+size_t r64(size_t n) { return (n + 63) & ~size_t(63); }
+}
+
+extern "C" int t2s_vae_create(const t2s_vae_weights* w, t2s_vae** out) {
+    T2S_REQUIRE(w && out, "t2s_vae_create: NULL argument");
+    T2S_REQUIRE(w->hidden > 0 && w->hidden <= 128 && w->hidden % 2 == 0, "t2s_vae_create: hidden=%d unsupported (<=128, even)", w->hidden);
+    T2S_REQUIRE(w->res_hidden > 0 && w->res_hidden <= VAE_CMAX, "t2s_vae_create: res_hidden=%d unsupported (<=256)", w->res_hidden);
+    T2S_REQUIRE(w->n_res_layers >= 0 && w->n_res_layers <= 4, "t2s_vae_create: n_res_layers=%d unsupported (<=4)", w->n_res_layers);
+    T2S_REQUIRE(w->emb == T2S_LAT_C, "t2s_vae_create: embedding_dim=%d must be 64", w->emb);
+    const bool dec = w->dec_conv1_w != nullptr;
+    const bool enc = w->enc_conv1_w != nullptr;
+    T2S_REQUIRE(dec || enc, "t2s_vae_create: neither decoder nor encoder weights given");
+    if (dec)
+        T2S_REQUIRE(w->dec_conv1_b && w->dec_ct1_w && w->dec_ct1_b && w->dec_ct2_w && w->dec_ct2_b,
+                    "t2s_vae_create: partial decoder weights");
+    const int H = w->hidden, R = w->res_hidden, E = w->emb, NR = w->n_res_layers;
+    if (enc)
+        T2S_REQUIRE(w->enc_conv1_b && w->enc_conv2_w && w->enc_conv2_b && w->enc_conv3_w && w->enc_conv3_b &&
+                        w->enc_prevq_w && w->enc_prevq_b,
+                    "t2s_vae_create: partial encoder weights");
+    struct Item { const float* src; size_t n; const float** dst; };
+    t2s_vae* h = new t2s_vae();
+    VaeDev& d = h->dev;
+    d.hidden = H; d.res_hidden = R; d.n_res = NR; d.emb = E;
+    std::vector<Item> items;
+    if (dec)
+        items = {{w->dec_conv1_w, (size_t)H * E * 3, &d.dec_conv1_w}, {w->dec_conv1_b, (size_t)H, &d.dec_conv1_b},
+                 {w->dec_ct1_w, (size_t)H * (H / 2) * 4, &d.dec_ct1_w}, {w->dec_ct1_b, (size_t)H / 2, &d.dec_ct1_b},
+                 {w->dec_ct2_w, (size_t)(H / 2) * 4, &d.dec_ct2_w}, {w->dec_ct2_b, 1, &d.dec_ct2_b}};
+    for (int l = 0; dec && l < NR; ++l) {
+        if (!w->dec_stack.conv3_w[l] || !w->dec_stack.conv1_w[l]) {
+            set_error("t2s_vae_create: NULL decoder residual weight %d", l);
+            delete h;
+            return T2S_E_INVALID;
+        }
+        items.push_back({w->dec_stack.conv3_w[l], (size_t)R * H * 3, &d.dec_c3[l]});
+        items.push_back({w->dec_stack.conv1_w[l], (size_t)H * R, &d.dec_c1[l]});
+    }
+    if (enc) {
+        items.push_back({w->enc_conv1_w, (size_t)(H / 2) * 4, &d.enc_conv1_w});
+        items.push_back({w->enc_conv1_b, (size_t)H / 2, &d.enc_conv1_b});
+        items.push_back({w->enc_conv2_w, (size_t)H * (H / 2) * 4, &d.enc_conv2_w});
+        items.push_back({w->enc_conv2_b, (size_t)H, &d.enc_conv2_b});
+        items.push_back({w->enc_conv3_w, (size_t)H * H * 3, &d.enc_conv3_w});
+        items.push_back({w->enc_conv3_b, (size_t)H, &d.enc_conv3_b});
+        items.push_back({w->enc_prevq_w, (size_t)E * H, &d.enc_prevq_w});
+        items.push_back({w->enc_prevq_b, (size_t)E, &d.enc_prevq_b});
+        for (int l = 0; l < NR; ++l) {
+            if (!w->enc_stack.conv3_w[l] || !w->enc_stack.conv1_w[l]) {
+                set_error("t2s_vae_create: NULL encoder residual weight %d", l);
+                delete h;
+                return T2S_E_INVALID;
+            }
+            items.push_back({w->enc_stack.conv3_w[l], (size_t)R * H * 3, &d.enc_c3[l]});
+            items.push_back({w->enc_stack.conv1_w[l], (size_t)H * R, &d.enc_c1[l]});
+        }
+    }
+    size_t total = 0;
+    for (auto& it : items) total += r64(it.n);
+    hipError_t e = hipMalloc(&h->arena, total * sizeof(float));
+    if (e != hipSuccess) {
+        set_error("t2s_vae_create: hipMalloc failed: %s", hipGetErrorString(e));
+        delete h;
+        return T2S_E_HIP;
+    }
+    size_t off = 0;
+    for (auto& it : items) {
+        e = hipMemcpy(h->arena + off, it.src, it.n * sizeof(float), hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) {
+            set_error("t2s_vae_create: weight copy failed: %s", hipGetErrorString(e));
+            t2s_vae_destroy(h);
+            return T2S_E_HIP;
+        }
+        *it.dst = h->arena + off;
+        off += r64(it.n);
+    }
+    h->has_encoder = enc;
+    h->has_decoder = dec;
+    static bool attr = false;
+    if (!attr) {
+        const int bytes = VAE_LDS_FLOATS * 4;
+        T2S_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(vae_decode_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        T2S_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(vae_encode_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        attr = true;
+    }
+    *out = h;
+    return T2S_OK;
+}
+
+extern "C" void t2s_vae_destroy(t2s_vae* h) {
+    if (!h) return;
+    if (h->arena) (void)hipFree(h->arena);
+    delete h;
+}
+
+extern "C" int t2s_vae_decode(t2s_vae* h, const float* z, float* recon, float* after, int B, int L,
+                              void* stream) {
+    T2S_REQUIRE(h && z && recon, "t2s_vae_decode: NULL argument");
+    T2S_REQUIRE(h->has_decoder, "t2s_vae_decode: handle was created without decoder weights");
+    T2S_REQUIRE(B > 0, "t2s_vae_decode: B=%d", B);
+    T2S_REQUIRE(L >= 4 && L % 4 == 0 && L / 4 <= VAE_TMAX, "t2s_vae_decode: L=%d unsupported (multiple of 4, <= 128)", L);
+    vae_decode_kernel<<<B, VAE_THREADS, VAE_LDS_FLOATS * 4, (hipStream_t)stream>>>(h->dev, z, recon, after, L);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+extern "C" int t2s_vae_encode(t2s_vae* h, const float* x, float* z, float* before, int B, int L,
+                              void* stream) {
+    T2S_REQUIRE(h && x && z, "t2s_vae_encode: NULL argument");
+    T2S_REQUIRE(h->has_encoder, "t2s_vae_encode: handle was created without encoder weights");
+    T2S_REQUIRE(B > 0, "t2s_vae_encode: B=%d", B);
+    T2S_REQUIRE(L >= 4 && L % 4 == 0 && L / 4 <= VAE_TMAX, "t2s_vae_encode: L=%d unsupported (multiple of 4, <= 128)", L);
+    vae_encode_kernel<<<B, VAE_THREADS, VAE_LDS_FLOATS * 4, (hipStream_t)stream>>>(h->dev, x, z, before, L);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}

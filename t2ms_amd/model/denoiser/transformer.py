@@ -1,0 +1,294 @@
+"""Host-side mirror of the reference DiT denoiser (model/denoiser/transformer.py).
+
+Same class name, constructor, parameter names/shapes/initialisation and
+``forward(input=, t=, text_input=)`` contract as the reference, so
+checkpoints and drivers are drop-in -- but ``forward`` runs the hand-written
+HIP kernels of libt2s_hip.so (t2s_dit_forward).  The nn.Module tree below only
+*holds parameters* under the reference's state-dict keys; no torch op computes
+the network, and there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import weakref
+
+import torch
+import torch.nn as nn
+
+from ... import _lib as L
+
+__all__ = ["Transformer", "Transformerlayer", "TimeEmbedding", "modulate",
+           "get_sinusoidal_positional_embeddings", "InverseLatentEmbedding", "LatentEmbedding"]
+
+EMB, HEADS, DEPTH, PATCH = 128, 4, 4, 2
+LAT_H, LAT_W = 30, 64           # the reference's self.H / self.W (transformer.py:132-133)
+N_PATCH = (LAT_H // PATCH) * (LAT_W // PATCH)
+
+
+def modulate(x, shift, scale):
+    """transformer.py:7-8 -- kept for API compatibility; the HIP path fuses it into the GEMM prologue."""
+    raise L.T2SError("modulate() is fused into the HIP kernels; call Transformer.forward instead")
+
+
+def get_sinusoidal_positional_embeddings(num_positions, d_model):
+    """Fixed sin/cos table (transformer.py:14-23): built once on the host at construction."""
+    pos = torch.arange(num_positions).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d_model, 2) * -(math.log(10000.0) / d_model)).unsqueeze(0)
+    table = torch.zeros(num_positions, d_model)
+    table[:, 0::2] = torch.sin(pos * div)
+    table[:, 1::2] = torch.cos(pos * div)
+    return table.unsqueeze(0)
+
+
+class TimeEmbedding(nn.Module):
+    """transformer.py:25-40.  Parameter-free; evaluated by t2s_time_embedding on the GPU."""
+
+    def __init__(self, dim):
+        super().__init__()
+        assert dim % 2 == 0, "Dimension must be even"
+        self.dim = dim
+
+    def forward(self, t):
+        if self.dim != EMB:
+            raise L.T2SError("HIP TimeEmbedding is built for dim=128")
+        tf = L.as_f32(t)
+        if not tf.is_cuda:
+            raise L.T2SError("TimeEmbedding: t must live on a GPU (no CPU fallback)")
+        freqs = _freqs_on(tf.device)
+        out = torch.empty(tf.shape[0], EMB, device=tf.device, dtype=torch.float32)
+        # t2s_time_embedding only needs the freqs table, which lives in a DiT handle; use a tiny one
+        h = _scratch_handle(tf.device)
+        L.check(L.lib().t2s_time_embedding(h, L.dev_ptr(tf, "t"), L.dev_ptr(out), tf.shape[0],
+                                           L.stream_ptr(tf.device)), "t2s_time_embedding")
+        del freqs
+        return out
+
+
+class _Attention(nn.Module):
+    """Parameter container with timm's Attention sub-module names (qkv, proj)."""
+
+    def __init__(self, dim, num_heads):
+        super().__init__()
+        self.num_heads = num_heads
+        self.qkv = nn.Linear(dim, 3 * dim, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, *_a, **_k):
+        raise L.T2SError("attention runs inside t2s_dit_forward (t2s_attn.hip); call Transformer.forward")
+
+
+class _Mlp(nn.Module):
+    """Parameter container with timm's Mlp sub-module names (fc1, fc2)."""
+
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, *_a, **_k):
+        raise L.T2SError("the MLP runs inside t2s_dit_forward (t2s_gemm.h); call Transformer.forward")
+
+
+class Transformerlayer(nn.Module):
+    """adaLN-Zero DiT block parameters (transformer.py:94-124)."""
+
+    def __init__(self):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(EMB, elementwise_affine=False, eps=1e-6)
+        self.norm2 = nn.LayerNorm(EMB, elementwise_affine=False, eps=1e-6)
+        self.attn = _Attention(EMB, HEADS)
+        self.mlp = _Mlp(EMB, int(EMB * 2.0))
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(EMB, 6 * EMB, bias=True))
+
+    def forward(self, *_a, **_k):
+        raise L.T2SError("DiT blocks run inside t2s_dit_forward; call Transformer.forward")
+
+
+class LatentEmbedding(nn.Module):
+    """Dead code in the reference (transformer.py:46-62, never instantiated); kept importable."""
+
+    def __init__(self, embed_dim: int = 64):
+        super().__init__()
+        self.dim = embed_dim
+        self.embedding2d = nn.Conv2d(1, embed_dim, kernel_size=(6, 6), stride=(6, 6))
+
+
+class InverseLatentEmbedding(nn.Module):
+    """Instantiated as ``unpatch`` but never called by the reference forward
+    (transformer.py:65-87,150): its tensors must exist in the state-dict, nothing else."""
+
+    def __init__(self, embed_dim: int = 64):
+        super().__init__()
+        self.dim = embed_dim
+        self.inv_embedding2d = nn.ConvTranspose2d(embed_dim, 1, kernel_size=(6, 6), stride=(6, 6))
+        self.fc1 = nn.Linear(60, 128)
+        self.fc2 = nn.Linear(128, 64)
+
+
+# ---------------------------------------------------------------------------- device-side state
+_FREQS = {}
+_SCRATCH = {}
+
+
+def _freqs_on(device) -> torch.Tensor:
+    """10000**linspace(0,1,64) evaluated with the reference's own fp32 torch ops on the host
+    (transformer.py:34), then uploaded -- bit-identical table, device sin/cos."""
+    key = str(device)
+    if key not in _FREQS:
+        _FREQS[key] = torch.pow(10000, torch.linspace(0, 1, EMB // 2)).to(device)
+    return _FREQS[key]
+
+
+class _DitHandle:
+    """Owns one t2s_dit (packed weights + workspace) for one module on one device."""
+
+    def __init__(self, weights: L.DitWeights, keep, max_seqs: int):
+        self.ptr = C.c_void_p()
+        self.keep = keep
+        self.max_seqs = max_seqs
+        L.check(L.lib().t2s_dit_create(C.byref(weights), max_seqs, C.byref(self.ptr)), "t2s_dit_create")
+        self._fin = weakref.finalize(self, L.lib().t2s_dit_destroy, self.ptr)
+
+    def close(self):
+        self._fin()
+
+
+def _scratch_handle(device):
+    """A 1-sequence handle with dummy weights, used only for its time-frequency table."""
+    key = str(device)
+    if key not in _SCRATCH:
+        z = torch.zeros(480 * 128, device=device)
+        w = L.DitWeights()
+        for name, _ in L.DitWeights._fields_[:-1]:
+            setattr(w, name, z.data_ptr())
+        w.time_freqs = _freqs_on(device).data_ptr()
+        for b in w.blk:
+            for name, _ in L.DitBlockWeights._fields_:
+                setattr(b, name, z.data_ptr())
+        _SCRATCH[key] = _DitHandle(w, (z,), 1)
+    return _SCRATCH[key].ptr
+
+
+class Transformer(nn.Module):
+    """Drop-in for ``model.denoiser.transformer.Transformer`` (transformer.py:128-204)."""
+
+    def __init__(self):
+        super().__init__()
+        self.channel, self.H, self.W, self.patch_size = 1, LAT_H, LAT_W, PATCH
+        self.patch_count = N_PATCH
+        self.conv = nn.Conv2d(1, PATCH * PATCH, kernel_size=PATCH, padding=0, stride=PATCH)
+        self.patch_emb = nn.Linear(PATCH * PATCH, EMB)
+        self.pos_embed = nn.Parameter(get_sinusoidal_positional_embeddings(N_PATCH, EMB), requires_grad=False)
+        self.ln = nn.LayerNorm(EMB)
+        self.linear_emb_to_patch = nn.Linear(EMB, PATCH * PATCH)
+        self.time_emb = TimeEmbedding(dim=EMB)
+        self.layers = nn.ModuleList([Transformerlayer() for _ in range(DEPTH)])
+        self.unpatch = InverseLatentEmbedding(embed_dim=EMB)
+        self.initialize_weights()
+
+    # -- a15: xavier on every Linear, zero biases, zero adaLN output layer (transformer.py:194-204)
+    def initialize_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+        for blk in self.layers:
+            nn.init.zeros_(blk.adaLN_modulation[-1].weight)
+            nn.init.zeros_(blk.adaLN_modulation[-1].bias)
+
+    # ---------------------------------------------------------------- HIP handle management
+    def _dit_tensors(self):
+        ts = [self.conv.weight, self.conv.bias, self.patch_emb.weight, self.patch_emb.bias, self.pos_embed,
+              self.ln.weight, self.ln.bias, self.linear_emb_to_patch.weight, self.linear_emb_to_patch.bias]
+        for blk in self.layers:
+            ts += [blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight, blk.attn.proj.bias,
+                   blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias,
+                   blk.adaLN_modulation[-1].weight, blk.adaLN_modulation[-1].bias]
+        return ts
+
+    def _weights_struct(self, device):
+        ts = self._dit_tensors()
+        for t in ts:
+            if t.device != device:
+                raise L.T2SError(f"Transformer parameters live on {t.device} but the input is on {device}; "
+                                 f"call model.to(device) first")
+        keep = [L.as_f32(t.detach()) for t in ts]
+        w = L.DitWeights()
+        names = [n for n, _ in L.DitWeights._fields_ if n not in ("blk", "time_freqs")]
+        for n, t in zip(names, keep[:9]):
+            setattr(w, n, t.data_ptr())
+        w.time_freqs = _freqs_on(device).data_ptr()
+        bnames = [n for n, _ in L.DitBlockWeights._fields_]
+        for i in range(DEPTH):
+            for n, t in zip(bnames, keep[9 + 10 * i: 19 + 10 * i]):
+                setattr(w.blk[i], n, t.data_ptr())
+        stamp = tuple((t.data_ptr(), t._version) for t in ts)
+        return w, keep, stamp
+
+    def t2s_handle(self, device, n_seqs: int):
+        """(Re)build or refresh the packed-weight handle: weights are re-packed whenever a parameter
+        was modified in place (optimizer step, load_state_dict) or re-allocated (.to())."""
+        device = torch.device(device)
+        w, keep, stamp = self._weights_struct(device)
+        h = self.__dict__.get("_t2s_h")
+        if h is None or self.__dict__.get("_t2s_dev") != device or h.max_seqs < n_seqs:
+            if h is not None:
+                h.close()
+            cap = max(n_seqs, h.max_seqs if h is not None else 0)
+            torch.cuda.synchronize(device)
+            with torch.cuda.device(device):
+                h = _DitHandle(w, keep, cap)
+            self.__dict__["_t2s_h"], self.__dict__["_t2s_dev"], self.__dict__["_t2s_stamp"] = h, device, stamp
+        elif self.__dict__.get("_t2s_stamp") != stamp:
+            L.check(L.lib().t2s_dit_update_weights(h.ptr, C.byref(w), L.stream_ptr(device)),
+                    "t2s_dit_update_weights")
+            h.keep = keep
+            self.__dict__["_t2s_stamp"] = stamp
+        return h.ptr
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in ("_t2s_h", "_t2s_dev", "_t2s_stamp"):
+            state.pop(k, None)
+        return state
+
+    # ---------------------------------------------------------------- forward (transformer.py:158-193)
+    def forward(self, input: torch.Tensor, t: torch.Tensor, text_input):
+        """input (B,64,30) latent, t (B,) int64 (DDPM) or float (flow), text_input (B,128) or None."""
+        if not input.is_cuda:
+            raise L.T2SError("Transformer.forward: input must live on a GPU; the HIP path has no CPU fallback")
+        if input.dim() != 3 or input.shape[1] != LAT_W or input.shape[2] != LAT_H:
+            raise L.T2SError(f"Transformer.forward: input must be (B,64,30), got {tuple(input.shape)}")
+        if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self._dit_tensors())):
+            from ...train import dit_forward_autograd
+            return dit_forward_autograd(self, input, t, text_input)
+        return self._forward_nograd(input, t, text_input)
+
+    def _forward_nograd(self, input, t, text_input):
+        dev = input.device
+        B = input.shape[0]
+        x = L.as_f32(input)
+        tf = L.as_f32(t.to(dev))          # `t * 100.0` promotes int64 -> fp32 in the reference too
+        if tf.shape != (B,):
+            raise L.T2SError(f"Transformer.forward: t must be ({B},), got {tuple(tf.shape)}")
+        text = None
+        if text_input is not None:
+            text = L.as_f32(text_input)
+            if tuple(text.shape) != (B, EMB):
+                raise L.T2SError(f"Transformer.forward: text_input must be ({B},128), got {tuple(text.shape)}")
+        with torch.cuda.device(dev):
+            h = self.t2s_handle(dev, B)
+            st = L.stream_ptr(dev)
+            temb = torch.empty(B, EMB, device=dev, dtype=torch.float32)
+            out = torch.empty(B, LAT_W, LAT_H, device=dev, dtype=torch.float32)
+            lib = L.lib()
+            L.check(lib.t2s_time_embedding(h, L.dev_ptr(tf, "t"), L.dev_ptr(temb), B, st), "t2s_time_embedding")
+            L.check(lib.t2s_dit_forward(h, L.dev_ptr(x, "input"), L.dev_ptr(temb), B, L.dev_ptr(text, "text_input"),
+                                        L.dev_ptr(out), B, st), "t2s_dit_forward")
+        return out
+
+
+for _cls in (Transformer, Transformerlayer, TimeEmbedding, InverseLatentEmbedding, LatentEmbedding):
+    _cls.__module__ = "model.denoiser.transformer"   # pickles stay loadable by the reference and vice versa

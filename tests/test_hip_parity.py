@@ -1,0 +1,355 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the committed golden
+vectors.  Needs a real MI355X: run with `pytest -m gpu` via gpurun.
+
+Tolerances (fp32): 1e-4 absolute per forward / per step as BASELINE.json's north_star states;
+chains are checked relative to max|x|."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import t2s_oracle as O
+from t2ms_amd import _lib as L
+from t2ms_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _load(golden_dir, name):
+    return {k: v for k, v in np.load(os.path.join(golden_dir, name + ".npz")).items()}
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def dit(dev):
+    from model.denoiser.transformer import Transformer
+    m = Transformer()
+    m.load_state_dict(synth.make_dit_state_dict(2025), strict=True)
+    return m.to(dev).eval()
+
+
+@pytest.fixture(scope="module")
+def vae(dev):
+    import types
+    from model.pretrained.vqvae import vqvae
+    v = vqvae(types.SimpleNamespace(block_hidden_size=128, num_residual_layers=2, res_hidden_size=256,
+                                    embedding_dim=64))
+    v.load_state_dict(synth.make_vae_state_dict(2025), strict=True)
+    return v.to(dev).eval()
+
+
+def _maxdiff(a, b):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max())
+
+
+def test_native_library_is_loaded(dev):
+    lib = L.lib()
+    maps = open("/proc/self/maps").read()
+    assert "libt2s_hip.so" in maps
+    assert b"gfx950" in lib.t2s_version()
+
+
+def test_time_embedding(golden_dir, dev, dit):
+    g = _load(golden_dir, "time_emb")
+    e_long = dit.time_emb(_t(g["t_long"]).to(dev))
+    e_float = dit.time_emb(_t(g["t_float"]).to(dev))
+    assert _maxdiff(e_long, g["emb_long"]) < 1e-5
+    assert _maxdiff(e_float, g["emb_float"]) < 1e-5
+    # all 1000 DDPM steps (arguments up to 99,900 rad)
+    t = torch.arange(1000)
+    assert _maxdiff(dit.time_emb(t.to(dev)), O.time_embedding(t)) < 1e-5
+
+
+def test_attention_kernel_vs_oracle(dev):
+    rs = np.random.RandomState(11)
+    BH = 12
+    q, k, v = (torch.from_numpy(rs.randn(BH, 480, 32).astype(np.float32)) for _ in range(3))
+    q = q * 2.0  # sharper softmax
+    ref = torch.softmax((q * 32 ** -0.5) @ k.transpose(-1, -2), dim=-1) @ v
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    od = torch.empty_like(qd)
+    L.check(L.lib().t2s_attn_fwd(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), BH,
+                                 L.stream_ptr(dev)))
+    assert _maxdiff(od, ref) < 2e-5
+
+
+def test_attention_online_softmax_rescale_branch(dev):
+    """Force the running max to jump at a late key block (rule: a rare data-dependent branch needs
+    its own test): one key row is aligned with the queries and scaled up."""
+    rs = np.random.RandomState(12)
+    q = torch.from_numpy(rs.randn(4, 480, 32).astype(np.float32))
+    k = torch.from_numpy(rs.randn(4, 480, 32).astype(np.float32))
+    v = torch.from_numpy(rs.randn(4, 480, 32).astype(np.float32))
+    k[:, 333] = q[:, 100] * 6.0      # spike in key block 10 for query 100
+    k[:, 5] = q[:, 200] * 4.0        # and an early one
+    ref = torch.softmax((q.double() * 32 ** -0.5) @ k.double().transpose(-1, -2), dim=-1) @ v.double()
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    od = torch.empty_like(qd)
+    L.check(L.lib().t2s_attn_fwd(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), 4,
+                                 L.stream_ptr(dev)))
+    assert _maxdiff(od, ref.float()) < 2e-5
+
+
+def test_dit_forward_golden(golden_dir, dev, dit):
+    g = _load(golden_dir, "dit_forward")
+    x = synth.make_latents(2025, 4).to(dev)
+    text = synth.make_text_embeddings(2025, 4).to(dev)
+    with torch.no_grad():
+        yc = dit(input=x, t=_t(g["t_long"]).to(dev), text_input=text)
+        # the residual stream the forward left behind (post block 3) vs the reference's hook tap
+        stream = torch.empty(4, 480, 128, device=dev)
+        L.check(L.lib().t2s_dit_read_stream(dit.t2s_handle(dev, 4), stream.data_ptr(), 4, L.stream_ptr(dev)))
+        yu = dit(input=x, t=_t(g["t_long"]).to(dev), text_input=None)
+        yf = dit(input=x, t=_t(g["t_float"]).to(dev), text_input=text)
+    assert _maxdiff(stream[:1, ::7], g["tap_post_mlp_3"]) < TOL
+    assert _maxdiff(yc, g["cond"]) < TOL
+    assert _maxdiff(yu, g["uncond"]) < TOL
+    assert _maxdiff(yf, g["cond_float"]) < TOL
+
+
+@pytest.mark.parametrize("B", [1, 3, 7])
+def test_dit_forward_vs_oracle_ragged_batches(dev, dit, B):
+    """Odd batch sizes exercise the partial 64-row tiles (B*480 is not a multiple of 64)."""
+    sd = synth.make_dit_state_dict(2025)
+    x = synth.make_latents(900 + B, B)
+    text = synth.make_text_embeddings(900 + B, B)
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(B))
+    with torch.no_grad():
+        ref_c = O.dit_forward(sd, x, t, text)
+        ref_u = O.dit_forward(sd, x, t, None)
+        got_c = dit(input=x.to(dev), t=t.to(dev), text_input=text.to(dev))
+        got_u = dit(input=x.to(dev), t=t.to(dev), text_input=None)
+    assert _maxdiff(got_c, ref_c) < TOL
+    assert _maxdiff(got_u, ref_u) < TOL
+
+
+def test_cfg_pass_equals_two_forwards_bitwise(dev, dit):
+    B = 5
+    x = synth.make_latents(77, B).to(dev)
+    text = synth.make_text_embeddings(77, B).to(dev)
+    t = torch.full((B,), 421, dtype=torch.long, device=dev)
+    with torch.no_grad():
+        yu = dit(input=x, t=t, text_input=None)
+        yc = dit(input=x, t=t, text_input=text)
+        h = dit.t2s_handle(dev, 2 * B)
+        temb = dit.time_emb(t[:1])
+        ou, oc = torch.empty_like(x), torch.empty_like(x)
+        L.check(L.lib().t2s_dit_forward_cfg(h, x.data_ptr(), temb.data_ptr(), text.data_ptr(), ou.data_ptr(),
+                                            oc.data_ptr(), B, L.stream_ptr(dev)))
+    assert torch.equal(ou, yu) and torch.equal(oc, yc)
+
+
+def test_weight_update_is_picked_up(dev):
+    from model.denoiser.transformer import Transformer
+    m = Transformer().to(dev).eval()
+    m.load_state_dict(synth.make_dit_state_dict(5), strict=True)
+    x = synth.make_latents(5, 2).to(dev)
+    t = torch.tensor([10, 20], device=dev)
+    with torch.no_grad():
+        y1 = m(input=x, t=t, text_input=None)
+        m.load_state_dict(synth.make_dit_state_dict(6), strict=True)   # in-place copy_ -> version bump
+        y2 = m(input=x, t=t, text_input=None)
+        ref2 = O.dit_forward(synth.make_dit_state_dict(6), x.cpu(), t.cpu(), None)
+    assert _maxdiff(y2, ref2) < TOL and _maxdiff(y1, y2) > 1e-3
+
+
+def test_full_size_batch_invariance(dev, dit):
+    """BASELINE size (B=256 -> 512 sequences in one CFG pass): every row must be BITWISE what the
+    same row gives in a 4-row batch (rows are independent through the whole network), and rows
+    agree with the oracle."""
+    B = 256
+    x = synth.make_latents(4242, B).to(dev)
+    text = synth.make_text_embeddings(4242, B).to(dev)
+    t = torch.full((B,), 999, dtype=torch.long, device=dev)
+    with torch.no_grad():
+        h = dit.t2s_handle(dev, 2 * B)
+        temb = dit.time_emb(t[:1])
+        ou, oc = torch.empty_like(x), torch.empty_like(x)
+        L.check(L.lib().t2s_dit_forward_cfg(h, x.data_ptr(), temb.data_ptr(), text.data_ptr(), ou.data_ptr(),
+                                            oc.data_ptr(), B, L.stream_ptr(dev)))
+        rows = [0, 1, 130, 255]
+        small_c = dit(input=x[rows].contiguous(), t=t[:4], text_input=text[rows].contiguous())
+        small_u = dit(input=x[rows].contiguous(), t=t[:4], text_input=None)
+        ref_c = O.dit_forward(synth.make_dit_state_dict(2025), x[rows].cpu(), t[:4].cpu(), text[rows].cpu())
+    assert torch.equal(oc[rows], small_c) and torch.equal(ou[rows], small_u)
+    assert _maxdiff(small_c, ref_c) < TOL
+    assert bool(torch.isfinite(oc).all()) and bool(torch.isfinite(ou).all())
+
+
+def test_ddpm_backbone_golden(golden_dir, dev):
+    from model.backbone.DDPM import DDPM
+    g = _load(golden_dir, "ddpm")
+    for T in (50, 1000):
+        d = DDPM(T, dev)
+        for k in ("beta", "alpha", "alpha_bar"):
+            assert np.array_equal(getattr(d, k).cpu().numpy(), g[f"{k}_{T}"])
+    d = DDPM(1000, dev)
+    t = _t(g["t"]).to(dev)
+    xq, eps = d.q_sample(_t(g["x0"]).to(dev), t, _t(g["eps"]).to(dev))
+    assert _maxdiff(xq, g["q_sample"]) < 1e-6
+    xp = d.p_sample(_t(g["x0"]).to(dev), _t(g["eps_hat"]).to(dev), t, eps=_t(g["p_noise"]).to(dev))
+    assert _maxdiff(xp, g["p_sample"]) < 2e-6
+    # default path draws its own noise (like the reference) and stays finite / right shape
+    xr = d.p_sample(_t(g["x0"]).to(dev), _t(g["eps_hat"]).to(dev), t)
+    assert xr.shape == (4, 64, 30) and bool(torch.isfinite(xr).all())
+
+
+def test_rectified_flow_golden(golden_dir, dev):
+    from model.backbone.rectified_flow import RectifiedFlow
+    g = _load(golden_dir, "rf")
+    rf = RectifiedFlow()
+    assert _maxdiff(rf.euler(_t(g["x1"]).to(dev), _t(g["v"]).to(dev), 1.0 / 100), g["euler"]) < 1e-6
+    xt, x0 = rf.create_flow(_t(g["x1"]).to(dev), _t(g["t"]).to(dev), x_0=_t(g["x_0"]).to(dev))
+    assert _maxdiff(xt, g["x_t"]) < 1e-6
+
+
+def test_fused_ddpm_step_vs_oracle(dev):
+    from t2ms_amd.model.backbone.DDPM import ddpm_host_tables
+    rs = np.random.RandomState(3)
+    B, T = 6, 1000
+    x, u, c, z = (torch.from_numpy(rs.randn(B, 64, 30).astype(np.float32)) for _ in range(4))
+    tab = O.ddpm_tables(T)
+    coef = ddpm_host_tables(T)["coef"].to(dev)
+    for t_idx in (0, 1, 517, 999):
+        pred = u + 9.0 * (c - u)
+        ref = O.ddpm_p_sample(tab, x, pred, torch.full((B,), t_idx), z)
+        xd = x.to(dev).clone()
+        L.check(L.lib().t2s_ddpm_step(xd.data_ptr(), u.to(dev).data_ptr(), c.to(dev).data_ptr(),
+                                      z.to(dev).data_ptr(), coef.data_ptr(), t_idx, 9.0, 0, 0, 0, B,
+                                      L.stream_ptr(dev)))
+        assert _maxdiff(xd, ref) < 2e-5, t_idx
+    # RF step
+    ref = O.rf_euler(x, u + 5.0 * (c - u), 0.01)
+    xd = x.to(dev).clone()
+    L.check(L.lib().t2s_rf_step(xd.data_ptr(), u.to(dev).data_ptr(), c.to(dev).data_ptr(), 5.0, 0.01, B,
+                                L.stream_ptr(dev)))
+    assert _maxdiff(xd, ref) < 2e-6
+
+
+def test_mse(dev):
+    from t2ms_amd.train import mse_loss
+    rs = np.random.RandomState(8)
+    a = torch.from_numpy(rs.randn(9, 64, 30).astype(np.float32))
+    b = torch.from_numpy(rs.randn(9, 64, 30).astype(np.float32))
+    got = mse_loss(a.to(dev), b.to(dev))
+    np.testing.assert_allclose(got.item(), O.mse_loss(a, b).item(), rtol=1e-5)
+
+
+def test_philox_matches_oracle(dev):
+    n_rows, row0, seed, stream = 8, 1000, 2025, 17
+    out = torch.empty(n_rows, 1920, device=dev)
+    L.check(L.lib().t2s_philox_normal(out.data_ptr(), seed, stream, row0, n_rows, 1920, L.stream_ptr(dev)))
+    ref = O.device_normal(seed, stream, row0, n_rows)
+    assert _maxdiff(out, ref) < 1e-5
+    # sharding invariance: rows 4..7 drawn alone equal rows 4..7 of the big draw, bit for bit
+    part = torch.empty(4, 1920, device=dev)
+    L.check(L.lib().t2s_philox_normal(part.data_ptr(), seed, stream, row0 + 4, 4, 1920, L.stream_ptr(dev)))
+    assert torch.equal(part, out[4:])
+    big = torch.empty(4096, 1920, device=dev)
+    L.check(L.lib().t2s_philox_normal(big.data_ptr(), seed, 1, 0, 4096, 1920, L.stream_ptr(dev)))
+    assert abs(big.mean().item()) < 2e-3 and abs(big.std().item() - 1.0) < 2e-3
+
+
+@pytest.mark.parametrize("L_", [24, 48, 96])
+@pytest.mark.parametrize("B", [1, 5])
+def test_vae_golden(golden_dir, dev, vae, L_, B):
+    g = _load(golden_dir, "vae")
+    xs = synth.make_series(100 + L_ + B, B, L_).to(dev)
+    with torch.no_grad():
+        z, before = vae.encoder(xs)
+        rec, after = vae.decoder(z, length=L_)
+        rec2, _ = vae.decoder(synth.make_latents(300 + L_, B).to(dev), length=L_)
+    assert _maxdiff(z, g[f"z_{L_}_{B}"]) < 1e-5
+    assert _maxdiff(before, g[f"before_{L_}_{B}"]) < 1e-5
+    assert _maxdiff(after, g[f"after_{L_}_{B}"]) < 1e-5
+    assert tuple(rec.shape) == g[f"rec_{L_}_{B}"].shape      # torch.squeeze rule: (L,) when B == 1
+    assert _maxdiff(rec, g[f"rec_{L_}_{B}"]) < 1e-5
+    assert _maxdiff(rec2, g[f"rec_rand_{L_}_{B}"]) < 2e-5
+
+
+def _chain_setup(dev, vae):
+    from model.denoiser.transformer import Transformer
+    from t2ms_amd.sampler import Sampler
+    m = Transformer()
+    m.load_state_dict(synth.make_dit_state_dict(31337, gain=0.7), strict=True)
+    m = m.to(dev).eval()
+    xT = synth.make_latents(31337, 4)
+    text = synth.make_text_embeddings(31337, 4)
+    noises = torch.from_numpy(np.random.RandomState(99).randn(20, 4, 64, 30).astype(np.float32))
+    return m, Sampler, xT, text, noises
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_chain_ddpm_golden(golden_dir, dev, vae, use_graph):
+    g = _load(golden_dir, "chains")
+    m, Sampler, xT, text, noises = _chain_setup(dev, vae)
+    s = Sampler(m, vae.decoder, "ddpm", 20, 7.0, 4, 96, dev, use_graph=use_graph)
+    lat, series, _ = s.run(text, x_T=xT, noise=noises)
+    scale = max(1.0, float(np.abs(g["ddpm_latent"]).max()))
+    assert _maxdiff(lat, g["ddpm_latent"]) < TOL * scale
+    assert _maxdiff(series, g["ddpm_series"]) < TOL * scale
+    # second run on the same sampler (graph replay) reproduces the first bit for bit
+    lat2, series2, _ = s.run(text, x_T=xT, noise=noises)
+    assert torch.equal(lat, lat2) and torch.equal(series, series2)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_chain_rf_golden(golden_dir, dev, vae, use_graph):
+    g = _load(golden_dir, "chains")
+    m, Sampler, xT, text, _ = _chain_setup(dev, vae)
+    s = Sampler(m, vae.decoder, "flowmatching", 20, 7.0, 4, 96, dev, use_graph=use_graph)
+    lat, series, _ = s.run(text, x_T=xT)
+    scale = max(1.0, float(np.abs(g["rf_latent"]).max()))
+    assert _maxdiff(lat, g["rf_latent"]) < TOL * scale
+    assert _maxdiff(series, g["rf_series"]) < TOL * scale
+
+
+def test_chain_stepwise_class_api_matches_fused(dev, vae):
+    """The reference-style loop (infer.py:76-88) written against the mirrored classes gives the
+    fused sampler's result (same kernels, same order)."""
+    from model.backbone.DDPM import DDPM
+    m, Sampler, xT, text, noises = _chain_setup(dev, vae)
+    steps, cfg = 20, 7.0
+    ddpm = DDPM(steps, dev)
+    x = xT.to(dev)
+    textd = text.to(dev)
+    with torch.no_grad():
+        for j in range(steps):
+            t = torch.full((4,), steps - 1 - j, dtype=torch.long, device=dev)
+            u = m(input=x, t=t, text_input=None)
+            c = m(input=x, t=t, text_input=textd)
+            pred = u + cfg * (c - u)      # torch glue, as in infer.py:87
+            x = ddpm.p_sample(x, pred, t, eps=noises[j].to(dev))
+    s = Sampler(m, vae.decoder, "ddpm", steps, cfg, 4, 96, dev, use_graph=True)
+    lat, _, _ = s.run(text, x_T=xT, noise=noises)
+    assert _maxdiff(lat, x) < 5e-5 * max(1.0, float(x.abs().max()))
+
+
+def test_trace_and_perf_mode_sharding(dev, vae):
+    """Perf mode (Philox noise): a 6-row batch equals two 3-row shards with row0 offsets, bit for bit
+    (multi-GPU sharding is invisible in the results); trace decodes row 0 after every step."""
+    m, Sampler, _, _, _ = _chain_setup(dev, vae)
+    text = synth.make_text_embeddings(1, 6)
+    full = Sampler(m, vae.decoder, "ddpm", 8, 5.0, 6, 48, dev, use_graph=True, seed=7, row0=0)
+    lat, ser, _ = full.run(text)
+    a = Sampler(m, vae.decoder, "ddpm", 8, 5.0, 3, 48, dev, use_graph=True, seed=7, row0=0)
+    b = Sampler(m, vae.decoder, "ddpm", 8, 5.0, 3, 48, dev, use_graph=False, seed=7, row0=3)
+    la, sa, _ = a.run(text[:3])
+    lb, sb, tr = b.run(text[3:], trace=True)
+    assert torch.equal(lat[:3], la) and torch.equal(lat[3:], lb)
+    assert torch.equal(ser[:3], sa) and torch.equal(ser[3:], sb)
+    assert tr.shape == (8, 48) and torch.equal(tr[-1], sb[0])
