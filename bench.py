@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: generated series / second for 1000-step CFG DDPM sampling with the DiT
+denoiser (BASELINE.json configs[1]: B=256 per GPU, L=96, cfg 9.0, fp32), synthetic inputs.
+
+One "step" = one pass of the hot path over one batch: x_T (Philox, on device) -> 1000 x
+[512-sequence DiT forward + CFG combine + DDPM update] -> LA-VAE decode to (256,96).  Inputs
+(text embeddings, weights) are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU = weak scaling: every rank samples its own 256-series shard (global rows
+[256*rank, 256*rank+256) of the Philox stream); no data-path collective, RCCL only for the
+barrier and the max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+# algorithmic FLOPs
+FLOP_ATTN_PER_SEQ_BLOCK = 2 * 2 * 4 * 480 * 480 * 32          # QK^T + PV, 4 heads = 117.96 MFLOP
+FLOP_FORWARD_PER_SEQ = 0.977e9
+PEAK_FP32_MFMA_TFLOPS = 157.3                                 # MI355X_MICROARCH.md, Peak FP32 (matrix)
+
+
+def build_models(dev, seed=2025):
+    from t2ms_amd import synth
+    from model.denoiser.transformer import Transformer
+    from model.pretrained.vqvae import vqvae
+    m = Transformer()
+    m.load_state_dict(synth.make_dit_state_dict(seed), strict=True)   # adaLN re-initialised N(0,0.02)
+    v = vqvae(types.SimpleNamespace(block_hidden_size=128, num_residual_layers=2, res_hidden_size=256,
+                                    embedding_dim=64))
+    v.load_state_dict(synth.make_vae_state_dict(seed), strict=True)
+    return m.to(dev).eval(), v.to(dev).eval()
+
+
+def time_attention_kernel(dev, n_seq, iters=20):
+    """Average duration of the dominant kernel (fused attention) at the workload's shape, with HIP
+    events on the stream it is launched on."""
+    from t2ms_amd import _lib as L
+    BH = n_seq * 4
+    g = torch.Generator(device=dev).manual_seed(1)
+    q, k, v = (torch.randn(BH, 480, 32, device=dev, generator=g) for _ in range(3))
+    o = torch.empty_like(q)
+    st = torch.cuda.current_stream(dev)
+    lib = L.lib()
+    for _ in range(3):
+        L.check(lib.t2s_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, st.cuda_stream))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        L.check(lib.t2s_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, st.cuda_stream))
+    e1.record(st)
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def cpu_baseline(batch, diff_steps, cfg, length, n_cfg_steps=4):
+    """The CPU oracle (torch fp32, all host threads) on a bounded sample of the same workload:
+    n_cfg_steps CFG steps at the full batch + one decode, extrapolated to diff_steps steps (every
+    step costs the same)."""
+    from oracle import t2s_oracle as O
+    from t2ms_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synth.make_dit_state_dict(2025)
+    vsd = synth.make_vae_state_dict(2025)
+    x = synth.make_latents(2025, batch)
+    text = synth.make_text_embeddings(2025, batch)
+    tab = O.ddpm_tables(diff_steps)
+    g = torch.Generator().manual_seed(0)
+
+    def one_step(x, j):
+        t = torch.full((batch,), diff_steps - 1 - j, dtype=torch.long)
+        u = O.dit_forward(sd, x, t, None)
+        c = O.dit_forward(sd, x, t, text)
+        return O.ddpm_p_sample(tab, x, u + cfg * (c - u), t, torch.randn(x.shape, generator=g))
+
+    with torch.no_grad():
+        x = one_step(x, 0)  # warm
+        t0 = time.perf_counter()
+        for j in range(1, 1 + n_cfg_steps):
+            x = one_step(x, j)
+        t_step = (time.perf_counter() - t0) / n_cfg_steps
+        t0 = time.perf_counter()
+        O.vae_decode(vsd, x, length)
+        t_dec = time.perf_counter() - t0
+    total = t_step * diff_steps + t_dec
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": batch / total, "unit": "series/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_cfg_steps} CFG steps (2 DiT forwards + DDPM update) at B={batch} + 1 decode, "
+                      f"extrapolated x{diff_steps}/{n_cfg_steps}; {t_step:.3f} s/step; CPU: {cpu_model}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2, help="timed batches (each = full 1000-step sampling of B series)")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="series per GPU")
+    ap.add_argument("--diffusion-steps", type=int, default=1000)
+    ap.add_argument("--cfg-scale", type=float, default=9.0)
+    ap.add_argument("--length", type=int, default=96)
+    ap.add_argument("--backbone", default="ddpm", choices=["ddpm", "flowmatching"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from t2ms_amd import synth
+    from t2ms_amd.sampler import Sampler
+
+    B = args.batch
+    model, vae = build_models(dev)
+    sampler = Sampler(model, vae.decoder, args.backbone, args.diffusion_steps, args.cfg_scale, B, args.length,
+                      dev, use_graph=not args.no_graph, seed=2025, row0=rank * B)
+    text = synth.make_text_embeddings(2025, B, row0=rank * B).to(dev)
+    sampler.run(text, decode=True)                      # allocates persistent buffers, captures the graph
+    for _ in range(max(0, args.warmup - 1)):
+        sampler.run_inplace(decode=True)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lat, series = sampler.run_inplace(decode=True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert bool(torch.isfinite(series).all()) and bool(torch.isfinite(lat).all())
+
+    total_series = args.steps * B * world
+    value = total_series / elapsed
+    out = {
+        "metric": "generated series/sec (B=256, L=96, 1000-step DDPM)",
+        "value": value, "unit": "series/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[1]: DiT denoiser, {args.diffusion_steps}-step {args.backbone} with CFG "
+                               f"(2 forwards/step), B={B}/GPU, L={args.length}, cfg_scale={args.cfg_scale}, "
+                               f"LA-VAE decode; Philox noise on device; hipGraph={'off' if args.no_graph else 'on'}",
+                   "global_batch": B * world, "diffusion_steps": args.diffusion_steps, "parallelism": f"batch-shard x{world}"},
+    }
+    if rank == 0:
+        # roofline of the dominant kernel (fused attention; 48 % of all FLOPs), same shapes as the workload
+        t_attn = time_attention_kernel(dev, 2 * B)
+        flop_attn = FLOP_ATTN_PER_SEQ_BLOCK * 2 * B
+        achieved = flop_attn / t_attn / 1e12
+        traffic = None
+        tfile = os.path.join(REPO, "profiles", "attn_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            except (OSError, ValueError):
+                traffic = None
+        out["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel", "achieved": achieved,
+                           "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                           "traffic": traffic, "avg_launch_us": t_attn * 1e6,
+                           "flop_per_launch": flop_attn}
+        # whole-step figure for context: all DiT FLOPs / wall time
+        step_flops = FLOP_FORWARD_PER_SEQ * 2 * B * args.diffusion_steps * args.steps
+        out["whole_path_tflops"] = step_flops / elapsed / 1e12
+        out["whole_path_frac_of_fp32_mfma_peak"] = out["whole_path_tflops"] / PEAK_FP32_MFMA_TFLOPS
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(B, args.diffusion_steps, args.cfg_scale, args.length)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

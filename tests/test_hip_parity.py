@@ -224,18 +224,18 @@ def test_fused_ddpm_step_vs_oracle(dev):
     x, u, c, z = (torch.from_numpy(rs.randn(B, 64, 30).astype(np.float32)) for _ in range(4))
     tab = O.ddpm_tables(T)
     coef = ddpm_host_tables(T)["coef"].to(dev)
+    ud, cd, zd = u.to(dev), c.to(dev), z.to(dev)   # keep the device copies alive across the launches
     for t_idx in (0, 1, 517, 999):
         pred = u + 9.0 * (c - u)
         ref = O.ddpm_p_sample(tab, x, pred, torch.full((B,), t_idx), z)
         xd = x.to(dev).clone()
-        L.check(L.lib().t2s_ddpm_step(xd.data_ptr(), u.to(dev).data_ptr(), c.to(dev).data_ptr(),
-                                      z.to(dev).data_ptr(), coef.data_ptr(), t_idx, 9.0, 0, 0, 0, B,
-                                      L.stream_ptr(dev)))
+        L.check(L.lib().t2s_ddpm_step(xd.data_ptr(), ud.data_ptr(), cd.data_ptr(), zd.data_ptr(),
+                                      coef.data_ptr(), t_idx, 9.0, 0, 0, 0, B, L.stream_ptr(dev)))
         assert _maxdiff(xd, ref) < 2e-5, t_idx
     # RF step
     ref = O.rf_euler(x, u + 5.0 * (c - u), 0.01)
     xd = x.to(dev).clone()
-    L.check(L.lib().t2s_rf_step(xd.data_ptr(), u.to(dev).data_ptr(), c.to(dev).data_ptr(), 5.0, 0.01, B,
+    L.check(L.lib().t2s_rf_step(xd.data_ptr(), ud.data_ptr(), cd.data_ptr(), 5.0, 0.01, B,
                                 L.stream_ptr(dev)))
     assert _maxdiff(xd, ref) < 2e-6
 
