@@ -66,13 +66,31 @@ def time_attention_kernel(dev, n_seq, iters=20):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually use: min(affinity mask, cgroup cpu quota, 16).
+    os.cpu_count() reports the whole host (256 on the GPU box) although a one-GPU job owns a
+    16-core share; oversubscribing torch's pool there is 17x slower than using the share."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("T2S_CPU_BASELINE_THREADS", "16"))))
+
+
 def cpu_baseline(batch, diff_steps, cfg, length, n_cfg_steps=4):
     """The CPU oracle (torch fp32, all host threads) on a bounded sample of the same workload:
     n_cfg_steps CFG steps at the full batch + one decode, extrapolated to diff_steps steps (every
     step costs the same)."""
     from oracle import t2s_oracle as O
     from t2ms_amd import synth
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     sd = synth.make_dit_state_dict(2025)
     vsd = synth.make_vae_state_dict(2025)

@@ -12,6 +12,10 @@
 //   O^T[d][query] += V^T P^T         (A operand = V rows from LDS)
 // with MFMA step r contracting the key pair {klo(r), klo(r)+4} that register r holds in the
 // two lane halves.  No LDS round trip for P, no transposes.
+//
+// FRAG = true: q/k/v/o are in the library's fragment-major layout (t2s_common.h: frag_index;
+// q/k/v per head with C = 32, o per sequence with C = 128) so Q loads, K/V staging reads and
+// O stores are contiguous 1 KiB per wave instruction.  FRAG = false: plain (BH,480,32).
 #include "t2s_common.h"
 
 namespace t2s {
@@ -19,11 +23,11 @@ namespace t2s {
 constexpr int KSTR = 36;  // padded K row stride (floats): conflict-free ds_read_b128 across 16 rows
 constexpr int ATTN_LDS_BYTES = (NTOK * KSTR + NTOK * DH) * 4;  // 130,560
 
+template <bool FRAG>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__ q,
                                                        const float* __restrict__ k,
                                                        const float* __restrict__ v,
-                                                       float* __restrict__ o, int o_row_stride,
-                                                       int o_head_stride, int o_seq_stride) {
+                                                       float* __restrict__ o) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;
     float* Vs = smem + NTOK * KSTR;
@@ -43,9 +47,17 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
     for (int idx = tid; idx < NTOK * DH / 4; idx += 512) {
         const f32x4 kv = reinterpret_cast<const f32x4*>(kg)[idx];
         const f32x4 vv = reinterpret_cast<const f32x4*>(vg)[idx];
-        const int row = idx >> 3, c4 = idx & 7;
-        *reinterpret_cast<f32x4*>(Ks + row * KSTR + c4 * 4) = kv;
-        *reinterpret_cast<f32x4*>(Vs + row * DH + c4 * 4) = vv;
+        int row, col;
+        if constexpr (FRAG) {  // idx = (tile*4 + g)*64 + l
+            const int l = idx & 63, g = (idx >> 6) & 3, tile = idx >> 8;
+            row = tile * 32 + (l & 31);
+            col = 8 * g + 4 * (l >> 5);
+        } else {
+            row = idx >> 3;
+            col = (idx & 7) * 4;
+        }
+        *reinterpret_cast<f32x4*>(Ks + row * KSTR + col) = kv;
+        *reinterpret_cast<f32x4*>(Vs + row * DH + col) = vv;
     }
     __syncthreads();
 
@@ -53,15 +65,15 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
     const float qscale = 0.17677669529663687f * 1.4426950408889634f;
 
     for (int qt = wave; qt < NTOK / 32; qt += 8) {
-        // Q^T fragment: lane (i,half) holds Q[qt*32+i][16*half + 4c + e]
+        // Q^T fragment: lane (i,half) holds Q[qt*32+i][8g + 4*half + e]
         f32x4 qf[4];
-        {
-            const float* qrow = qg + (size_t)(qt * 32 + i) * DH + 16 * half;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                qf[c] = *reinterpret_cast<const f32x4*>(qrow + 4 * c);
-                qf[c] *= qscale;
-            }
+        for (int g = 0; g < 4; ++g) {
+            if constexpr (FRAG)
+                qf[g] = reinterpret_cast<const f32x4*>(qg)[(qt * 4 + g) * 64 + lane];
+            else
+                qf[g] = *reinterpret_cast<const f32x4*>(qg + (size_t)(qt * 32 + i) * DH + 8 * g + 4 * half);
+            qf[g] *= qscale;
         }
         f32x16 ot;
 #pragma unroll
@@ -74,12 +86,12 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
             f32x16 st;
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[r] = 0.f;
-            const float* krow = Ks + (jb * 32 + i) * KSTR + 16 * half;
+            const float* krow = Ks + (jb * 32 + i) * KSTR + 4 * half;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f32x4 kf = *reinterpret_cast<const f32x4*>(krow + 4 * c);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(krow + 8 * g);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) st = mfma32(kf[e], qf[c][e], st);
+                for (int e = 0; e < 4; ++e) st = mfma32(kf[e], qf[g][e], st);
             }
             // ---- online softmax over this lane pair's 32 keys ----
             float mloc = st[0];
@@ -109,34 +121,36 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
         // ---- normalise and store O[query i][d]: lane holds d = 8g + 4*half + (0..3) ----
         const float l_tot = l_lane + xhalf(l_lane);
         const float inv = 1.0f / l_tot;
-        float* orow = o + (size_t)(bh / NH) * o_seq_stride + (size_t)(bh % NH) * o_head_stride +
-                      (size_t)(qt * 32 + i) * o_row_stride + 4 * half;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            f32x4 w = {ot[4 * g + 0] * inv, ot[4 * g + 1] * inv, ot[4 * g + 2] * inv,
-                       ot[4 * g + 3] * inv};
-            *reinterpret_cast<f32x4*>(orow + 8 * g) = w;
+            const f32x4 w = {ot[4 * g + 0] * inv, ot[4 * g + 1] * inv, ot[4 * g + 2] * inv,
+                             ot[4 * g + 3] * inv};
+            if constexpr (FRAG) {
+                // o is (S*480,128) fragment-major: tile = seq*15 + qt, G = head*4 + g
+                const int seq = bh / NH, head = bh % NH;
+                reinterpret_cast<f32x4*>(o)[(((size_t)seq * (NTOK / 32) + qt) * 16 + head * 4 + g) * 64 + lane] = w;
+            } else {
+                *reinterpret_cast<f32x4*>(o + ((size_t)bh * NTOK + qt * 32 + i) * DH + 8 * g + 4 * half) = w;
+            }
         }
     }
 }
 
-// o layout is parameterised so the same kernel serves the standalone C-ABI entry
-// ((BH,480,32) output) and the DiT ((S,480,128) with head h at columns 32h..32h+31).
 int attn_init() {  // once, outside any stream capture
     static bool attr_set = false;
     if (!attr_set) {
-        T2S_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          ATTN_LDS_BYTES));
+        T2S_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS_BYTES));
+        T2S_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS_BYTES));
         attr_set = true;
     }
     return T2S_OK;
 }
 
-int launch_attn(const float* q, const float* k, const float* v, float* o, int BH, int o_row_stride,
-                int o_head_stride, int o_seq_stride, hipStream_t st) {
-    attn_fwd_kernel<<<BH, 512, ATTN_LDS_BYTES, st>>>(q, k, v, o, o_row_stride, o_head_stride,
-                                                      o_seq_stride);
+// DiT-internal launch: fragment-major q/k/v (per head) and o (per sequence)
+int launch_attn_frag(const float* q, const float* k, const float* v, float* o, int BH, hipStream_t st) {
+    attn_fwd_kernel<true><<<BH, 512, ATTN_LDS_BYTES, st>>>(q, k, v, o);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }
@@ -148,7 +162,7 @@ extern "C" int t2s_attn_fwd(const float* q, const float* k, const float* v, floa
     T2S_REQUIRE(q && k && v && o, "t2s_attn_fwd: NULL pointer");
     T2S_REQUIRE(BH > 0, "t2s_attn_fwd: BH=%d must be > 0", BH);
     if (int rc = t2s::attn_init()) return rc;
-    // (BH,480,32) output: bh = seq*NH + head -> offset bh*480*32
-    return t2s::launch_attn(q, k, v, o, BH, t2s::DH, t2s::NTOK * t2s::DH,
-                            t2s::NH * t2s::NTOK * t2s::DH, (hipStream_t)stream);
+    t2s::attn_fwd_kernel<false><<<BH, 512, t2s::ATTN_LDS_BYTES, (hipStream_t)stream>>>(q, k, v, o);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
 }

@@ -75,4 +75,21 @@ __host__ __device__ inline size_t packed_index(int n, int k, int K) {
     return ((((size_t)nt * (K >> 3) + g) * 64) + (h * 32 + j)) * 4 + e;
 }
 
+// "Fragment-major" activation layout used BETWEEN the library's own kernels (never at the C ABI):
+// a (rows, C) fp32 matrix with rows % 32 == 0 and C % 8 == 0 is stored as
+//   [tile = row/32][G = col/8][lane = 32*((col/4)&1) + row%32][e = col%4]
+// i.e. exactly one MFMA operand/accumulator fragment (float4 per lane) per 1 KiB, so every
+// wave-level load/store of a token tile is one contiguous 1 KiB transaction.
+__host__ __device__ inline size_t frag_index(int row, int col, int C) {
+    const int tile = row >> 5, i = row & 31, G = col >> 3, h = (col >> 2) & 1, e = col & 3;
+    return ((((size_t)tile * (C >> 3) + G) * 64) + (h * 32 + i)) * 4 + e;
+}
+
+// LDS-DMA: 64 lanes x 16 B from per-lane global addresses to a wave-uniform LDS base (+16*lane)
+__device__ __forceinline__ void glds16(const f32x4* gsrc_lane, f32x4* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)gsrc_lane,
+        (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 }  // namespace t2s

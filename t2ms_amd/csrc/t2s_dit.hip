@@ -1,12 +1,15 @@
 // DiT denoiser forward for MI355X: handle, weight packing, small VALU kernels and the
 // per-forward launch sequence.  Mirrors Transformer.forward
-// (reference model/denoiser/transformer.py:158-193); heavy lifting is in t2s_gemm.h
-// (fused linears) and t2s_attn.hip (fused attention).
-#include <mutex>
-#include <string>
+// (reference model/denoiser/transformer.py:158-193).  The heavy lifting is in
+//   t2s_rows.h  : the register-resident row-local chain (proj, MLP, next block's qkv)
+//   t2s_attn.hip: fused attention
+//   t2s_gemm.h  : the adaLN modulation GEMM (SiLU prologue)
+// Between kernels the residual stream, the attention output and q/k/v stay in the
+// fragment-major layout (t2s_common.h: frag_index).
 #include <vector>
 
 #include "t2s_gemm.h"
+#include "t2s_rows.h"
 
 namespace t2s {
 
@@ -19,19 +22,25 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-int launch_attn(const float* q, const float* k, const float* v, float* o, int BH, int o_row_stride,
-                int o_head_stride, int o_seq_stride, hipStream_t st);
+int launch_attn_frag(const float* q, const float* k, const float* v, float* o, int BH, hipStream_t st);
 int attn_init();
 
 // ------------------------------------------------------------------ small kernels
+// W (N,K) row-major -> MFMA-fragment order.  mode 0: packed_index (tile-major: [nt][G][lane][e]);
+// mode 1 (fc2, K=256): chunk order [c = G/4][nt][g = G%4][lane][e] so the 16 fragments one fc1
+// chunk feeds into fc2 are one contiguous 16 KiB (t2s_rows.h).
 __global__ void pack_weight_kernel(const float* __restrict__ W, float* __restrict__ P, int N, int K,
-                                   int n_offset, int K_total_rows) {
-    // W is (N,K); packed destination covers rows [n_offset, n_offset+N) of a (K_total_rows,K) matrix
+                                   int n_offset, int mode) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * K) return;
-    const int n = idx / K, k = idx - n * K;
-    P[packed_index(n + n_offset, k, K)] = W[idx];
-    (void)K_total_rows;
+    const int n = idx / K + n_offset, k = idx - (idx / K) * K;
+    if (mode == 0) {
+        P[packed_index(n, k, K)] = W[idx];
+    } else {
+        const int nt = n >> 5, j = n & 31, G = k >> 3, h = (k >> 2) & 1, e = k & 3;
+        const int c = G >> 2, g = G & 3;
+        P[((((size_t)(c * (N >> 5) + nt) * 4 + g) * 64) + (h * 32 + j)) * 4 + e] = W[idx];
+    }
 }
 
 // TimeEmbedding.forward (transformer.py:30-40): out[b] = [sin(100 t / f) | cos(100 t / f)]
@@ -62,15 +71,17 @@ __global__ void cond_kernel(float* __restrict__ c, const float* __restrict__ tem
 
 // patchify (transformer.py:166-172): token n = hh*32 + ww reads the 2x2 patch
 // in[b][2ww+j][2hh+i]; conv 1->4 (2x2, stride 2), Linear 4->128, + pos_embed.
-// Sequence s reads latent row s % B (both CFG branches share x).
+// Sequence s reads latent row s % B (both CFG branches share x).  Output fragment-major.
 __global__ __launch_bounds__(256) void patchify_kernel(
     const float* __restrict__ x, int B, float* __restrict__ h, int S, const float* __restrict__ cw,
     const float* __restrict__ cb, const float* __restrict__ pw, const float* __restrict__ pb,
     const float* __restrict__ pos) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (token, float4 column)
-    const int c4 = gid & 31;
-    const int tokg = gid >> 5;
-    if (tokg >= S * NTOK) return;
+    // one thread per output float4; consecutive threads walk the fragment-major order
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= S * NTOK * 32) return;
+    const int l = gid & 63, G = (gid >> 6) & 15, tile = gid >> 10;
+    const int tokg = tile * 32 + (l & 31);
+    const int c4 = 2 * G + (l >> 5);  // float4 column index: cols 4*c4 .. 4*c4+3
     const int s = tokg / NTOK, n = tokg - s * NTOK;
     const int hh = n >> 5, ww = n & 31;
     const float* xin = x + (size_t)(s % B) * LAT;
@@ -99,11 +110,12 @@ __global__ __launch_bounds__(256) void patchify_kernel(
         acc += w.w * cv[3];
         o[e] = acc + pb[d] + pos[n * D + d];
     }
-    *reinterpret_cast<f32x4*>(h + (size_t)tokg * D + c4 * 4) = o;
+    reinterpret_cast<f32x4*>(h)[gid] = o;
 }
 
 // final layer (transformer.py:182-191): affine LayerNorm (eps 1e-5), Linear 128->4, unpatchify:
 // out[s][(2ww+pw)*30 + 2hh+ph] = y[ph*2+pw].  Sequences [0,split) go to out0, the rest to out1.
+// One wave per 32-token tile; lane (i,half) holds the 64 features {8G+4half+e} of token i.
 __global__ __launch_bounds__(256) void final_kernel(const float* __restrict__ h, int S,
                                                     const float* __restrict__ lnw,
                                                     const float* __restrict__ lnb,
@@ -111,40 +123,61 @@ __global__ __launch_bounds__(256) void final_kernel(const float* __restrict__ h,
                                                     const float* __restrict__ ob,
                                                     float* __restrict__ out0,
                                                     float* __restrict__ out1, int split) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c4 = gid & 31;
-    int tokg = gid >> 5;
-    const bool valid = tokg < S * NTOK;
-    if (!valid) tokg = S * NTOK - 1;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(h + (size_t)tokg * D + c4 * 4);
-    float s1 = (v.x + v.y) + (v.z + v.w);
+    const int lane = threadIdx.x & 63, half = lane >> 5;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile * 32 >= S * NTOK) return;
+    const f32x4* hr = reinterpret_cast<const f32x4*>(h) + (size_t)tile * 16 * 64 + lane;
+    f32x4 v[16];
+    float s1 = 0.f;
 #pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+    for (int G = 0; G < 16; ++G) {
+        v[G] = hr[G * 64];
+        s1 += (v[G].x + v[G].y) + (v[G].z + v[G].w);
+    }
+    s1 += xhalf(s1);
     const float mean = s1 * (1.0f / 128.0f);
-    const f32x4 d = v - mean;
-    float s2 = (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    float s2 = 0.f;
 #pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+    for (int G = 0; G < 16; ++G) {
+        v[G] = v[G] - mean;
+        s2 += (v[G].x * v[G].x + v[G].y * v[G].y) + (v[G].z * v[G].z + v[G].w * v[G].w);
+    }
+    s2 += xhalf(s2);
     const float rstd = rsqrtf(s2 * (1.0f / 128.0f) + 1e-5f);
-    const f32x4 g = *reinterpret_cast<const f32x4*>(lnw + c4 * 4);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(lnb + c4 * 4);
-    const f32x4 y = (d * rstd) * g + b;
-    float acc[4];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(ow + p * D + c4 * 4);
-        float a = (y.x * w.x + y.y * w.y) + (y.z * w.z + y.w * w.w);
+    for (int G = 0; G < 16; ++G) {
+        const int col = 8 * G + 4 * half;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(lnw + col);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(lnb + col);
+        const f32x4 y = (v[G] * rstd) * g + b;
 #pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
-        acc[p] = a + ob[p];
+        for (int p = 0; p < 4; ++p) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(ow + p * D + col);
+            acc[p] += (y.x * w.x + y.y * w.y) + (y.z * w.z + y.w * w.w);
+        }
     }
-    if (valid && c4 < 4) {
-        const int s = tokg / NTOK, n = tokg - s * NTOK;
-        const int hh = n >> 5, ww = n & 31;
-        const int ph = c4 >> 1, pw = c4 & 1;
-        float* dst = (s < split) ? out0 + (size_t)s * LAT : out1 + (size_t)(s - split) * LAT;
-        dst[(2 * ww + pw) * LATW + 2 * hh + ph] = acc[c4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[p] += xhalf(acc[p]);
+    // lane half 0 writes patch outputs p = 0,1; half 1 writes p = 2,3
+    const int tokg = tile * 32 + (lane & 31);
+    const int s = tokg / NTOK, n = tokg - s * NTOK;
+    const int hh = n >> 5, ww = n & 31;
+    float* dst = (s < split) ? out0 + (size_t)s * LAT : out1 + (size_t)(s - split) * LAT;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int p = 2 * half + q;
+        const int ph = p >> 1, pw = p & 1;
+        dst[(2 * ww + pw) * LATW + 2 * hh + ph] = (half ? acc[2 + q] : acc[q]) + ob[p];
     }
+}
+
+// fragment-major (rows,128) -> row-major, for the test tap
+__global__ void unfrag128_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * D) return;
+    const int row = idx >> 7, col = idx & 127;
+    dst[idx] = src[frag_index(row, col, D)];
 }
 
 }  // namespace t2s
@@ -155,12 +188,12 @@ using namespace t2s;
 struct t2s_dit {
     int max_seqs = 0;
     // parameters (device)
-    float* arena = nullptr;  // all small fp32 params, offsets below
+    float* arena = nullptr;  // all parameters, offsets below
     float *conv_w, *conv_b, *patch_w, *patch_b, *pos, *ln_w, *ln_b, *out_w, *out_b, *freqs;
     float *qkv_b[NBLK], *proj_b[NBLK], *fc1_b[NBLK], *fc2_b[NBLK], *ada_b;
-    f32x4 *qkv_p[NBLK], *proj_p[NBLK], *fc1_p[NBLK], *fc2_p[NBLK], *ada_p;
-    // workspace (device)
-    float *h = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *ao = nullptr, *mid = nullptr;
+    f32x4 *qkv_p[NBLK], *proj_p[NBLK], *fc1_p[NBLK], *fc2_c[NBLK], *ada_p;
+    // workspace (device), activations fragment-major
+    float *h = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *ao = nullptr;
     float *mod = nullptr, *c = nullptr;
 };
 
@@ -180,10 +213,10 @@ int copy_param(float* dst, const float* src, size_t n, hipStream_t st) {
     return T2S_OK;
 }
 
-int pack(const float* W, f32x4* P, int N, int K, int n_offset, hipStream_t st) {
+int pack(const float* W, f32x4* P, int N, int K, int n_offset, int mode, hipStream_t st) {
     const int total = N * K;
     pack_weight_kernel<<<(total + 255) / 256, 256, 0, st>>>(W, reinterpret_cast<float*>(P), N, K,
-                                                            n_offset, 0);
+                                                            n_offset, mode);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }
@@ -215,11 +248,11 @@ int upload_weights(t2s_dit* h, const t2s_dit_weights* w, hipStream_t st) {
         CP(h->fc1_b[i], b.fc1_b, 2 * D);
         CP(h->fc2_b[i], b.fc2_b, D);
         CP(h->ada_b + i * MODW, b.ada_b, MODW);
-        if ((rc = pack(b.qkv_w, h->qkv_p[i], 3 * D, D, 0, st)) != T2S_OK) return rc;
-        if ((rc = pack(b.proj_w, h->proj_p[i], D, D, 0, st)) != T2S_OK) return rc;
-        if ((rc = pack(b.fc1_w, h->fc1_p[i], 2 * D, D, 0, st)) != T2S_OK) return rc;
-        if ((rc = pack(b.fc2_w, h->fc2_p[i], D, 2 * D, 0, st)) != T2S_OK) return rc;
-        if ((rc = pack(b.ada_w, h->ada_p, MODW, D, i * MODW, st)) != T2S_OK) return rc;
+        if ((rc = pack(b.qkv_w, h->qkv_p[i], 3 * D, D, 0, 0, st)) != T2S_OK) return rc;
+        if ((rc = pack(b.proj_w, h->proj_p[i], D, D, 0, 0, st)) != T2S_OK) return rc;
+        if ((rc = pack(b.fc1_w, h->fc1_p[i], 2 * D, D, 0, 0, st)) != T2S_OK) return rc;
+        if ((rc = pack(b.fc2_w, h->fc2_c[i], D, 2 * D, 0, 1, st)) != T2S_OK) return rc;
+        if ((rc = pack(b.ada_w, h->ada_p, MODW, D, i * MODW, 0, st)) != T2S_OK) return rc;
     }
 #undef CP
     return T2S_OK;
@@ -245,40 +278,32 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
         T2S_LAUNCH_CHECK();
     }
     const int M = S * NTOK;
+    // Row-local chain as one register-resident kernel per block (t2s_rows.h):
+    //   rows<qkv only>(block 0) ; { attention(i) ; rows<proj+MLP of i, qkv of i+1> } x 4
+    auto rows_args = [&](int blk, int qkv_blk) {
+        RowArgs a{};
+        a.x = h->h; a.ao = h->ao; a.mod = h->mod; a.M = M; a.blk = blk; a.qkv_blk = qkv_blk;
+        if (blk >= 0) {
+            a.Wp = h->proj_p[blk]; a.W1 = h->fc1_p[blk]; a.W2c = h->fc2_c[blk];
+            a.bp = h->proj_b[blk]; a.b1 = h->fc1_b[blk]; a.b2 = h->fc2_b[blk];
+        }
+        if (qkv_blk >= 0) { a.Wq = h->qkv_p[qkv_blk]; a.bq = h->qkv_b[qkv_blk]; }
+        a.q = h->q; a.k = h->k; a.v = h->v;
+        return a;
+    };
+    if ((rc = launch_dit_rows<false, true>(rows_args(-1, 0), st)) != T2S_OK) return rc;
     for (int i = 0; i < NBLK; ++i) {
-        const int base = i * MODW;
-        {   // LN1 + modulate + qkv linear, scattered to (S,4,480,32) q/k/v
-            GemmArgs a{};
-            a.A = h->h; a.Wp = h->qkv_p[i]; a.bias = h->qkv_b[i]; a.M = M; a.N = 3 * D;
-            a.mod = h->mod; a.shift_off = base + 0 * D; a.scale_off = base + 1 * D;
-            a.q = h->q; a.k = h->k; a.v = h->v;
-            if ((rc = launch_gemm_rows<128, 3, PRO_LNMOD, EPI_QKV>(a, st)) != T2S_OK) return rc;
-        }
-        if ((rc = launch_attn(h->q, h->k, h->v, h->ao, S * NH, D, DH, NTOK * D, st)) != T2S_OK)
-            return rc;
-        {   // x += gate_msa * proj(attn)
-            GemmArgs a{};
-            a.A = h->ao; a.Wp = h->proj_p[i]; a.bias = h->proj_b[i]; a.out = h->h; a.M = M; a.N = D;
-            a.mod = h->mod; a.gate_off = base + 2 * D;
-            if ((rc = launch_gemm_rows<128, 1, PRO_PLAIN, EPI_GATERES>(a, st)) != T2S_OK) return rc;
-        }
-        {   // LN2 + modulate + fc1 + GELU(tanh)
-            GemmArgs a{};
-            a.A = h->h; a.Wp = h->fc1_p[i]; a.bias = h->fc1_b[i]; a.out = h->mid; a.M = M; a.N = 2 * D;
-            a.mod = h->mod; a.shift_off = base + 3 * D; a.scale_off = base + 4 * D;
-            if ((rc = launch_gemm_rows<128, 2, PRO_LNMOD, EPI_GELU>(a, st)) != T2S_OK) return rc;
-        }
-        {   // x += gate_mlp * fc2(.)
-            GemmArgs a{};
-            a.A = h->mid; a.Wp = h->fc2_p[i]; a.bias = h->fc2_b[i]; a.out = h->h; a.M = M; a.N = D;
-            a.mod = h->mod; a.gate_off = base + 5 * D;
-            if ((rc = launch_gemm_rows<256, 1, PRO_PLAIN, EPI_GATERES>(a, st)) != T2S_OK) return rc;
-        }
+        if ((rc = launch_attn_frag(h->q, h->k, h->v, h->ao, S * NH, st)) != T2S_OK) return rc;
+        if (i + 1 < NBLK)
+            rc = launch_dit_rows<true, true>(rows_args(i, i + 1), st);
+        else
+            rc = launch_dit_rows<true, false>(rows_args(i, -1), st);
+        if (rc != T2S_OK) return rc;
     }
     {
-        const int threads = S * NTOK * 32;
-        final_kernel<<<(threads + 255) / 256, 256, 0, st>>>(h->h, S, h->ln_w, h->ln_b, h->out_w,
-                                                            h->out_b, out0, out1, split);
+        const int tiles = M / 32;
+        final_kernel<<<(tiles + 3) / 4, 256, 0, st>>>(h->h, S, h->ln_w, h->ln_b, h->out_w, h->out_b,
+                                                      out0, out1, split);
         T2S_LAUNCH_CHECK();
     }
     return T2S_OK;
@@ -298,7 +323,7 @@ int dit_forward_cfg_step(t2s_dit* h, const float* x, const float* temb_table, co
 extern "C" {
 
 const char* t2s_last_error(void) { return t2s::g_err; }
-const char* t2s_version(void) { return "t2s 0.1 gfx950 fp32-mfma"; }
+const char* t2s_version(void) { return "t2s 0.2 gfx950 fp32-mfma"; }
 
 int t2s_dit_create(const t2s_dit_weights* w, int max_seqs, t2s_dit** out) {
     T2S_REQUIRE(w && out, "t2s_dit_create: NULL argument");
@@ -311,12 +336,12 @@ int t2s_dit_create(const t2s_dit_weights* w, int max_seqs, t2s_dit** out) {
                  o_ln_b = p.take(D), o_out_w = p.take(4 * D), o_out_b = p.take(4),
                  o_freqs = p.take(64), o_ada_b = p.take(MODROW), o_ada_p = p.take((size_t)MODROW * D);
     size_t o_qkv_b[NBLK], o_proj_b[NBLK], o_fc1_b[NBLK], o_fc2_b[NBLK];
-    size_t o_qkv_p[NBLK], o_proj_p[NBLK], o_fc1_p[NBLK], o_fc2_p[NBLK];
+    size_t o_qkv_p[NBLK], o_proj_p[NBLK], o_fc1_p[NBLK], o_fc2_c[NBLK];
     for (int i = 0; i < NBLK; ++i) {
         o_qkv_b[i] = p.take(3 * D); o_proj_b[i] = p.take(D); o_fc1_b[i] = p.take(2 * D);
         o_fc2_b[i] = p.take(D);
         o_qkv_p[i] = p.take(3 * D * D); o_proj_p[i] = p.take(D * D);
-        o_fc1_p[i] = p.take(2 * D * D); o_fc2_p[i] = p.take(2 * D * D);
+        o_fc1_p[i] = p.take(2 * D * D); o_fc2_c[i] = p.take(2 * D * D);
     }
     hipError_t e = hipMalloc(&h->arena, p.off * sizeof(float));
     if (e != hipSuccess) {
@@ -335,12 +360,12 @@ int t2s_dit_create(const t2s_dit_weights* w, int max_seqs, t2s_dit** out) {
         h->qkv_p[i] = reinterpret_cast<f32x4*>(A + o_qkv_p[i]);
         h->proj_p[i] = reinterpret_cast<f32x4*>(A + o_proj_p[i]);
         h->fc1_p[i] = reinterpret_cast<f32x4*>(A + o_fc1_p[i]);
-        h->fc2_p[i] = reinterpret_cast<f32x4*>(A + o_fc2_p[i]);
+        h->fc2_c[i] = reinterpret_cast<f32x4*>(A + o_fc2_c[i]);
     }
     const size_t S = (size_t)max_seqs, tokD = S * NTOK * D;
-    float** bufs[] = {&h->h, &h->q, &h->k, &h->v, &h->ao, &h->mid, &h->mod, &h->c};
-    const size_t sizes[] = {tokD, tokD, tokD, tokD, tokD, 2 * tokD, S * MODROW, S * D};
-    for (int i = 0; i < 8; ++i) {
+    float** bufs[] = {&h->h, &h->q, &h->k, &h->v, &h->ao, &h->mod, &h->c};
+    const size_t sizes[] = {tokD, tokD, tokD, tokD, tokD, S * MODROW, S * D};
+    for (int i = 0; i < 7; ++i) {
         e = hipMalloc(bufs[i], sizes[i] * sizeof(float));
         if (e != hipSuccess) {
             set_error("t2s_dit_create: hipMalloc(workspace %d, %zu B) failed: %s", i,
@@ -350,7 +375,6 @@ int t2s_dit_create(const t2s_dit_weights* w, int max_seqs, t2s_dit** out) {
         }
     }
     int rc = attn_init();
-    if (rc == T2S_OK) rc = gemm_rows_init<256, 1, PRO_PLAIN, EPI_GATERES>();
     if (rc == T2S_OK) rc = upload_weights(h, w, nullptr);
     if (rc == T2S_OK && hipStreamSynchronize(nullptr) != hipSuccess) {
         set_error("t2s_dit_create: weight upload failed");
@@ -371,7 +395,7 @@ int t2s_dit_update_weights(t2s_dit* h, const t2s_dit_weights* w, void* stream) {
 
 void t2s_dit_destroy(t2s_dit* h) {
     if (!h) return;
-    float* bufs[] = {h->arena, h->h, h->q, h->k, h->v, h->ao, h->mid, h->mod, h->c};
+    float* bufs[] = {h->arena, h->h, h->q, h->k, h->v, h->ao, h->mod, h->c};
     for (float* b : bufs)
         if (b) (void)hipFree(b);
     delete h;
@@ -407,8 +431,9 @@ int t2s_dit_forward_cfg(t2s_dit* h, const float* x, const float* temb, const flo
 
 int t2s_dit_read_stream(const t2s_dit* h, float* out, int S, void* stream) {
     T2S_REQUIRE(h && out && S > 0 && S <= h->max_seqs, "t2s_dit_read_stream: bad argument");
-    T2S_HIP_CHECK(hipMemcpyAsync(out, h->h, (size_t)S * NTOK * D * sizeof(float),
-                                 hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    const int total = S * NTOK * D;
+    unfrag128_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(h->h, out, S * NTOK);
+    T2S_LAUNCH_CHECK();
     return T2S_OK;
 }
 

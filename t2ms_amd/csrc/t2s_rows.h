@@ -1,0 +1,308 @@
+// The DiT's row-local chain as ONE register-resident kernel (MI355X / gfx950).
+//
+// Everything in a DiT block except attention is independent per token:
+//   x += g1 * proj(attn)            (transformer.py:116, timm Attention.proj)
+//   x += g2 * fc2(gelu(fc1(mod(LN(x)))))      (transformer.py:117, timm Mlp)
+//   q,k,v = qkv(mod(LN(x)))  of the NEXT block (transformer.py:116, timm Attention.qkv)
+// An f32 MFMA operand is one register per lane, and the 32x32 accumulator layout
+// (lane = column, registers = rows {(r&3)+8(r>>2)+4*half}) is -- for TRANSPOSED products
+// Y^T[n][tok] = W[n][:] . act[tok][:] -- exactly the B-operand layout of the next product:
+// step (G,e) of a K-loop contracts the k-pair {8G+e, 8G+4+e} held by the two lane halves.
+// So a wave puts 32 tokens on its lanes and carries them through the whole chain in
+// registers: no intermediate HBM traffic, no LDS round trip for activations (the fc1
+// activation, the post-attention residual and the LayerNorm outputs never leave the
+// register file).
+//
+// Weights are the A operand.  A workgroup (4 waves = 128 tokens) streams them ONCE through a
+// double-buffered 2 x 16 KiB LDS ring filled by LDS-DMA (global_load_lds_dwordx4) one chunk
+// ahead; a chunk = 16 fragments of 1 KiB = one 32-output tile over K = 128 (proj / fc1 / qkv)
+// or the 4 x 4 (n-tile, k-group) fragments one fc1 chunk feeds into fc2.  Waves read
+// fragments with conflict-free ds_read_b128 (lane-linear).  One barrier per chunk
+// (= per 64 MFMAs per wave).
+//
+// Activations live in HBM in the fragment-major layout (t2s_common.h: frag_index), so every
+// global access of this kernel is a contiguous 1 KiB per wave instruction.
+//
+// Per 32-token tile: 256 (proj) + 512 (fc1) + 512 (fc2) + 768 (qkv) MFMAs of 32x32x2.
+#pragma once
+#include "t2s_common.h"
+
+namespace t2s {
+
+constexpr int ROWS_CHUNK_F4 = 1024;                       // float4 per chunk (16 KiB)
+constexpr int ROWS_LDS_BYTES = 2 * ROWS_CHUNK_F4 * 16;    // 32 KiB ring
+
+struct RowArgs {
+    float* x;          // (M,128) residual stream, fragment-major, in place
+    const float* ao;   // (M,128) attention output (pre-proj), fragment-major
+    const float* mod;  // (S,MODROW)
+    int M;             // S*480 (multiple of 32)
+    int blk;           // block whose proj+MLP run (ignored if !DO_MLP)
+    int qkv_blk;       // block whose LN1/modulate/qkv run (ignored if !DO_QKV)
+    const f32x4 *Wp, *W1, *W2c, *Wq;    // packed weights; W2c is fc2 in chunk order [c][nt][g]
+    const float *bp, *b1, *b2, *bq;
+    float *q, *k, *v;  // each (S*4 heads, 480, 32), fragment-major per head
+};
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return x / (1.0f + __expf(-2.0f * u));
+}
+
+// per-register constants: feature n = 32*nt + 8*g + 4*half + e  <->  register 4g+e of tile nt
+__device__ __forceinline__ f32x4 ldc4(const float* __restrict__ vec, int nt, int g, int half) {
+    return *reinterpret_cast<const f32x4*>(vec + 32 * nt + 8 * g + 4 * half);
+}
+
+// LayerNorm (no affine, eps) + modulate over the 128 features a lane pair holds
+__device__ __forceinline__ void ln_modulate(const f32x16 (&x)[4], f32x16 (&y)[4],
+                                            const float* __restrict__ shift,
+                                            const float* __restrict__ scale, int half, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += x[nt][r];
+    s += xhalf(s);
+    const float mean = s * (1.0f / 128.0f);
+    float ss = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = x[nt][r] - mean;
+            ss += d * d;
+        }
+    ss += xhalf(ss);
+    const float rstd = rsqrtf(ss * (1.0f / 128.0f) + eps);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 sc = ldc4(scale, nt, g, half);
+            const f32x4 sh = ldc4(shift, nt, g, half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                y[nt][4 * g + e] = (x[nt][4 * g + e] - mean) * rstd * (1.0f + sc[e]) + sh[e];
+        }
+}
+
+template <bool DO_MLP, bool DO_QKV>
+__global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 wring[];  // [2][1024]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int half = lane >> 5;
+    const int n_tiles = a.M >> 5;
+    int tile = blockIdx.x * 4 + wave;             // 32-token tile of this wave
+    const bool active = tile < n_tiles;           // tail waves compute on a clamped tile, store nothing
+    if (!active) tile = n_tiles - 1;
+    const int seq = (tile * 32) / NTOK;           // 480 = 15*32: a tile never straddles sequences
+    const float* __restrict__ modrow = a.mod + (size_t)seq * MODROW;
+
+    constexpr int N_CHUNKS = (DO_MLP ? 20 : 0) + (DO_QKV ? 12 : 0);
+    auto chunk_src = [&](int ci) -> const f32x4* {
+        if constexpr (DO_MLP) {
+            if (ci < 4) return a.Wp + (size_t)ci * ROWS_CHUNK_F4;
+            if (ci < 20) {
+                const int j = ci - 4;
+                return ((j & 1) ? a.W2c : a.W1) + (size_t)(j >> 1) * ROWS_CHUNK_F4;
+            }
+            ci -= 20;
+        }
+        return a.Wq + (size_t)ci * ROWS_CHUNK_F4;
+    };
+    // each wave DMAs fragments {wave, wave+4, wave+8, wave+12} of the chunk
+    auto fill = [&](int ci) {
+        const f32x4* src = chunk_src(ci) + lane;
+        f32x4* dst = wring + (ci & 1) * ROWS_CHUNK_F4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) glds16(src + (wave + 4 * p) * 64, dst + (wave + 4 * p) * 64);
+    };
+
+    fill(0);
+
+    // residual stream of this lane's token, accumulator layout: x[nt][4g+e] = X[row][32nt+8g+4half+e]
+    f32x16 x[4];
+    {
+        const f32x4* xr = reinterpret_cast<const f32x4*>(a.x) + (size_t)tile * 16 * 64 + lane;
+#pragma unroll
+        for (int G = 0; G < 16; ++G) {
+            const f32x4 t = xr[G * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[G >> 2][4 * (G & 3) + e] = t[e];
+        }
+    }
+    int ci = 0;
+
+    if constexpr (DO_MLP) {
+        const float* __restrict__ mb = modrow + a.blk * MODW;
+        // ---------------- x += gate_msa * (proj(ao) + b) ----------------
+        {
+            f32x16 bop[4];  // B operand: ao[row][8G+4half+e] at bop[G>>2][4(G&3)+e]
+            const f32x4* ar = reinterpret_cast<const f32x4*>(a.ao) + (size_t)tile * 16 * 64 + lane;
+#pragma unroll
+            for (int G = 0; G < 16; ++G) {
+                const f32x4 t = ar[G * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bop[G >> 2][4 * (G & 3) + e] = t[e];
+            }
+            __syncthreads();  // chunk 0 landed (vmcnt(0) + barrier)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                fill(ci + 1);
+                const f32x4* wb = wring + (ci & 1) * ROWS_CHUNK_F4 + lane;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int G = 0; G < 16; ++G) {
+                    const f32x4 w = wb[G * 64];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = mfma32(w[e], bop[G >> 2][4 * (G & 3) + e], acc);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bias = ldc4(a.bp, nt, g, half);
+                    const f32x4 gate = ldc4(mb + 2 * D, nt, g, half);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[nt][4 * g + e] += gate[e] * (acc[4 * g + e] + bias[e]);
+                }
+                __syncthreads();
+                ++ci;
+            }
+        }
+        // ---------------- x += gate_mlp * (fc2(gelu(fc1(mod(LN(x))))) + b2) ----------------
+        f32x4* xw = reinterpret_cast<f32x4*>(a.x) + (size_t)tile * 16 * 64 + lane;
+        {
+            f32x16 xm[4];
+            ln_modulate(x, xm, mb + 3 * D, mb + 4 * D, half, 1e-6f);
+            // Park the post-attention residual in its own HBM slot (each lane re-reads exactly
+            // what it wrote) so the 1024-MFMA MLP loop does not carry 64 more live registers.
+            if (active) {
+#pragma unroll
+                for (int G = 0; G < 16; ++G) {
+                    f32x4 t;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = x[G >> 2][4 * (G & 3) + e];
+                    xw[G * 64] = t;
+                }
+            }
+            f32x16 acc[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll 1
+            for (int c = 0; c < 8; ++c) {  // 32 hidden units per chunk; ci = 4 + 2c (even) here
+                fill(ci + 1);
+                f32x16 hT;
+                {
+                    const f32x4* wb = wring + lane;  // ci even -> ring slot 0
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hT[r] = 0.f;
+#pragma unroll
+                    for (int G = 0; G < 16; ++G) {
+                        const f32x4 w = wb[G * 64];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hT = mfma32(w[e], xm[G >> 2][4 * (G & 3) + e], hT);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.b1 + 32 * c + 8 * g + 4 * half);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hT[4 * g + e] = gelu_tanh_f(hT[4 * g + e] + bias[e]);
+                    }
+                }
+                __syncthreads();
+                ++ci;
+                if (ci + 1 < N_CHUNKS) fill(ci + 1);
+                {   // fc2 partial over k-groups 4c..4c+3 of K=256; fragments ordered [nt][g]
+                    const f32x4* wb = wring + ROWS_CHUNK_F4 + lane;  // ci odd -> ring slot 1
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) {
+                            const f32x4 w = wb[(nt * 4 + g) * 64];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[nt] = mfma32(w[e], hT[4 * g + e], acc[nt]);
+                        }
+                    }
+                }
+                __syncthreads();
+                ++ci;
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bias = ldc4(a.b2, nt, g, half);
+                    const f32x4 gate = ldc4(mb + 5 * D, nt, g, half);
+                    const f32x4 xo = xw[(nt * 4 + g) * 64];   // the parked residual
+                    f32x4 t;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        t[e] = xo[e] + gate[e] * (acc[nt][4 * g + e] + bias[e]);
+                        x[nt][4 * g + e] = t[e];
+                    }
+                    if (active) xw[(nt * 4 + g) * 64] = t;   // final residual stream of this block
+                }
+        }
+    } else {
+        __syncthreads();  // chunk 0 landed
+    }
+
+    if constexpr (DO_QKV) {
+        const float* __restrict__ mb = modrow + a.qkv_blk * MODW;
+        f32x16 xm[4];
+        ln_modulate(x, xm, mb + 0 * D, mb + 1 * D, half, 1e-6f);
+        const int tile_in_seq = tile - seq * (NTOK / 32);
+#pragma unroll 1
+        for (int t = 0; t < 12; ++t) {  // output tile t = which*4 + head
+            if (ci + 1 < N_CHUNKS) fill(ci + 1);
+            f32x4 bias[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                bias[g] = *reinterpret_cast<const f32x4*>(a.bq + 32 * t + 8 * g + 4 * half);
+            const f32x4* wb = wring + (ci & 1) * ROWS_CHUNK_F4 + lane;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int G = 0; G < 16; ++G) {
+                const f32x4 w = wb[G * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = mfma32(w[e], xm[G >> 2][4 * (G & 3) + e], acc);
+            }
+            if (active) {
+                const int which = t >> 2, head = t & 3;
+                float* base = which == 0 ? a.q : (which == 1 ? a.k : a.v);
+                f32x4* dst = reinterpret_cast<f32x4*>(base) +
+                             (((size_t)seq * NH + head) * (NTOK / 32) + tile_in_seq) * 4 * 64 + lane;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = acc[4 * g + e] + bias[g][e];
+                    dst[g * 64] = o;
+                }
+            }
+            __syncthreads();
+            ++ci;
+        }
+    }
+}
+
+template <bool DO_MLP, bool DO_QKV>
+inline int launch_dit_rows(const RowArgs& a, hipStream_t st) {
+    if (a.M <= 0 || a.M % 32 != 0) {
+        set_error("dit_rows: M=%d must be a positive multiple of 32", a.M);
+        return T2S_E_INVALID;
+    }
+    const int tiles = a.M / 32;
+    dit_rows_kernel<DO_MLP, DO_QKV><<<(tiles + 3) / 4, 256, ROWS_LDS_BYTES, st>>>(a);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+}  // namespace t2s
