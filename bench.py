@@ -51,16 +51,17 @@ def time_attention_kernel(dev, n_seq, iters=20):
     from t2ms_amd import _lib as L
     BH = n_seq * 4
     g = torch.Generator(device=dev).manual_seed(1)
+    # random N(0,1) operands in the library's fragment-major layout (a permutation of the plain one)
     q, k, v = (torch.randn(BH, 480, 32, device=dev, generator=g) for _ in range(3))
     o = torch.empty_like(q)
     st = torch.cuda.current_stream(dev)
     lib = L.lib()
     for _ in range(3):
-        L.check(lib.t2s_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, st.cuda_stream))
+        L.check(lib.t2s_attn_fwd_packed(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), n_seq, st.cuda_stream))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(st)
     for _ in range(iters):
-        L.check(lib.t2s_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, st.cuda_stream))
+        L.check(lib.t2s_attn_fwd_packed(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), n_seq, st.cuda_stream))
     e1.record(st)
     e1.synchronize()
     return e0.elapsed_time(e1) * 1e-3 / iters
@@ -213,7 +214,7 @@ def main():
                 traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
             except (OSError, ValueError):
                 traffic = None
-        out["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel", "achieved": achieved,
+        out["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_packed_kernel", "achieved": achieved,
                            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                            "traffic": traffic, "avg_launch_us": t_attn * 1e6,
                            "flop_per_launch": flop_attn}

@@ -119,6 +119,16 @@ int t2s_dit_read_stream(const t2s_dit* h, float* out, int S, void* stream);
 /* Fused softmax(q k^T / sqrt(32)) v for N=480, head_dim=32 (timm Attention.forward
  * core; call site transformer.py:116).  q,k,v: (BH,480,32); o: (BH,480,32). */
 int t2s_attn_fwd(const float* q, const float* k, const float* v, float* o, int BH, void* stream);
+/* The same attention on the library's internal "fragment-major" tensors -- the kernel the DiT
+ * forward actually launches (exposed for benchmarking / tests).  With tile = row/32, i = row%32,
+ * a (480,32) per-head matrix X is stored as float4 fragments
+ *     P[((tile*4 + g)*64 + 32*h + i)*4 + e] = X[32*tile + i][8*g + 4*h + e]
+ * q, k: P of the head's Q and K;  vT: P of V TRANSPOSED, i.e.
+ *     vT[((tile*4 + g)*64 + 32*h + d)*4 + e] = V[32*tile + 8*g + 4*h + e][d];
+ * heads ordered (seq*4 + head).  o: (n_seq*480, 128) with
+ *     o[(((row/32)*16 + G)*64 + 32*h + row%32)*4 + e] = O[row][8*G + 4*h + e]  (G = col/8). */
+int t2s_attn_fwd_packed(const float* q, const float* k, const float* vT, float* o, int n_seq,
+                        void* stream);
 
 /* ------------------------------------------------------------------------ *
  * Diffusion backbones: model/backbone/DDPM.py, model/backbone/rectified_flow.py

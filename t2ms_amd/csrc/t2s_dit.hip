@@ -22,7 +22,7 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-int launch_attn_frag(const float* q, const float* k, const float* v, float* o, int BH, hipStream_t st);
+int launch_attn_packed(const float* q, const float* k, const float* vT, float* o, int BH, hipStream_t st);
 int attn_init();
 
 // ------------------------------------------------------------------ small kernels
@@ -293,7 +293,7 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
     };
     if ((rc = launch_dit_rows<false, true>(rows_args(-1, 0), st)) != T2S_OK) return rc;
     for (int i = 0; i < NBLK; ++i) {
-        if ((rc = launch_attn_frag(h->q, h->k, h->v, h->ao, S * NH, st)) != T2S_OK) return rc;
+        if ((rc = launch_attn_packed(h->q, h->k, h->v, h->ao, S * NH, st)) != T2S_OK) return rc;
         if (i + 1 < NBLK)
             rc = launch_dit_rows<true, true>(rows_args(i, i + 1), st);
         else

@@ -41,7 +41,7 @@ struct RowArgs {
     int qkv_blk;       // block whose LN1/modulate/qkv run (ignored if !DO_QKV)
     const f32x4 *Wp, *W1, *W2c, *Wq;    // packed weights; W2c is fc2 in chunk order [c][nt][g]
     const float *bp, *b1, *b2, *bq;
-    float *q, *k, *v;  // each (S*4 heads, 480, 32), fragment-major per head
+    float *q, *k, *v;  // per head (S*4, 480, 32): q, k fragment-major; v TRANSPOSED fragment-major (V^T)
 };
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
@@ -260,31 +260,53 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
 #pragma unroll 1
         for (int t = 0; t < 12; ++t) {  // output tile t = which*4 + head
             if (ci + 1 < N_CHUNKS) fill(ci + 1);
-            f32x4 bias[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                bias[g] = *reinterpret_cast<const f32x4*>(a.bq + 32 * t + 8 * g + 4 * half);
             const f32x4* wb = wring + (ci & 1) * ROWS_CHUNK_F4 + lane;
+            const int which = t >> 2, head = t & 3;
+            float* base = which == 0 ? a.q : (which == 1 ? a.k : a.v);
+            f32x4* dst = reinterpret_cast<f32x4*>(base) +
+                         (((size_t)seq * NH + head) * (NTOK / 32) + tile_in_seq) * 4 * 64 + lane;
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            if (which < 2) {
+                // q / k tile, transposed product: lane = token, registers = features d
+                f32x4 bias[4];
 #pragma unroll
-            for (int G = 0; G < 16; ++G) {
-                const f32x4 w = wb[G * 64];
+                for (int g = 0; g < 4; ++g)
+                    bias[g] = *reinterpret_cast<const f32x4*>(a.bq + 32 * t + 8 * g + 4 * half);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc = mfma32(w[e], xm[G >> 2][4 * (G & 3) + e], acc);
-            }
-            if (active) {
-                const int which = t >> 2, head = t & 3;
-                float* base = which == 0 ? a.q : (which == 1 ? a.k : a.v);
-                f32x4* dst = reinterpret_cast<f32x4*>(base) +
-                             (((size_t)seq * NH + head) * (NTOK / 32) + tile_in_seq) * 4 * 64 + lane;
+                for (int G = 0; G < 16; ++G) {
+                    const f32x4 w = wb[G * 64];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 o;
+                    for (int e = 0; e < 4; ++e) acc = mfma32(w[e], xm[G >> 2][4 * (G & 3) + e], acc);
+                }
+                if (active) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = acc[4 * g + e] + bias[g][e];
-                    dst[g * 64] = o;
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = acc[4 * g + e] + bias[g][e];
+                        dst[g * 64] = o;
+                    }
+                }
+            } else {
+                // v tile with the MFMA operands swapped: lane = feature d, registers = tokens
+                // {8g+4half+e}: exactly the V^T fragment the attention kernel consumes
+                const float bias = a.bq[32 * t + (lane & 31)];
+#pragma unroll
+                for (int G = 0; G < 16; ++G) {
+                    const f32x4 w = wb[G * 64];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = mfma32(xm[G >> 2][4 * (G & 3) + e], w[e], acc);
+                }
+                if (active) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = acc[4 * g + e] + bias;
+                        dst[g * 64] = o;
+                    }
                 }
             }
             __syncthreads();

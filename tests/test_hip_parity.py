@@ -87,6 +87,39 @@ def test_attention_kernel_vs_oracle(dev):
     assert _maxdiff(od, ref) < 2e-5
 
 
+def _pack_frag(x):
+    """(BH,480,32) -> fragment-major (include/t2s.h, t2s_attn_fwd_packed)."""
+    BH = x.shape[0]
+    # [bh][tile][i][g][h][e] -> [bh][tile][g][h][i][e]
+    return x.reshape(BH, 15, 32, 4, 2, 4).permute(0, 1, 3, 4, 2, 5).contiguous()
+
+
+def _pack_vT(v):
+    """(BH,480,32) -> transposed fragment-major: [bh][tile][g][h][d][e] = V[32 tile + 8g + 4h + e][d]."""
+    BH = v.shape[0]
+    return v.reshape(BH, 15, 4, 2, 4, 32).permute(0, 1, 2, 3, 5, 4).contiguous()
+
+
+def test_attention_packed_kernel_vs_oracle(dev):
+    """The kernel the DiT forward launches (fragment-major operands, LDS-DMA ring), incl. spikes
+    that force the online-softmax rescale at early and late key blocks."""
+    rs = np.random.RandomState(21)
+    n_seq = 3
+    BH = n_seq * 4
+    q, k, v = (torch.from_numpy(rs.randn(BH, 480, 32).astype(np.float32)) for _ in range(3))
+    k[:, 333] = q[:, 100] * 5.0
+    k[:, 5] = q[:, 479] * 4.0
+    k[:, 479] = q[:, 0] * 4.0
+    ref = (torch.softmax((q.double() * 32 ** -0.5) @ k.double().transpose(-1, -2), dim=-1) @ v.double()).float()
+    qd, kd, vd = _pack_frag(q).to(dev), _pack_frag(k).to(dev), _pack_vT(v).to(dev)
+    od = torch.empty(n_seq * 480 * 128, device=dev)
+    L.check(L.lib().t2s_attn_fwd_packed(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), n_seq,
+                                        L.stream_ptr(dev)))
+    # o: [tile = seq*15 + t][G = head*4 + g][h][i][e] = O[seq][head][32 t + i][8g + 4h + e]
+    o = od.cpu().reshape(n_seq, 15, 4, 4, 2, 32, 4).permute(0, 2, 1, 5, 3, 4, 6).reshape(BH, 480, 32)
+    assert _maxdiff(o, ref) < 2e-5
+
+
 def test_attention_online_softmax_rescale_branch(dev):
     """Force the running max to jump at a late key block (rule: a rare data-dependent branch needs
     its own test): one key row is aligned with the queries and scaled up."""
