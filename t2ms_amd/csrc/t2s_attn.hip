@@ -31,12 +31,24 @@ struct SoftmaxState {
     float l_lane;  // this lane's partial row sum
 };
 
+// max / sum over a lane pair (l, l^32) with v_permlane32_swap (VALU; no LDS crossbar round trip):
+// swap(v, v) returns {lo-half of v | lo-half of v} and {hi-half | hi-half}, so op(r0, r1) is the
+// pair-wise result in both halves.
+__device__ __forceinline__ float pair_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float pair_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // online-softmax update of one 32x32 transposed score tile held in st (in: scores, out: P^T)
 __device__ __forceinline__ void softmax_block(f32x16& st, f32x16& ot, SoftmaxState& s) {
     float mloc = st[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[r]);
-    mloc = fmaxf(mloc, xhalf(mloc));
+    mloc = pair_max(mloc);
     const float m_new = fmaxf(s.m_run, mloc);
     const float alpha = __builtin_amdgcn_exp2f(s.m_run - m_new);  // first block: exp2(-inf) = 0
     s.m_run = m_new;
@@ -59,102 +71,427 @@ constexpr int ATT_SLOT_F4 = 512;                        // 4 K + 4 V^T fragments
 constexpr int ATT_LDS_BYTES = ATT_SLOTS * ATT_SLOT_F4 * 16;  // 32 KiB
 constexpr int NKB = NTOK / 32;                          // 15 key blocks / query tiles
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_packed_kernel(const float* __restrict__ q,
-                                                                 const float* __restrict__ k,
-                                                                 const float* __restrict__ vT,
-                                                                 float* __restrict__ o) {
-    extern __shared__ __attribute__((aligned(16))) f32x4 ring[];
-    const int bh = blockIdx.x >> 1;
-    const int part = blockIdx.x & 1;          // query tiles [8*part, 8*part+8)
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const f32x4* qg = reinterpret_cast<const f32x4*>(q) + (size_t)bh * NKB * 256;
-    const f32x4* kg = reinterpret_cast<const f32x4*>(k) + (size_t)bh * NKB * 256;
-    const f32x4* vg = reinterpret_cast<const f32x4*>(vT) + (size_t)bh * NKB * 256;
+// ---- softmax with a sticky reference (the DiT kernel's scheme) ------------------------------
+// On gfx950 the f32 MFMA executes on the vector lanes (measured: MFMA-busy + VALU-busy cycles add
+// up, SQ_VALU_MFMA_COEXEC = 0), so softmax VALU instructions are paid 1:1 in matrix time.  The
+// common path therefore does the minimum: the score accumulator is INITIALISED with -m_ref (a
+// 16-register copy kept per tile: the MFMA C operand may differ from D, so the subtraction is
+// free), then 16 v_exp + a 16-term sum; no per-block max, no output rescale.  m_ref is the true
+// running max as of the last re-reference; a block is re-referenced (classic online-softmax
+// step, recomputed from raw scores) only when its exponentials show that m_ref is stale by
+// more than 2^60 -- detected a posteriori from the row sum, wave-uniformly.  Block 0 always
+// re-references (m_ref starts at -inf, so its common-path sum is +inf).
+constexpr float SM_BIG = 1.152921504606847e18f;   // 2^60
 
-    // this wave DMAs K fragments {wave} and V^T fragment {wave} of every block (8 pieces / 4 waves)
-    auto issue = [&](int jb) {
-        f32x4* slot = ring + (jb & (ATT_SLOTS - 1)) * ATT_SLOT_F4;
-        glds16(kg + (jb * 4 + wave) * 64 + lane, slot + wave * 64);
-        glds16(vg + (jb * 4 + wave) * 64 + lane, slot + 256 + wave * 64);
-    };
-    issue(0);
-    issue(1);
+#if defined(T2S_EXP) && (T2S_EXP & 32)
+__device__ unsigned long long t2s_dbg[8 * 2 * 4096 * 4];  // 2 regions x (4096 WGs x 4 waves) x 8 words
+#define STAMP(i) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); seg[i] += _t - tprev; tprev = _t; }
+#else
+#define STAMP(i)
+#endif
 
-    const int t0 = part * 8 + wave * 2;       // query tiles t0, t0+1 (tile 15 does not exist)
-    const int t1 = (t0 + 1 < NKB) ? t0 + 1 : NKB - 1;
-    const bool t1_valid = t0 + 1 < NKB;
+struct TileState {
+    f32x16 negm;   // -m_ref in all 16 registers (C operand of the first QK MFMA)
+    float m_ref;
+    float l_lane;
+};
+
+// in place: st <- 2^st, returns the lane's 16-term sum
+__device__ __forceinline__ float exp_sum(f32x16& st) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = __builtin_amdgcn_exp2f(st[r]);
+    return ((st[0] + st[1]) + (st[2] + st[3])) + ((st[4] + st[5]) + (st[6] + st[7])) +
+           (((st[8] + st[9]) + (st[10] + st[11])) + ((st[12] + st[13]) + (st[14] + st[15])));
+}
+
+// rare path: raw scores (C = 0) -> new reference, rescale the running sum / output, P^T in st
+__device__ __forceinline__ float rereference(const f32x4 (&kf)[4], const f32x4 (&q)[4], f32x16& st,
+                                             f32x16& ot, TileState& t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st = mfma32(kf[g][e], q[g][e], st);
+    float mloc = st[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[r]);
+    mloc = pair_max(mloc);
+    const float m_new = fmaxf(t.m_ref, mloc);
+    const float alpha = __builtin_amdgcn_exp2f(t.m_ref - m_new);   // 0 on the first block
+    t.m_ref = m_new;
+    t.l_lane *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        ot[r] *= alpha;
+        t.negm[r] = -m_new;
+        st[r] -= m_new;
+    }
+    return exp_sum(st);
+}
+
+// NT = number of query tiles this wave really owns (2, or 1 for the wave holding tile 14 alone).
+// Order per key block jb, K fragments of jb already in registers:
+//   ds_read V(jb) | QK_A, QK_B | exp+sum (A, B), overflow check | PV_A |
+//   wait+barrier(jb+1), DMA(jb+3), ds_read K(jb+1) | PV_B
+// so the LDS latencies and the barrier hide behind matrix work.
+template <int NT>
+__device__ __forceinline__ void attn_packed_body(f32x4* ring, const f32x4* qg, const f32x4* kg,
+                                                 const f32x4* vg, f32x4* og, int bh, int t0, int lane,
+                                                 int wave) {
     f32x4 qa[4], qb[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         qa[g] = qg[(t0 * 4 + g) * 64 + lane] * QSCALE;
-        qb[g] = qg[(t1 * 4 + g) * 64 + lane] * QSCALE;
+        if (NT == 2) qb[g] = qg[((t0 + 1) * 4 + g) * 64 + lane] * QSCALE;
     }
     f32x16 oa, ob;
+    TileState ta, tb;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oa[r] = ob[r] = 0.f;
-    SoftmaxState sa{-INFINITY, 0.f}, sb{-INFINITY, 0.f};
+    for (int r = 0; r < 16; ++r) {
+        oa[r] = ob[r] = 0.f;
+        ta.negm[r] = tb.negm[r] = INFINITY;
+    }
+    ta.m_ref = tb.m_ref = -INFINITY;
+    ta.l_lane = tb.l_lane = 0.f;
 
+    // Blocks 0..2 were issued by the caller.  The DMA is kept exactly three blocks (= 6 glds per
+    // wave) ahead for the WHOLE loop -- past the end it re-fetches the last block into a slot nobody
+    // reads -- so every wait is the same counted `vmcnt(4)`.
+    auto issue_clamped = [&](int jb) {
+        const int src = jb < NKB ? jb : NKB - 1;
+        f32x4* slot = ring + (jb & (ATT_SLOTS - 1)) * ATT_SLOT_F4;
+        glds16(kg + (src * 4 + wave) * 64 + lane, slot + wave * 64);
+        glds16(vg + (src * 4 + wave) * 64 + lane, slot + 256 + wave * 64);
+    };
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_clamped(3);
+    f32x4 kf[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) kf[g] = ring[g * 64 + lane];
+
+#if defined(T2S_EXP) && (T2S_EXP & 32)
+    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tprev;
+#endif
 #pragma unroll 1
     for (int jb = 0; jb < NKB; ++jb) {
-        // block jb landed in every wave's view: own DMA retired (all but the youngest pair),
-        // then the workgroup barrier
-        if (jb < NKB - 1)
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (jb + 2 < NKB) issue(jb + 2);   // slot (jb+2)&3 was last read in iteration jb-2
         const f32x4* slot = ring + (jb & (ATT_SLOTS - 1)) * ATT_SLOT_F4 + lane;
+        f32x4 vf[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) vf[g] = slot[256 + g * 64];
 
-        f32x16 sta, stb;
+        f32x16 sta = ta.negm, stb = tb.negm;     // scores relative to the sticky reference
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sta[r] = stb[r] = 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 kf = slot[g * 64];
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                sta = mfma32(kf[e], qa[g][e], sta);
-                stb = mfma32(kf[e], qb[g][e], stb);
+                sta = mfma32(kf[g][e], qa[g][e], sta);
+                if (NT == 2) stb = mfma32(kf[g][e], qb[g][e], stb);
             }
+        STAMP(0)
+        float psa = exp_sum(sta);
+        float psb = (NT == 2) ? exp_sum(stb) : 0.f;
+        const bool stale = !(psa < SM_BIG) || !(psb < SM_BIG);
+        if (__builtin_amdgcn_ballot_w64(stale) != 0) {   // wave-uniform, rare
+            psa = rereference(kf, qa, sta, oa, ta);
+            if (NT == 2) psb = rereference(kf, qb, stb, ob, tb);
         }
-        softmax_block(sta, oa, sa);
-        softmax_block(stb, ob, sb);
+        ta.l_lane += psa;
+        tb.l_lane += psb;
+        STAMP(1)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 vf = slot[256 + g * 64];
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                oa = mfma32(vf[e], sta[4 * g + e], oa);
-                ob = mfma32(vf[e], stb[4 * g + e], ob);
-            }
+            for (int e = 0; e < 4; ++e) oa = mfma32(vf[g][e], sta[4 * g + e], oa);      // PV_A
+        STAMP(2)
+        // ---- make block jb+1 visible, keep the DMA two blocks ahead, fetch its K fragments ----
+#if !defined(T2S_EXP) || !(T2S_EXP & 8)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        STAMP(3)
+        __builtin_amdgcn_s_barrier();
+        STAMP(4)
+        issue_clamped(jb + 4);   // slot (jb+4)&3 == jb&3: every wave read K(jb), V(jb) before this barrier
+#endif
+        {
+            const f32x4* nslot = ring + ((jb + 1) & (ATT_SLOTS - 1)) * ATT_SLOT_F4 + lane;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) kf[g] = nslot[g * 64];
         }
+        if (NT == 2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ob = mfma32(vf[g][e], stb[4 * g + e], ob);  // PV_B
+        }
+        STAMP(5)
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the trailing (unused) DMAs
+#if defined(T2S_EXP) && (T2S_EXP & 32)
+    if (lane == 0 && blockIdx.x < 4096) {
+        unsigned long long* d = t2s_dbg + (size_t)(blockIdx.x * 4 + wave) * 8;
+        for (int i = 0; i < 6; ++i) d[i] = seg[i];
+        d[6] = tprev - tstart;
+        d[7] = tstart;
+    }
+#endif
 
     // ---- normalise and store O[query][d]: lane (query i, half) holds d = 8g + 4*half + e ----
     const int seq = bh / NH, head = bh % NH;
-    f32x4* og = reinterpret_cast<f32x4*>(o);
     {
-        const float inv = 1.0f / (sa.l_lane + xhalf(sa.l_lane));
+        const float inv = 1.0f / pair_sum(ta.l_lane);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 w = {oa[4 * g] * inv, oa[4 * g + 1] * inv, oa[4 * g + 2] * inv, oa[4 * g + 3] * inv};
             og[(((size_t)seq * NKB + t0) * 16 + head * 4 + g) * 64 + lane] = w;
         }
     }
-    if (t1_valid) {
-        const float inv = 1.0f / (sb.l_lane + xhalf(sb.l_lane));
+    if (NT == 2) {
+        const float inv = 1.0f / pair_sum(tb.l_lane);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 w = {ob[4 * g] * inv, ob[4 * g + 1] * inv, ob[4 * g + 2] * inv, ob[4 * g + 3] * inv};
-            og[(((size_t)seq * NKB + t1) * 16 + head * 4 + g) * 64 + lane] = w;
+            og[(((size_t)seq * NKB + t0 + 1) * 16 + head * 4 + g) * 64 + lane] = w;
         }
     }
 }
 
+__global__ __launch_bounds__(256, 2) void attn_fwd_packed_kernel(const float* __restrict__ q,
+                                                                 const float* __restrict__ k,
+                                                                 const float* __restrict__ vT,
+                                                                 float* __restrict__ o, int BH) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 ring[];
+#if defined(T2S_EXP) && (T2S_EXP & 32)
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
+    // The two workgroups of a (sequence, head) stream the same K/V: give them ids r and r+8 of a
+    // 16-id group so that (round-robin XCD placement) they share an L2.  Speed only.
+    const int grp = blockIdx.x >> 4, rr = blockIdx.x & 15;
+    const int bh = grp * 8 + (rr & 7);
+    const int part = rr >> 3;                 // query tiles [8*part, 8*part+8)
+    if (bh >= BH) return;                     // whole workgroup (grid is padded to 16-id groups)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const f32x4* qg = reinterpret_cast<const f32x4*>(q) + (size_t)bh * NKB * 256;
+    const f32x4* kg = reinterpret_cast<const f32x4*>(k) + (size_t)bh * NKB * 256;
+    const f32x4* vg = reinterpret_cast<const f32x4*>(vT) + (size_t)bh * NKB * 256;
+    f32x4* og = reinterpret_cast<f32x4*>(o);
+
+    // this wave DMAs K fragment {wave} and V^T fragment {wave} of every block (8 pieces / 4 waves)
+    {
+        f32x4* slot0 = ring;
+        f32x4* slot1 = ring + ATT_SLOT_F4;
+        glds16(kg + (0 * 4 + wave) * 64 + lane, slot0 + wave * 64);
+        glds16(vg + (0 * 4 + wave) * 64 + lane, slot0 + 256 + wave * 64);
+        glds16(kg + (1 * 4 + wave) * 64 + lane, slot1 + wave * 64);
+        glds16(vg + (1 * 4 + wave) * 64 + lane, slot1 + 256 + wave * 64);
+        f32x4* slot2 = ring + 2 * ATT_SLOT_F4;
+        glds16(kg + (2 * 4 + wave) * 64 + lane, slot2 + wave * 64);
+        glds16(vg + (2 * 4 + wave) * 64 + lane, slot2 + 256 + wave * 64);
+    }
+    const int t0 = part * 8 + wave * 2;       // query tiles t0, t0+1 (tile 15 does not exist)
+    if (t0 + 1 < NKB)
+        attn_packed_body<2>(ring, qg, kg, vg, og, bh, t0, lane, wave);
+    else
+        attn_packed_body<1>(ring, qg, kg, vg, og, bh, t0, lane, wave);
+#if defined(T2S_EXP) && (T2S_EXP & 32)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && blockIdx.x < 4096) {
+        unsigned long long* d = t2s_dbg + (size_t)(4096 * 4 + blockIdx.x * 4 + wave) * 8;
+        d[0] = t_entry;
+        d[1] = __builtin_amdgcn_s_memtime();
+        d[2] = __builtin_amdgcn_s_getreg(0x1804 | (7 << 11));  // HW_ID low bits: wave, simd, ...
+    }
+#endif
+}
+
+// ------------------------------------------------------------------ persistent variant
+// Measured with in-kernel stamps (tools/probe_attn.py, probe_clock.py): the key-block loop runs at
+// ~96 % of the MFMA roof while two waves share a SIMD, but with two independent 4-wave workgroups
+// per CU the hardware's age-priority arbitration lets the older workgroup run at its stand-alone
+// speed and starves the younger one, which then finishes alone at ~62 % (bimodal durations,
+// 331 vs 496 us).  So here ONE 8-wave workgroup per CU stays resident and walks the heads: both
+// waves of every SIMD belong to the same workgroup and meet at the per-block barrier, which
+// enforces fair progress; a head's 15 query tiles map to the 8 waves x 2 tiles (the 16th slot is
+// skipped), K/V are streamed once per head, and the DMA ring / block loop run CONTINUOUSLY across
+// heads (next head's first blocks already in flight, its Q fragments prefetched).
+constexpr int PERSIST_THREADS = 512;
+
+template <int NT>
+__device__ __forceinline__ void attn_persistent_body(f32x4* ring, const f32x4* qall, const f32x4* kall,
+                                                     const f32x4* vall, f32x4* og, int BH, int lane, int wave) {
+    const int stride = gridDim.x;
+    const int t0 = wave * 2;
+    // this wave DMAs ONE fragment of every block: waves 0-3 the K fragments, 4-7 the V^T fragments.
+    // `jb` may run past 14 into the following heads of this workgroup.
+    const f32x4* my_src = (wave < 4 ? kall : vall) + (wave & 3) * 64 + lane;
+    const int my_dst = (wave < 4 ? 0 : 256) + (wave & 3) * 64;
+    auto issue_block = [&](int bh, int jb, int gslot) {
+        if (jb >= NKB) { jb -= NKB; bh += stride; }
+        if (bh >= BH) { bh -= stride; jb = NKB - 1; }   // past the end: harmless re-fetch
+        glds16(my_src + (size_t)bh * NKB * 256 + jb * 4 * 64,
+               ring + (gslot & (ATT_SLOTS - 1)) * ATT_SLOT_F4 + my_dst);
+    };
+    int bh = blockIdx.x;
+    int gb = 0;                                      // global block counter -> ring slot
+    issue_block(bh, 0, 0);
+    issue_block(bh, 1, 1);
+    issue_block(bh, 2, 2);
+
+    f32x4 qa[4], qb[4], qna[4], qnb[4];
+    {
+        const f32x4* qg = qall + (size_t)bh * NKB * 256;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            qa[g] = qg[(t0 * 4 + g) * 64 + lane] * QSCALE;
+            if (NT == 2) qb[g] = qg[((t0 + 1) * 4 + g) * 64 + lane] * QSCALE;
+            qna[g] = qa[g];
+            qnb[g] = qb[g];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_block(bh, 3, 3);
+    f32x4 kf[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) kf[g] = ring[g * 64 + lane];
+
+#pragma unroll 1
+    for (; bh < BH; bh += stride) {
+        f32x16 oa, ob;
+        TileState ta, tb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            oa[r] = ob[r] = 0.f;
+            ta.negm[r] = tb.negm[r] = INFINITY;
+        }
+        ta.m_ref = tb.m_ref = -INFINITY;
+        ta.l_lane = tb.l_lane = 0.f;
+
+#pragma unroll 1
+        for (int jb = 0; jb < NKB; ++jb, ++gb) {
+            const f32x4* slot = ring + (gb & (ATT_SLOTS - 1)) * ATT_SLOT_F4 + lane;
+            f32x4 vf[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) vf[g] = slot[256 + g * 64];
+            f32x16 sta = ta.negm, stb = tb.negm;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sta = mfma32(kf[g][e], qa[g][e], sta);
+                    if (NT == 2) stb = mfma32(kf[g][e], qb[g][e], stb);
+                }
+            float psa = exp_sum(sta);
+            float psb = (NT == 2) ? exp_sum(stb) : 0.f;
+            const bool stale = !(psa < SM_BIG) || !(psb < SM_BIG);
+            if (__builtin_amdgcn_ballot_w64(stale) != 0) {   // wave-uniform, rare
+                psa = rereference(kf, qa, sta, oa, ta);
+                if (NT == 2) psb = rereference(kf, qb, stb, ob, tb);
+            }
+            ta.l_lane += psa;
+            tb.l_lane += psb;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) oa = mfma32(vf[g][e], sta[4 * g + e], oa);      // PV_A
+            // prefetch the next head's Q fragments (a whole block old by the next counted wait, so
+            // the `vmcnt(2)` below never really waits on them)
+            if (jb == NKB - 4 && bh + stride < BH) {
+                const f32x4* qg = qall + (size_t)(bh + stride) * NKB * 256;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    qna[g] = qg[(t0 * 4 + g) * 64 + lane];
+                    if (NT == 2) qnb[g] = qg[((t0 + 1) * 4 + g) * 64 + lane];
+                }
+            }
+            // ---- make block gb+1 visible, keep the DMA three blocks ahead, fetch its K fragments
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            issue_block(bh, jb + 4, gb + 4);     // slot (gb+4)&3 == gb&3: all its reads are done
+            {
+                const f32x4* nslot = ring + ((gb + 1) & (ATT_SLOTS - 1)) * ATT_SLOT_F4 + lane;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) kf[g] = nslot[g * 64];
+            }
+            if (NT == 2) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ob = mfma32(vf[g][e], stb[4 * g + e], ob);  // PV_B
+            }
+        }
+        // ---- normalise and store O of this head; swap in the prefetched Q ----
+        const int seq = bh / NH, head = bh % NH;
+        {
+            const float inv = 1.0f / pair_sum(ta.l_lane);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 w = {oa[4 * g] * inv, oa[4 * g + 1] * inv, oa[4 * g + 2] * inv, oa[4 * g + 3] * inv};
+                og[(((size_t)seq * NKB + t0) * 16 + head * 4 + g) * 64 + lane] = w;
+            }
+        }
+        if (NT == 2) {
+            const float inv = 1.0f / pair_sum(tb.l_lane);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 w = {ob[4 * g] * inv, ob[4 * g + 1] * inv, ob[4 * g + 2] * inv, ob[4 * g + 3] * inv};
+                og[(((size_t)seq * NKB + t0 + 1) * 16 + head * 4 + g) * 64 + lane] = w;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            qa[g] = qna[g] * QSCALE;
+            if (NT == 2) qb[g] = qnb[g] * QSCALE;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the trailing (unused) DMAs
+}
+
+__global__ __launch_bounds__(PERSIST_THREADS, 2) void attn_fwd_persistent_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ vT,
+    float* __restrict__ o, int BH) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 ring[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const f32x4* qg = reinterpret_cast<const f32x4*>(q);
+    const f32x4* kg = reinterpret_cast<const f32x4*>(k);
+    const f32x4* vg = reinterpret_cast<const f32x4*>(vT);
+    f32x4* og = reinterpret_cast<f32x4*>(o);
+#if defined(T2S_EXP) && (T2S_EXP & 32)
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (wave < 7)
+        attn_persistent_body<2>(ring, qg, kg, vg, og, BH, lane, wave);
+    else
+        attn_persistent_body<1>(ring, qg, kg, vg, og, BH, lane, wave);   // tiles 14 only (15 is void)
+#if defined(T2S_EXP) && (T2S_EXP & 32)
+    if (lane == 0 && blockIdx.x < 512 && wave < 4) {
+        unsigned long long* d = t2s_dbg + (size_t)(blockIdx.x * 4 + wave) * 8;
+        d[0] = __builtin_amdgcn_s_memtime() - c0;
+        d[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+#endif
+}
+
 int launch_attn_packed(const float* q, const float* k, const float* vT, float* o, int BH, hipStream_t st) {
-    attn_fwd_packed_kernel<<<BH * 2, 256, ATT_LDS_BYTES, st>>>(q, k, vT, o);
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n_cu = prop.multiProcessorCount;
+        else
+            n_cu = 256;
+    }
+    if (BH >= 2 * n_cu) {
+        // persistent: one 8-wave workgroup per CU walks the heads
+        attn_fwd_persistent_kernel<<<n_cu, PERSIST_THREADS, ATT_LDS_BYTES, st>>>(q, k, vT, o, BH);
+    } else {
+        attn_fwd_packed_kernel<<<((BH + 7) / 8) * 16, 256, ATT_LDS_BYTES, st>>>(q, k, vT, o, BH);
+    }
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }
@@ -214,7 +551,7 @@ __global__ __launch_bounds__(512) void attn_fwd_plain_kernel(const float* __rest
                 ot = mfma32(vrow[klo * DH], st[r], ot);
             }
         }
-        const float inv = 1.0f / (s.l_lane + xhalf(s.l_lane));
+        const float inv = 1.0f / pair_sum(s.l_lane);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 w = {ot[4 * g] * inv, ot[4 * g + 1] * inv, ot[4 * g + 2] * inv, ot[4 * g + 3] * inv};
@@ -244,6 +581,12 @@ extern "C" int t2s_attn_fwd(const float* q, const float* k, const float* v, floa
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }
+
+#if defined(T2S_EXP) && (T2S_EXP & 32)
+extern "C" int t2s_debug_read(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(t2s::t2s_dbg), (size_t)n * 8);
+}
+#endif
 
 extern "C" int t2s_attn_fwd_packed(const float* q, const float* k, const float* vT, float* o, int n_seq,
                                    void* stream) {

@@ -38,7 +38,7 @@ struct GemmArgs {
 __device__ __forceinline__ float gelu_tanh(float x) {
     // 0.5 x (1 + tanh(u)) == x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3)
     const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    return x / (1.0f + __expf(-2.0f * u));
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
 }
 
 template <int K, int NT, int PRO, int EPI>

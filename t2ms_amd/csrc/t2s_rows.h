@@ -30,7 +30,14 @@
 namespace t2s {
 
 constexpr int ROWS_CHUNK_F4 = 1024;                       // float4 per chunk (16 KiB)
-constexpr int ROWS_LDS_BYTES = 2 * ROWS_CHUNK_F4 * 16;    // 32 KiB ring
+// LDS: [2 x 16 KiB weight ring][biases: bp 128 | b1 256 | b2 128 | bq 384][per wave: 6 adaLN vectors
+// of the MLP block (768) | shift, scale of the qkv block (256)].  Every per-feature constant the
+// chunk loops need is read from LDS (lgkmcnt); a global load inside those loops gets sunk next to
+// its use by the compiler and waits with vmcnt(0) -- a full memory round trip, draining the
+// weight DMA and all stores, once per 64 MFMAs (seen in the ISA; cost ~15 %).
+constexpr int ROWS_CB_FLOATS = 896;
+constexpr int ROWS_CM_FLOATS = 1024;                      // per wave
+constexpr int ROWS_LDS_BYTES = 2 * ROWS_CHUNK_F4 * 16 + (ROWS_CB_FLOATS + 4 * ROWS_CM_FLOATS) * 4;
 
 struct RowArgs {
     float* x;          // (M,128) residual stream, fragment-major, in place
@@ -44,9 +51,16 @@ struct RowArgs {
     float *q, *k, *v;  // per head (S*4, 480, 32): q, k fragment-major; v TRANSPOSED fragment-major (V^T)
 };
 
+// GELU(tanh): 0.5 x (1 + tanh(u)) == x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3).
+// On gfx950 the f32 MFMA shares the VALU lanes, so every VALU instruction here is paid in matrix
+// time: 7 instructions (x*x, fma, mul, v_exp, add, v_rcp, mul) instead of an IEEE division.
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    return x / (1.0f + __expf(-2.0f * u));
+    constexpr float C0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;   // -2 sqrt(2/pi) log2(e)
+    constexpr float C1 = C0 * 0.044715f;
+    const float t = x * x;
+    const float a = x * __builtin_fmaf(t, C1, C0);          // -2u * log2(e)
+    const float e = __builtin_amdgcn_exp2f(a);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 // per-register constants: feature n = 32*nt + 8*g + 4*half + e  <->  register 4g+e of tile nt
@@ -122,6 +136,27 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
 
     fill(0);
 
+    // ---- stage the per-feature constants in LDS (visible after the first barrier) ----
+    float* cb = reinterpret_cast<float*>(wring + 2 * ROWS_CHUNK_F4);
+    float* cm = cb + ROWS_CB_FLOATS + wave * ROWS_CM_FLOATS;
+    if constexpr (DO_MLP) {
+        for (int i = threadIdx.x; i < 512; i += 256)
+            cb[i] = i < 128 ? a.bp[i] : (i < 384 ? a.b1[i - 128] : a.b2[i - 384]);
+        const float* src = modrow + a.blk * MODW;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            *reinterpret_cast<f32x4*>(cm + (i * 64 + lane) * 4) = *reinterpret_cast<const f32x4*>(src + (i * 64 + lane) * 4);
+    }
+    if constexpr (DO_QKV) {
+        for (int i = threadIdx.x; i < 384; i += 256) cb[512 + i] = a.bq[i];
+        const float* src = modrow + a.qkv_blk * MODW;   // shift_msa | scale_msa
+        *reinterpret_cast<f32x4*>(cm + 768 + lane * 4) = *reinterpret_cast<const f32x4*>(src + lane * 4);
+    }
+    const float* c_bp = cb;
+    const float* c_b1 = cb + 128;
+    const float* c_b2 = cb + 384;
+    const float* c_bq = cb + 512;
+
     // residual stream of this lane's token, accumulator layout: x[nt][4g+e] = X[row][32nt+8g+4half+e]
     f32x16 x[4];
     {
@@ -136,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
     int ci = 0;
 
     if constexpr (DO_MLP) {
-        const float* __restrict__ mb = modrow + a.blk * MODW;
+        const float* mb = cm;   // [shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp] of a.blk
         // ---------------- x += gate_msa * (proj(ao) + b) ----------------
         {
             f32x16 bop[4];  // B operand: ao[row][8G+4half+e] at bop[G>>2][4(G&3)+e]
@@ -163,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x4 bias = ldc4(a.bp, nt, g, half);
+                    const f32x4 bias = ldc4(c_bp, nt, g, half);
                     const f32x4 gate = ldc4(mb + 2 * D, nt, g, half);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[nt][4 * g + e] += gate[e] * (acc[4 * g + e] + bias[e]);
@@ -209,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
                     }
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.b1 + 32 * c + 8 * g + 4 * half);
+                        const f32x4 bias = *reinterpret_cast<const f32x4*>(c_b1 + 32 * c + 8 * g + 4 * half);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) hT[4 * g + e] = gelu_tanh_f(hT[4 * g + e] + bias[e]);
                     }
@@ -236,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x4 bias = ldc4(a.b2, nt, g, half);
+                    const f32x4 bias = ldc4(c_b2, nt, g, half);
                     const f32x4 gate = ldc4(mb + 5 * D, nt, g, half);
                     const f32x4 xo = xw[(nt * 4 + g) * 64];   // the parked residual
                     f32x4 t;
@@ -253,13 +288,14 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
     }
 
     if constexpr (DO_QKV) {
-        const float* __restrict__ mb = modrow + a.qkv_blk * MODW;
         f32x16 xm[4];
-        ln_modulate(x, xm, mb + 0 * D, mb + 1 * D, half, 1e-6f);
+        ln_modulate(x, xm, cm + 768, cm + 768 + D, half, 1e-6f);
         const int tile_in_seq = tile - seq * (NTOK / 32);
 #pragma unroll 1
         for (int t = 0; t < 12; ++t) {  // output tile t = which*4 + head
+#if !defined(T2S_EXP) || !(T2S_EXP & 2)
             if (ci + 1 < N_CHUNKS) fill(ci + 1);
+#endif
             const f32x4* wb = wring + (ci & 1) * ROWS_CHUNK_F4 + lane;
             const int which = t >> 2, head = t & 3;
             float* base = which == 0 ? a.q : (which == 1 ? a.k : a.v);
@@ -273,14 +309,18 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
                 f32x4 bias[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    bias[g] = *reinterpret_cast<const f32x4*>(a.bq + 32 * t + 8 * g + 4 * half);
+                    bias[g] = *reinterpret_cast<const f32x4*>(c_bq + 32 * t + 8 * g + 4 * half);
 #pragma unroll
                 for (int G = 0; G < 16; ++G) {
                     const f32x4 w = wb[G * 64];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc = mfma32(w[e], xm[G >> 2][4 * (G & 3) + e], acc);
                 }
+#if defined(T2S_EXP) && (T2S_EXP & 1)
+                if (active && acc[0] == 1234.5f) {
+#else
                 if (active) {
+#endif
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         f32x4 o;
@@ -292,14 +332,18 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
             } else {
                 // v tile with the MFMA operands swapped: lane = feature d, registers = tokens
                 // {8g+4half+e}: exactly the V^T fragment the attention kernel consumes
-                const float bias = a.bq[32 * t + (lane & 31)];
+                const float bias = c_bq[32 * t + (lane & 31)];
 #pragma unroll
                 for (int G = 0; G < 16; ++G) {
                     const f32x4 w = wb[G * 64];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc = mfma32(xm[G >> 2][4 * (G & 3) + e], w[e], acc);
                 }
+#if defined(T2S_EXP) && (T2S_EXP & 1)
+                if (active && acc[0] == 1234.5f) {
+#else
                 if (active) {
+#endif
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         f32x4 o;
@@ -309,7 +353,16 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
                     }
                 }
             }
-            __syncthreads();
+#if !defined(T2S_EXP) || !(T2S_EXP & 2)
+            // Counted wait + raw barrier: only the chunk's 4 DMA pieces must have landed; the 4
+            // q/k/v stores issued after them (the youngest VM ops) stay in flight across the
+            // barrier.  (__syncthreads() would drain them: vmcnt(0).)  Tail waves store nothing.
+            if (active)
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#endif
             ++ci;
         }
     }

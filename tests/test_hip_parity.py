@@ -110,6 +110,12 @@ def test_attention_packed_kernel_vs_oracle(dev):
     k[:, 333] = q[:, 100] * 5.0
     k[:, 5] = q[:, 479] * 4.0
     k[:, 479] = q[:, 0] * 4.0
+    # the sticky softmax reference is only renewed when it is stale by > 2^60: force that branch at
+    # a late key block (log2-domain jump of ~100 for query 200 at key 410), and make one query's
+    # first block hugely negative so its first reference sits far below the later scores
+    k[:, 410] = q[:, 200] * 12.0
+    k[:, 0:32] = -q[:, 7:8] * 3.0 + 0.01 * k[:, 0:32]
+    k[:, 448] = q[:, 7] * 10.0
     ref = (torch.softmax((q.double() * 32 ** -0.5) @ k.double().transpose(-1, -2), dim=-1) @ v.double()).float()
     qd, kd, vd = _pack_frag(q).to(dev), _pack_frag(k).to(dev), _pack_vT(v).to(dev)
     od = torch.empty(n_seq * 480 * 128, device=dev)
@@ -118,6 +124,26 @@ def test_attention_packed_kernel_vs_oracle(dev):
     # o: [tile = seq*15 + t][G = head*4 + g][h][i][e] = O[seq][head][32 t + i][8g + 4h + e]
     o = od.cpu().reshape(n_seq, 15, 4, 4, 2, 32, 4).permute(0, 2, 1, 5, 3, 4, 6).reshape(BH, 480, 32)
     assert _maxdiff(o, ref) < 2e-5
+
+
+def test_attention_persistent_kernel_multi_item(dev):
+    """n_seq = 160 -> 1280 (head, part) items on a 512-workgroup persistent grid: 2-3 items per
+    workgroup, so the cross-item DMA ring, the Q prefetch and the per-item state reset are all
+    exercised (plus re-reference spikes in every head)."""
+    rs = np.random.RandomState(22)
+    n_seq = 160
+    BH = n_seq * 4
+    q, k, v = (torch.from_numpy(rs.randn(BH, 480, 32).astype(np.float32)) for _ in range(3))
+    k[:, 410] = q[:, 200] * 12.0
+    k[:, 31] = q[:, 470] * 6.0
+    ref = (torch.softmax((q * 32 ** -0.5) @ k.transpose(-1, -2), dim=-1) @ v)
+    qd, kd, vd = _pack_frag(q).to(dev), _pack_frag(k).to(dev), _pack_vT(v).to(dev)
+    od = torch.full((n_seq * 480 * 128,), float("nan"), device=dev)
+    L.check(L.lib().t2s_attn_fwd_packed(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), n_seq,
+                                        L.stream_ptr(dev)))
+    o = od.cpu().reshape(n_seq, 15, 4, 4, 2, 32, 4).permute(0, 2, 1, 5, 3, 4, 6).reshape(BH, 480, 32)
+    assert bool(torch.isfinite(o).all())
+    assert _maxdiff(o, ref) < 3e-5
 
 
 def test_attention_online_softmax_rescale_branch(dev):
