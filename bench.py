@@ -45,26 +45,33 @@ def build_models(dev, seed=2025):
     return m.to(dev).eval(), v.to(dev).eval()
 
 
-def time_attention_kernel(dev, n_seq, iters=20):
-    """Average duration of the dominant kernel (fused attention) at the workload's shape, with HIP
-    events on the stream it is launched on."""
+def time_kernels_in_situ(model, dev, x, text, n_steps=8):
+    """Average launch duration of the dominant kernel (fused attention) measured IN SITU: HIP
+    events recorded by the library on the launching stream around every kernel of real CFG
+    forwards (same shapes, same data path as the timed region, eager launches)."""
+    import ctypes as C
     from t2ms_amd import _lib as L
-    BH = n_seq * 4
-    g = torch.Generator(device=dev).manual_seed(1)
-    # random N(0,1) operands in the library's fragment-major layout (a permutation of the plain one)
-    q, k, v = (torch.randn(BH, 480, 32, device=dev, generator=g) for _ in range(3))
-    o = torch.empty_like(q)
-    st = torch.cuda.current_stream(dev)
+    B = x.shape[0]
     lib = L.lib()
-    for _ in range(3):
-        L.check(lib.t2s_attn_fwd_packed(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), n_seq, st.cuda_stream))
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(st)
-    for _ in range(iters):
-        L.check(lib.t2s_attn_fwd_packed(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), n_seq, st.cuda_stream))
-    e1.record(st)
-    e1.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / iters
+    with torch.cuda.device(dev):
+        h = model.t2s_handle(dev, 2 * B)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        temb = model.time_emb(torch.full((1,), 500, device=dev))
+        ou, oc = torch.empty_like(x), torch.empty_like(x)
+        for _ in range(2):
+            L.check(lib.t2s_dit_forward_cfg(h, x.data_ptr(), temb.data_ptr(), text.data_ptr(), ou.data_ptr(),
+                                            oc.data_ptr(), B, st))
+        torch.cuda.synchronize(dev)
+        L.check(lib.t2s_dit_timing_begin(h))
+        for _ in range(n_steps):
+            L.check(lib.t2s_dit_forward_cfg(h, x.data_ptr(), temb.data_ptr(), text.data_ptr(), ou.data_ptr(),
+                                            oc.data_ptr(), B, st))
+        out = (C.c_double * 6)()
+        L.check(lib.t2s_dit_timing_end(h, out))
+    return {"attn_us": out[0] / out[1] * 1e3, "attn_calls": int(out[1]),
+            "rows_us": out[2] / out[3] * 1e3, "rows_calls": int(out[3]),
+            "other_us": out[4] / out[5] * 1e3, "other_calls": int(out[5]),
+            "forward_us": (out[0] + out[2] + out[4]) / n_steps * 1e3}
 
 
 def usable_cores() -> int:
@@ -204,7 +211,8 @@ def main():
     }
     if rank == 0:
         # roofline of the dominant kernel (fused attention; 48 % of all FLOPs), same shapes as the workload
-        t_attn = time_attention_kernel(dev, 2 * B)
+        kt = time_kernels_in_situ(model, dev, lat.clone(), text)
+        t_attn = kt["attn_us"] * 1e-6
         flop_attn = FLOP_ATTN_PER_SEQ_BLOCK * 2 * B
         achieved = flop_attn / t_attn / 1e12
         traffic = None
@@ -214,10 +222,14 @@ def main():
                 traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
             except (OSError, ValueError):
                 traffic = None
-        out["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_packed_kernel", "achieved": achieved,
+        out["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_persistent_kernel", "achieved": achieved,
                            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                            "traffic": traffic, "avg_launch_us": t_attn * 1e6,
-                           "flop_per_launch": flop_attn}
+                           "flop_per_launch": flop_attn, "launches_timed": kt["attn_calls"],
+                           "timing": "HIP events on the launch stream around every attention launch of "
+                                     "8 eager 512-sequence CFG forwards (in situ)"}
+        out["kernel_breakdown_us"] = {"attention_x4": kt["attn_us"], "row_chain_x5": kt["rows_us"],
+                                      "other_x4": kt["other_us"], "forward_total": kt["forward_us"]}
         # whole-step figure for context: all DiT FLOPs / wall time
         step_flops = FLOP_FORWARD_PER_SEQ * 2 * B * args.diffusion_steps * args.steps
         out["whole_path_tflops"] = step_flops / elapsed / 1e12

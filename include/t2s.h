@@ -112,6 +112,13 @@ int t2s_dit_forward(t2s_dit* h, const float* x, const float* temb, int temb_rows
 int t2s_dit_forward_cfg(t2s_dit* h, const float* x, const float* temb, const float* text,
                         float* out_uncond, float* out_cond, int B, void* stream);
 
+/* In-situ kernel timing with HIP events recorded on the launching stream around every launch of
+ * the forward (not usable while the stream is being captured).  _begin arms it; after running
+ * forwards, _end synchronises and returns {attention ms, attention launches, row-chain ms,
+ * row-chain launches, other ms, other launches} in out6 and disarms it. */
+int t2s_dit_timing_begin(t2s_dit* h);
+int t2s_dit_timing_end(t2s_dit* h, double* out6);
+
 /* Test tap: copy out the residual stream (S,480,128) the last forward left in the
  * workspace (post block 3, before the final LayerNorm).  Used by tests to bisect. */
 int t2s_dit_read_stream(const t2s_dit* h, float* out, int S, void* stream);

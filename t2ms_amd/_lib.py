@@ -67,6 +67,8 @@ SYMBOLS = {
     "t2s_dit_forward": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP]),
     "t2s_dit_forward_cfg": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_dit_read_stream": (_I, [_VP, _VP, _I, _VP]),
+    "t2s_dit_timing_begin": (_I, [_VP]),
+    "t2s_dit_timing_end": (_I, [_VP, C.POINTER(C.c_double)]),
     "t2s_attn_fwd": (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_attn_fwd_packed": (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_ddpm_step": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _F, _U64, _U32, _U32, _I, _VP]),

@@ -195,6 +195,10 @@ struct t2s_dit {
     // workspace (device), activations fragment-major
     float *h = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *ao = nullptr;
     float *mod = nullptr, *c = nullptr;
+    // optional in-situ kernel timing (HIP events on the launching stream; never under capture)
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<int> ev_class;   // class of interval i = [ev_pool[2i], ev_pool[2i+1]]
 };
 
 namespace {
@@ -258,21 +262,39 @@ int upload_weights(t2s_dit* h, const t2s_dit_weights* w, hipStream_t st) {
     return T2S_OK;
 }
 
+enum { TC_ATTN = 0, TC_ROWS = 1, TC_OTHER = 2 };
+struct TimeScope {   // records an event pair around one launch when timing is on
+    t2s_dit* h; hipStream_t st; bool on;
+    TimeScope(t2s_dit* h_, int cls, hipStream_t st_) : h(h_), st(st_), on(h_->timing) {
+        if (!on) return;
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+        h->ev_pool.push_back(a); h->ev_pool.push_back(b); h->ev_class.push_back(cls);
+        (void)hipEventRecord(a, st);
+    }
+    ~TimeScope() { if (on) (void)hipEventRecord(h->ev_pool.back(), st); }
+};
+
 // One DiT forward over S sequences (sequence s reads latent row s % B).
 int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const float* temb,
                 int temb_rows, const int* step_ptr, const float* text, float* out0, float* out1,
                 int split, hipStream_t st) {
     int rc;
-    cond_kernel<<<(S * D + 255) / 256, 256, 0, st>>>(h->c, temb, temb_rows, step_ptr, text,
-                                                     uncond_rows, S);
+    {
+        TimeScope ts(h, TC_OTHER, st);
+        cond_kernel<<<(S * D + 255) / 256, 256, 0, st>>>(h->c, temb, temb_rows, step_ptr, text,
+                                                         uncond_rows, S);
+    }
     T2S_LAUNCH_CHECK();
     {   // adaLN for all 4 blocks at once: mod = silu(c) @ W_ada^T + b   (transformer.py:106-109,115)
         GemmArgs a{};
         a.A = h->c; a.Wp = h->ada_p; a.bias = h->ada_b; a.out = h->mod; a.M = S; a.N = MODROW;
+        TimeScope ts(h, TC_OTHER, st);
         if ((rc = launch_gemm_rows<128, 3, PRO_SILU, EPI_BIAS>(a, st)) != T2S_OK) return rc;
     }
     {
         const int threads = S * NTOK * 32;
+        TimeScope ts(h, TC_OTHER, st);
         patchify_kernel<<<(threads + 255) / 256, 256, 0, st>>>(x, B, h->h, S, h->conv_w, h->conv_b,
                                                                h->patch_w, h->patch_b, h->pos);
         T2S_LAUNCH_CHECK();
@@ -291,9 +313,16 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
         a.q = h->q; a.k = h->k; a.v = h->v;
         return a;
     };
-    if ((rc = launch_dit_rows<false, true>(rows_args(-1, 0), st)) != T2S_OK) return rc;
+    {
+        TimeScope ts(h, TC_ROWS, st);
+        if ((rc = launch_dit_rows<false, true>(rows_args(-1, 0), st)) != T2S_OK) return rc;
+    }
     for (int i = 0; i < NBLK; ++i) {
-        if ((rc = launch_attn_packed(h->q, h->k, h->v, h->ao, S * NH, st)) != T2S_OK) return rc;
+        {
+            TimeScope ts(h, TC_ATTN, st);
+            if ((rc = launch_attn_packed(h->q, h->k, h->v, h->ao, S * NH, st)) != T2S_OK) return rc;
+        }
+        TimeScope ts(h, TC_ROWS, st);
         if (i + 1 < NBLK)
             rc = launch_dit_rows<true, true>(rows_args(i, i + 1), st);
         else
@@ -302,6 +331,7 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
     }
     {
         const int tiles = M / 32;
+        TimeScope ts(h, TC_OTHER, st);
         final_kernel<<<(tiles + 3) / 4, 256, 0, st>>>(h->h, S, h->ln_w, h->ln_b, h->out_w, h->out_b,
                                                       out0, out1, split);
         T2S_LAUNCH_CHECK();
@@ -427,6 +457,32 @@ int t2s_dit_forward_cfg(t2s_dit* h, const float* x, const float* temb, const flo
                 h->max_seqs);
     return t2s::dit_forward_cfg_step(h, x, temb, nullptr, text, out_uncond, out_cond, B,
                                      (hipStream_t)stream);
+}
+
+int t2s_dit_timing_begin(t2s_dit* h) {
+    T2S_REQUIRE(h, "t2s_dit_timing_begin: NULL handle");
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    h->ev_pool.clear();
+    h->ev_class.clear();
+    h->timing = true;
+    return T2S_OK;
+}
+
+int t2s_dit_timing_end(t2s_dit* h, double* out6) {
+    T2S_REQUIRE(h && out6, "t2s_dit_timing_end: NULL argument");
+    h->timing = false;
+    for (int i = 0; i < 6; ++i) out6[i] = 0.0;
+    for (size_t i = 0; i < h->ev_class.size(); ++i) {
+        T2S_HIP_CHECK(hipEventSynchronize(h->ev_pool[2 * i + 1]));
+        float ms = 0.f;
+        T2S_HIP_CHECK(hipEventElapsedTime(&ms, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]));
+        out6[2 * h->ev_class[i]] += ms;
+        out6[2 * h->ev_class[i] + 1] += 1.0;
+    }
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    h->ev_pool.clear();
+    h->ev_class.clear();
+    return T2S_OK;
 }
 
 int t2s_dit_read_stream(const t2s_dit* h, float* out, int S, void* stream) {
