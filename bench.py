@@ -161,14 +161,10 @@ def main():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-
+    from t2ms_amd import dist as tdist
     from t2ms_amd import synth
     from t2ms_amd.sampler import Sampler
+    dist = tdist.init("nccl", dev)      # RCCL; None when single-process
 
     B = args.batch
     model, vae = build_models(dev)
@@ -179,22 +175,12 @@ def main():
     for _ in range(max(0, args.warmup - 1)):
         sampler.run_inplace(decode=True)
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    barrier()
+    tdist.barrier(dist, dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         lat, series = sampler.run_inplace(decode=True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    tdist.barrier(dist, dev)
+    elapsed = tdist.max_over_ranks(dist, time.perf_counter() - t0, dev)
     assert bool(torch.isfinite(series).all()) and bool(torch.isfinite(lat).all())
 
     total_series = args.steps * B * world

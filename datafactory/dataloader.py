@@ -1,0 +1,92 @@
+"""loader_provider(args, period) -> (dataset, DataLoader)   (reference datafactory/dataloader.py:79-133).
+
+Kept: dataset-name -> CSV-name mapping, the three data roots, mix-train = three lengths
+(24/48/96) concatenated behind one loader whose collate groups a batch by length, and
+`shuffle=True, drop_last=True` for BOTH periods (evaluation.py relies on N = floor(test/B)*B).
+New: `args.synthetic` (int rows) serves synthetic data when the CSVs are not on disk.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch.utils.data import ConcatDataset, DataLoader, Dataset
+
+from .dataset import SyntheticT2SDataset, T2SDataset
+
+_FRAGMENT = ("ETTh1", "ETTm1", "traffic", "airquality", "exchangerate", "weather", "electricity", "nationalillness")
+_MMD = ("Agriculture", "Climate", "Health_US", "Traffic", "Economy", "SocialGood")
+
+
+def csv_name(dataset_name: str) -> str:
+    """'ETTh1_24' -> 'embedding_cleaned_ETTh1_24', 'MMD-Climate_48' -> 'embedding_cleaned_Climate_48', ..."""
+    base = dataset_name.split("-", 1)[1] if dataset_name.startswith("MMD-") else dataset_name
+    return "embedding_cleaned_" + base
+
+
+data_dict = {n: csv_name(n) for n in
+             [f"{b}{s}" for b in _FRAGMENT[:6] + ("electricity",) for s in ("", "_24", "_48", "_96")] +
+             [f"MMD-{b}{s}" for b in _MMD for s in ("", "_24", "_48", "_96")] + ["SUSHI"]}
+
+
+class AlternatingDataset(Dataset):
+    """Three datasets back to back; item = (sample, which_dataset) (dataloader.py:6-22)."""
+
+    def __init__(self, d1, d2, d3):
+        self.datasets = [d1, d2, d3]
+        self._cat = ConcatDataset(self.datasets)
+        self._starts = np.cumsum([0] + [len(d) for d in self.datasets])
+
+    def __len__(self):
+        return len(self._cat)
+
+    def __getitem__(self, i):
+        which = int(np.searchsorted(self._starts, i, side="right") - 1)
+        return self._cat[i], which
+
+
+def custom_collate_fn(batch):
+    """Group a mixed batch by source dataset -> list of (texts, xs, embeddings) (dataloader.py:115-133)."""
+    out = []
+    for which in (0, 1, 2):
+        rows = [item for item, w in batch if w == which]
+        if not rows:
+            continue
+        texts, xs, embs = zip(*rows)
+        out.append((list(texts), torch.stack([torch.as_tensor(x) for x in xs]),
+                    torch.stack([torch.as_tensor(e) for e in embs])))
+    return out
+
+
+def _root_for(dataset_name: str, mix: bool) -> str:
+    family = dataset_name.split("_")[0]
+    if family in _FRAGMENT:
+        return "./Data/TSFragment-600K/" if mix else "./Data/our/"
+    if dataset_name == "SUSHI":
+        return "./Data/SUSHI/"
+    if dataset_name.startswith("MMD-"):
+        return "./Data/MMD/"
+    raise ValueError(f"unknown dataset {dataset_name!r}")
+
+
+def loader_provider(args, period):
+    synthetic = int(getattr(args, "synthetic", 0) or 0)
+    name = args.dataset_name
+    if getattr(args, "mix_train", False):
+        if synthetic:
+            parts = [SyntheticT2SDataset(synthetic, L, seed=2025 + L) for L in (24, 48, 96)]
+        elif name == "SUSHI":
+            ds = T2SDataset(name=csv_name(name), data_root=_root_for(name, True), period=period)
+            return ds, DataLoader(ds, batch_size=args.batch_size, shuffle=True, drop_last=True,
+                                  collate_fn=custom_collate_fn)
+        else:
+            root = _root_for(name, True)
+            parts = [T2SDataset(name=f"{csv_name(name)}_{L}", data_root=root, period=period) for L in (24, 48, 96)]
+        ds = AlternatingDataset(*parts)
+        return ds, DataLoader(ds, batch_size=args.batch_size, shuffle=True, drop_last=True,
+                              collate_fn=custom_collate_fn)
+    if synthetic:
+        length = int(name.rsplit("_", 1)[1]) if "_" in name and name.rsplit("_", 1)[1].isdigit() else 96
+        ds = SyntheticT2SDataset(synthetic, length)
+    else:
+        ds = T2SDataset(name=csv_name(name), data_root=_root_for(name, False), period=period)
+    return ds, DataLoader(ds, batch_size=args.batch_size, shuffle=True, drop_last=True)

@@ -412,3 +412,23 @@ def test_trace_and_perf_mode_sharding(dev, vae):
     assert torch.equal(lat[:3], la) and torch.equal(lat[3:], lb)
     assert torch.equal(ser[:3], sa) and torch.equal(ser[3:], sb)
     assert tr.shape == (8, 48) and torch.equal(tr[-1], sb[0])
+
+
+def test_infer_driver_end_to_end(dev, tmp_path, monkeypatch):
+    """The drop-in driver: reference flags and path derivations, the four .npy files evaluation.py reads
+    (infer.py:118-123,146), via synthetic data + seeded weights."""
+    import infer as drv
+    monkeypatch.chdir(tmp_path)
+    save = str(tmp_path / "results")
+    argv = ["--dataset_name", "ETTh1_24", "--backbone", "ddpm", "--denoiser", "DiT", "--total_step", "3",
+            "--cfg_scale", "9", "--batch_size", "4", "--save_path", save, "--synthetic", "10",
+            "--random_init", "--seed", "11", "--trace"]
+    drv.main(argv)
+    out = os.path.join(save, "generation", "ddpm_DiT_ETTh1_24_9.0_3")
+    n = (10 // 4) * 4     # drop_last: floor(rows / B) * B
+    shapes = {"x_1.npy": (n, 24, 1), "x_t.npy": (n, 24, 1), "x_t_latent_dec_array.npy": (n, 64, 30),
+              "x_t_latent_enc_array.npy": (n, 64, 30)}
+    for f, shp in shapes.items():
+        a = np.load(os.path.join(out, f))
+        assert a.shape == shp and a.dtype == np.float32 and np.isfinite(a).all(), (f, a.shape, a.dtype)
+    assert np.load(os.path.join(out, "x_infer_trace.npy")).shape == (3, 24)
