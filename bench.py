@@ -190,7 +190,7 @@ def main():
         "value": value, "unit": "series/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs[1]: DiT denoiser, {args.diffusion_steps}-step {args.backbone} with CFG "
+        "config": {"workload": f"{'configs[1]' if (args.backbone, args.diffusion_steps, B) == ('ddpm', 1000, 256) else 'custom'}: DiT denoiser, {args.diffusion_steps}-step {args.backbone} with CFG "
                                f"(2 forwards/step), B={B}/GPU, L={args.length}, cfg_scale={args.cfg_scale}, "
                                f"LA-VAE decode; Philox noise on device; hipGraph={'off' if args.no_graph else 'on'}",
                    "global_batch": B * world, "diffusion_steps": args.diffusion_steps, "parallelism": f"batch-shard x{world}"},
@@ -203,7 +203,7 @@ def main():
         achieved = flop_attn / t_attn / 1e12
         traffic = None
         tfile = os.path.join(REPO, "profiles", "attn_traffic.json")
-        if os.path.exists(tfile):
+        if os.path.exists(tfile) and B == 256:     # the PMC passes were taken at the headline shape
             try:
                 traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
             except (OSError, ValueError):

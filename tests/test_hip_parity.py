@@ -432,3 +432,58 @@ def test_infer_driver_end_to_end(dev, tmp_path, monkeypatch):
         a = np.load(os.path.join(out, f))
         assert a.shape == shp and a.dtype == np.float32 and np.isfinite(a).all(), (f, a.shape, a.dtype)
     assert np.load(os.path.join(out, "x_infer_trace.npy")).shape == (3, 24)
+
+
+def test_config3_rectified_flow_full_batch(dev, vae):
+    """BASELINE config 3 shape: B=1024 (2048 sequences per CFG pass), rectified flow, cfg 5, whole
+    step in one hipGraph -- at 3 steps; rows must equal the same rows sampled in a 4-row batch
+    bitwise, and agree with the oracle."""
+    m, Sampler, _, _, _ = _chain_setup(dev, vae)
+    B, steps, cfg = 1024, 3, 5.0
+    xT = synth.make_latents(606, B)
+    text = synth.make_text_embeddings(606, B)
+    big = Sampler(m, vae.decoder, "flowmatching", steps, cfg, B, 96, dev, use_graph=True)
+    lat, ser, _ = big.run(text, x_T=xT)
+    rows = [0, 511, 512, 1023]
+    small = Sampler(m, vae.decoder, "flowmatching", steps, cfg, 4, 96, dev, use_graph=True)
+    lat4, ser4, _ = small.run(text[rows], x_T=xT[rows])
+    assert torch.equal(lat[rows], lat4) and torch.equal(ser[rows], ser4)
+    with torch.no_grad():
+        ref = O.sample_rf(synth.make_dit_state_dict(31337, gain=0.7), xT[rows], text[rows], steps, cfg)
+    assert _maxdiff(lat4, ref) < TOL * max(1.0, float(ref.abs().max()))
+    assert bool(torch.isfinite(ser).all())
+
+
+def test_config5_variable_length_encode_sample_decode(dev, vae):
+    """BASELINE config 5: mixed lengths L in {24,48,96}: LA-VAE encode + DiT sampling + decode per
+    length group, each group sharded over 2 'ranks' (row offsets) -- sharding must be invisible and
+    every stage agrees with the oracle."""
+    m, Sampler, _, _, _ = _chain_setup(dev, vae)
+    sd = synth.make_dit_state_dict(31337, gain=0.7)
+    vsd = synth.make_vae_state_dict(2025)
+    steps, cfg, row = 4, 7.0, 0
+    for L_ in (24, 48, 96):
+        B = 6
+        xs = synth.make_series(40 + L_, B, L_)
+        text = synth.make_text_embeddings(40 + L_, B)
+        with torch.no_grad():
+            z, before = vae.encoder(xs.to(dev))
+            z_ref, before_ref = O.vae_encode(vsd, xs)
+        assert _maxdiff(z, z_ref) < 1e-5 and _maxdiff(before, before_ref) < 1e-5
+        noises = torch.from_numpy(np.random.RandomState(L_).randn(steps, B, 64, 30).astype(np.float32))
+        xT = synth.make_latents(50 + L_, B)
+        full = Sampler(m, vae.decoder, "ddpm", steps, cfg, B, L_, dev, use_graph=True, row0=row)
+        lat, ser, _ = full.run(text, x_T=xT, noise=noises)
+        halves = []
+        for lo, hi in ((0, 3), (3, 6)):
+            s = Sampler(m, vae.decoder, "ddpm", steps, cfg, hi - lo, L_, dev, use_graph=True, row0=row + lo)
+            halves.append(s.run(text[lo:hi], x_T=xT[lo:hi], noise=noises[:, lo:hi].contiguous()))
+        assert torch.equal(torch.cat([h[0] for h in halves]), lat)
+        assert torch.equal(torch.cat([h[1] for h in halves]), ser)
+        with torch.no_grad():
+            ref = O.sample_ddpm(sd, xT, text, steps, cfg, noises)
+            ref_ser, _ = O.vae_decode(vsd, ref, L_)
+        scale = max(1.0, float(ref.abs().max()))
+        assert _maxdiff(lat, ref) < TOL * scale and _maxdiff(ser, ref_ser) < TOL * scale
+        assert ser.shape == (B, L_)
+        row += B
