@@ -138,6 +138,38 @@ int t2s_attn_fwd_packed(const float* q, const float* k, const float* vT, float* 
                         void* stream);
 
 /* ------------------------------------------------------------------------ *
+ * Training step of the DiT: train.py:101-127 (pred = model(x_t, t, emb); loss.backward();
+ * optimizer.step()).  The host mirror wraps these in a torch.autograd.Function.
+ * ------------------------------------------------------------------------ */
+typedef struct t2s_dit_block_grads { /* same shapes as t2s_dit_block_weights */
+    float *qkv_w, *qkv_b, *proj_w, *proj_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *ada_w, *ada_b;
+} t2s_dit_block_grads;
+typedef struct t2s_dit_grads { /* every tensor that receives a gradient (925,592 values) */
+    float *conv_w, *conv_b, *patch_w, *patch_b, *ln_w, *ln_b, *out_w, *out_b;
+    t2s_dit_block_grads blk[T2S_N_BLOCKS];
+} t2s_dit_grads;
+
+/* Transformer.forward that keeps the activations for a following backward (fp32, plain layouts).
+ * `w` are the caller's CURRENT weights (call t2s_dit_update_weights first if they changed since
+ * the handle was created/updated); arguments otherwise as t2s_dit_forward.  Allocates its
+ * workspace on first use (not capturable). */
+int t2s_dit_train_forward(t2s_dit* h, const t2s_dit_weights* w, const float* x, const float* temb,
+                          int temb_rows, const float* text, float* out, int B, void* stream);
+/* Backward of the last t2s_dit_train_forward: dout (B,64,30) = dLoss/dout; writes (overwrites)
+ * every gradient tensor of `g`.  Weight gradients are accumulated with fp32 atomics (order, hence
+ * the last bits, may vary from run to run). */
+int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g, int B, void* stream);
+/* One fused AdamW update (torch.optim.AdamW semantics; train.py:37 uses lr 1e-4, weight_decay 0):
+ * p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ * p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps).  step >= 1. */
+int t2s_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                   void* stream);
+/* Backward of t2s_mse: da = 2 (a-b) g / n, db = -da (either may be NULL); grad_out: device scalar. */
+int t2s_mse_backward(const float* a, const float* b, const float* grad_out, float* da, float* db,
+                     uint64_t n, void* stream);
+
+/* ------------------------------------------------------------------------ *
  * Diffusion backbones: model/backbone/DDPM.py, model/backbone/rectified_flow.py
  * ------------------------------------------------------------------------ */
 /* DDPM.p_sample (DDPM.py:28-36) fused with the CFG combine (infer.py:87):

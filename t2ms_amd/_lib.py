@@ -32,6 +32,16 @@ class DitWeights(C.Structure):
                  "time_freqs")] + [("blk", DitBlockWeights * N_BLOCKS)]
 
 
+class DitBlockGrads(C.Structure):
+    _fields_ = DitBlockWeights._fields_
+
+
+class DitGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("conv_w", "conv_b", "patch_w", "patch_b", "ln_w", "ln_b", "out_w", "out_b")] + \
+               [("blk", DitBlockGrads * N_BLOCKS)]
+
+
 class VaeStackWeights(C.Structure):
     _fields_ = [("conv3_w", C.c_void_p * 4), ("conv1_w", C.c_void_p * 4)]
 
@@ -69,6 +79,10 @@ SYMBOLS = {
     "t2s_dit_read_stream": (_I, [_VP, _VP, _I, _VP]),
     "t2s_dit_timing_begin": (_I, [_VP]),
     "t2s_dit_timing_end": (_I, [_VP, C.POINTER(C.c_double)]),
+    "t2s_dit_train_forward": (_I, [_VP, C.POINTER(DitWeights), _VP, _VP, _I, _VP, _VP, _I, _VP]),
+    "t2s_dit_train_backward": (_I, [_VP, _VP, C.POINTER(DitGrads), _I, _VP]),
+    "t2s_adamw_step": (_I, [_VP, _VP, _VP, _VP, _U64, _F, _F, _F, _F, _F, _I, _VP]),
+    "t2s_mse_backward": (_I, [_VP, _VP, _VP, _VP, _VP, _U64, _VP]),
     "t2s_attn_fwd": (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_attn_fwd_packed": (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_ddpm_step": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _F, _U64, _U32, _U32, _I, _VP]),

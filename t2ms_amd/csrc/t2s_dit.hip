@@ -24,6 +24,7 @@ void set_error(const char* fmt, ...) {
 
 int launch_attn_packed(const float* q, const float* k, const float* vT, float* o, int BH, hipStream_t st);
 int attn_init();
+void train_free(t2s_dit* h);
 
 // ------------------------------------------------------------------ small kernels
 // W (N,K) row-major -> MFMA-fragment order.  mode 0: packed_index (tile-major: [nt][G][lane][e]);
@@ -184,22 +185,7 @@ __global__ void unfrag128_kernel(const float* __restrict__ src, float* __restric
 
 using namespace t2s;
 
-// ------------------------------------------------------------------ handle
-struct t2s_dit {
-    int max_seqs = 0;
-    // parameters (device)
-    float* arena = nullptr;  // all parameters, offsets below
-    float *conv_w, *conv_b, *patch_w, *patch_b, *pos, *ln_w, *ln_b, *out_w, *out_b, *freqs;
-    float *qkv_b[NBLK], *proj_b[NBLK], *fc1_b[NBLK], *fc2_b[NBLK], *ada_b;
-    f32x4 *qkv_p[NBLK], *proj_p[NBLK], *fc1_p[NBLK], *fc2_c[NBLK], *ada_p;
-    // workspace (device), activations fragment-major
-    float *h = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *ao = nullptr;
-    float *mod = nullptr, *c = nullptr;
-    // optional in-situ kernel timing (HIP events on the launching stream; never under capture)
-    bool timing = false;
-    std::vector<hipEvent_t> ev_pool;
-    std::vector<int> ev_class;   // class of interval i = [ev_pool[2i], ev_pool[2i+1]]
-};
+#include "t2s_dit_internal.h"
 
 namespace {
 
@@ -425,6 +411,7 @@ int t2s_dit_update_weights(t2s_dit* h, const t2s_dit_weights* w, void* stream) {
 
 void t2s_dit_destroy(t2s_dit* h) {
     if (!h) return;
+    t2s::train_free(h);
     float* bufs[] = {h->arena, h->h, h->q, h->k, h->v, h->ao, h->mod, h->c};
     for (float* b : bufs)
         if (b) (void)hipFree(b);

@@ -1,0 +1,25 @@
+// Internal definition of the t2s_dit handle, shared by t2s_dit.hip (inference) and t2s_train.hip.
+#pragma once
+#include <vector>
+
+#include "t2s_common.h"
+
+struct t2s_train_ws;   // training workspace (t2s_train.hip), created on first use
+
+struct t2s_dit {
+    int max_seqs = 0;
+    // parameters (device)
+    float* arena = nullptr;  // all parameters, offsets below
+    float *conv_w, *conv_b, *patch_w, *patch_b, *pos, *ln_w, *ln_b, *out_w, *out_b, *freqs;
+    float *qkv_b[t2s::NBLK], *proj_b[t2s::NBLK], *fc1_b[t2s::NBLK], *fc2_b[t2s::NBLK], *ada_b;
+    t2s::f32x4 *qkv_p[t2s::NBLK], *proj_p[t2s::NBLK], *fc1_p[t2s::NBLK], *fc2_c[t2s::NBLK], *ada_p;
+    // workspace (device), activations fragment-major
+    float *h = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *ao = nullptr;
+    float *mod = nullptr, *c = nullptr;
+    // optional in-situ kernel timing (HIP events on the launching stream; never under capture)
+    t2s_train_ws* train = nullptr;
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<int> ev_class;   // class of interval i = [ev_pool[2i], ev_pool[2i+1]]
+};
+

@@ -16,8 +16,8 @@
 
 namespace t2s {
 
-enum { PRO_PLAIN = 0, PRO_LNMOD = 1, PRO_SILU = 2 };
-enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_QKV = 2, EPI_GATERES = 3 };
+enum { PRO_PLAIN = 0, PRO_LNMOD = 1, PRO_SILU = 2, PRO_GELU = 3 };
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_QKV = 2, EPI_GATERES = 3, EPI_GELUBWD = 4 };
 
 struct GemmArgs {
     const float* A;     // (M,K)
@@ -33,7 +33,17 @@ struct GemmArgs {
     float* q;           // EPI_QKV destinations, each (S,4,480,32)
     float* k;
     float* v;
+    float* save_A;      // optional (M,K): the prologue-transformed A rows (training saves LN-modulated inputs)
+    const float* aux;   // EPI_GELUBWD: pre-activation u (M,N); out = acc * gelu'(u)
 };
+
+// d/du [ u * sigmoid(2 z(u)) ],  z = sqrt(2/pi) (u + 0.044715 u^3)   (GELU tanh form)
+__device__ __forceinline__ float gelu_tanh_grad(float u) {
+    const float c = 0.7978845608028654f;
+    const float z = c * (u + 0.044715f * u * u * u);
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * z));
+    return sg + u * sg * (1.0f - sg) * 2.0f * c * (1.0f + 3.0f * 0.044715f * u * u);
+}
 
 __device__ __forceinline__ float gelu_tanh(float x) {
     // 0.5 x (1 + tanh(u)) == x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3)
@@ -56,39 +66,52 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmArgs a) {
     const int m0 = blockIdx.x * BM;
 
     // ---------------- prologue: stage (and transform) the A tile ----------------
-    {
-        constexpr int LPR = K / 4;         // lanes per row (float4 each): 32 or 64
-        constexpr int RPP = 256 / LPR;     // rows per pass
-        const int c4 = tid % LPR;
-        const int rip = tid / LPR;
+    if constexpr (PRO == PRO_LNMOD) {
+        // LayerNorm + modulate over d_model = 128: 32 lanes (float4 each) per row, 8 rows per pass
+        static_assert(PRO != PRO_LNMOD || K == 128, "LayerNorm prologue is over d_model=128");
+        const int c4 = tid & 31;
+        const int rip = tid >> 5;
 #pragma unroll 4
-        for (int pass = 0; pass < BM / RPP; ++pass) {
-            const int row = pass * RPP + rip;
+        for (int pass = 0; pass < BM / 8; ++pass) {
+            const int row = pass * 8 + rip;
             const int grow = m0 + row;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (grow < a.M) v = *reinterpret_cast<const f32x4*>(a.A + (size_t)grow * K + c4 * 4);
-            if constexpr (PRO == PRO_LNMOD) {
-                static_assert(PRO != PRO_LNMOD || K == 128, "LayerNorm prologue is over d_model=128");
-                float s = (v.x + v.y) + (v.z + v.w);
+            float s = (v.x + v.y) + (v.z + v.w);
 #pragma unroll
-                for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-                const float mean = s * (1.0f / 128.0f);
-                f32x4 d = v - mean;
-                float ss = (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+            for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+            const float mean = s * (1.0f / 128.0f);
+            f32x4 d = v - mean;
+            float ss = (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
 #pragma unroll
-                for (int o = 16; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
-                const float rstd = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
-                const int seq = (grow < a.M ? grow : 0) / NTOK;
-                const float* mrow = a.mod + (size_t)seq * MODROW;
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(mrow + a.scale_off + c4 * 4);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(mrow + a.shift_off + c4 * 4);
-                v = (d * rstd) * (1.0f + sc) + sh;
-            } else if constexpr (PRO == PRO_SILU) {
+            for (int o = 16; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            const float rstd = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+            const int seq = (grow < a.M ? grow : 0) / NTOK;
+            const float* mrow = a.mod + (size_t)seq * MODROW;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(mrow + a.scale_off + c4 * 4);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(mrow + a.shift_off + c4 * 4);
+            v = (d * rstd) * (1.0f + sc) + sh;
+            if (a.save_A != nullptr && blockIdx.y == 0 && grow < a.M)
+                *reinterpret_cast<f32x4*>(a.save_A + (size_t)grow * K + c4 * 4) = v;
+            *reinterpret_cast<f32x4*>(smem + row * LDA + c4 * 4) = v;
+        }
+    } else {
+        constexpr int F4 = K / 4;   // float4 per row
+        for (int idx = tid; idx < BM * F4; idx += 256) {
+            const int row = idx / F4, c4 = idx - row * F4;
+            const int grow = m0 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (grow < a.M) v = *reinterpret_cast<const f32x4*>(a.A + (size_t)grow * K + c4 * 4);
+            if constexpr (PRO == PRO_SILU) {
                 v.x = v.x / (1.0f + __expf(-v.x));
                 v.y = v.y / (1.0f + __expf(-v.y));
                 v.z = v.z / (1.0f + __expf(-v.z));
                 v.w = v.w / (1.0f + __expf(-v.w));
+            } else if constexpr (PRO == PRO_GELU) {
+                v.x = gelu_tanh(v.x); v.y = gelu_tanh(v.y); v.z = gelu_tanh(v.z); v.w = gelu_tanh(v.w);
             }
+            if (a.save_A != nullptr && blockIdx.y == 0 && grow < a.M)
+                *reinterpret_cast<f32x4*>(a.save_A + (size_t)grow * K + c4 * 4) = v;
             *reinterpret_cast<f32x4*>(smem + row * LDA + c4 * 4) = v;
         }
     }
@@ -135,7 +158,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int col = (nt0 + nt) * 32 + j;
-        const float bias = a.bias[col];
+        const float bias = a.bias ? a.bias[col] : 0.f;
         float* qkv_base = nullptr;
         int head = 0;
         if constexpr (EPI == EPI_QKV) {
@@ -154,6 +177,8 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmArgs a) {
                     a.out[(size_t)grow * a.N + col] = y;
                 } else if constexpr (EPI == EPI_GELU) {
                     a.out[(size_t)grow * a.N + col] = gelu_tanh(y);
+                } else if constexpr (EPI == EPI_GELUBWD) {
+                    a.out[(size_t)grow * a.N + col] = y * gelu_tanh_grad(a.aux[(size_t)grow * a.N + col]);
                 } else if constexpr (EPI == EPI_QKV) {
                     const int seq = grow / NTOK;
                     const int tok = grow - seq * NTOK;
@@ -187,6 +212,14 @@ inline int launch_gemm_rows(const GemmArgs& a, hipStream_t st) {
         return T2S_E_INVALID;
     }
     constexpr size_t lds = (size_t)64 * (K + 4) * sizeof(float);
+    if constexpr (lds > 48 * 1024) {
+        static bool attr = false;   // first call must not be under stream capture (training never is)
+        if (!attr) {
+            T2S_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<K, NT, PRO, EPI>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = true;
+        }
+    }
     dim3 grid((a.M + 63) / 64, a.N / BN);
     gemm_rows_kernel<K, NT, PRO, EPI><<<grid, 256, lds, st>>>(a);
     T2S_LAUNCH_CHECK();

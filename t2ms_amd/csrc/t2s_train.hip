@@ -1,0 +1,763 @@
+// Training step of the DiT for MI355X (reference train.py:101-127): forward that keeps the
+// activations, hand-written backward for every trainable tensor, fused AdamW.
+//
+//   forward  (per block)  x_in -LN1,mod-> a1 -qkv-> q,k,v -attn-> o -proj-> p ; x_mid = x_in + g1 p
+//                         x_mid -LN2,mod-> a2 -fc1-> u -gelu,fc2-> f ; x_out = x_mid + g2 f
+//   backward (reverse)    gate/residual, fc2 (dgrad+wgrad), gelu', fc1, LN2/mod, proj, attention
+//                         (dQ kernel + dK/dV kernel, P recomputed from the saved log-sum-exp), qkv,
+//                         LN1/mod; then patchify, final layer and the adaLN linear.
+//
+// Round-1 design: correctness first, fp32 end to end, activations row-major.  Forward linears and
+// every dgrad reuse gemm_rows_kernel (dgrad = the same kernel on transposed-packed weights);
+// weight gradients are one MFMA kernel (A = dY^T, B = X straight from row-major global memory,
+// contraction over token rows, fp32 atomics into the gradient); per-sequence reductions (adaLN
+// shift / scale / gate gradients, LayerNorm backward) are deterministic one-workgroup-per-sequence
+// kernels.  Parity: tests/test_hip_train.py against autograd through the CPU oracle and the
+// reference-generated fixture tests/golden/train_step.npz.
+#include <vector>
+
+#include "t2s_gemm.h"
+#include "t2s_dit_internal.h"
+
+using namespace t2s;
+
+namespace t2s {
+int attn_plain_train_fwd(const float* q, const float* k, const float* v, float* o_rows, float* lse, int BH,
+                         hipStream_t st);
+int attn_bwd(const float* q, const float* k, const float* v, const float* o_rows, const float* do_rows,
+             const float* lse, float* dsum, float* dqkv_rows, int BH, hipStream_t st);
+}
+
+// ------------------------------------------------------------------ workspace
+struct t2s_train_ws {
+    int cap_seqs = 0;
+    int S = 0;            // sequences of the last forward
+    bool has_text = false;
+    // packed weights for training (tile-major, both orientations), refreshed by pack_train_weights
+    float* warena = nullptr;
+    f32x4 *qkv_f[NBLK], *proj_f[NBLK], *fc1_f[NBLK], *fc2_f[NBLK];   // forward:  W   (N,K)
+    f32x4 *qkv_t[NBLK], *proj_t[NBLK], *fc1_t[NBLK], *fc2_t[NBLK];   // dgrad:    W^T (K,N)
+    f32x4* out_t = nullptr;                                           // unused (final layer is VALU)
+    // raw (reference-layout) copies the VALU backward kernels read
+    float *w_out = nullptr, *w_pe = nullptr, *w_conv = nullptr, *ln_g = nullptr;
+    // saved activations
+    float* act = nullptr;
+    float *x_in[NBLK + 1], *a1[NBLK], *q[NBLK], *k[NBLK], *v[NBLK], *o[NBLK], *lse[NBLK], *p[NBLK],
+        *x_mid[NBLK], *a2[NBLK], *u[NBLK], *f[NBLK];
+    float *silu_c = nullptr, *mod = nullptr, *c = nullptr, *lat = nullptr;   // (S,128) (S,3072) (S,128) (S,1920)
+    // backward temporaries
+    float *dx = nullptr, *t1 = nullptr, *t2a = nullptr, *t2b = nullptr, *t3 = nullptr, *t4 = nullptr, *dsum = nullptr,
+          *dmod = nullptr;
+};
+
+namespace {
+
+size_t r64(size_t n) { return (n + 63) & ~size_t(63); }
+
+// W (N,K) row-major -> packed_index order of W (transpose=0) or of W^T (K,N) (transpose=1)
+__global__ void pack_any_kernel(const float* __restrict__ W, float* __restrict__ P, int N, int K, int transpose) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * K) return;
+    const int n = idx / K, k = idx - n * K;
+    if (!transpose)
+        P[packed_index(n, k, K)] = W[idx];
+    else
+        P[packed_index(k, n, N)] = W[idx];   // W^T is (K rows, N cols)
+}
+
+int pack_any(const float* W, f32x4* P, int N, int K, int transpose, hipStream_t st) {
+    pack_any_kernel<<<(N * K + 255) / 256, 256, 0, st>>>(W, reinterpret_cast<float*>(P), N, K, transpose);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+// ---------------------------------------------------------------- elementwise / per-sequence kernels
+// x_out = x_in + gate[seq] * f      (rows of 128)
+__global__ __launch_bounds__(256) void gate_res_kernel(const float* __restrict__ xin, const float* __restrict__ f,
+                                                       const float* __restrict__ mod, int gate_off,
+                                                       float* __restrict__ xout, int M) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // float4 index
+    if (idx >= M * 32) return;
+    const int row = idx >> 5, c4 = idx & 31;
+    const int seq = row / NTOK;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(mod + (size_t)seq * MODROW + gate_off + c4 * 4);
+    const f32x4 a = reinterpret_cast<const f32x4*>(xin)[idx];
+    const f32x4 b = reinterpret_cast<const f32x4*>(f)[idx];
+    reinterpret_cast<f32x4*>(xout)[idx] = a + g * b;
+}
+
+// one workgroup per sequence: t = gate * dx ; dgate[seq] = sum_tok dx * f
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ f,
+                                                       const float* __restrict__ mod, int gate_off,
+                                                       float* __restrict__ t, float* __restrict__ dmod) {
+    __shared__ f32x4 red[8][32];
+    const int seq = blockIdx.x;
+    const int c4 = threadIdx.x & 31, rg = threadIdx.x >> 5;   // 8 row groups
+    const f32x4 g = *reinterpret_cast<const f32x4*>(mod + (size_t)seq * MODROW + gate_off + c4 * 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int tok = rg; tok < NTOK; tok += 8) {
+        const size_t idx = ((size_t)seq * NTOK + tok) * 32 + c4;
+        const f32x4 d = reinterpret_cast<const f32x4*>(dx)[idx];
+        const f32x4 fv = reinterpret_cast<const f32x4*>(f)[idx];
+        reinterpret_cast<f32x4*>(t)[idx] = g * d;
+        acc += d * fv;
+    }
+    red[rg][c4] = acc;
+    __syncthreads();
+    if (rg == 0) {
+        f32x4 s = red[0][c4];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) s += red[i][c4];
+        *reinterpret_cast<f32x4*>(dmod + (size_t)seq * MODROW + gate_off + c4 * 4) = s;
+    }
+}
+
+// one workgroup per sequence.  da = grad wrt modulate(LN(x)); computes
+//   dshift = sum_tok da, dscale = sum_tok da * n, dn = da * (1 + scale),
+//   dx += rstd * (dn - mean(dn) - n * mean(dn * n))          (LayerNorm backward, eps 1e-6, no affine)
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict__ da, const float* __restrict__ x,
+                                                         const float* __restrict__ mod, int shift_off, int scale_off,
+                                                         float* __restrict__ dx, float* __restrict__ dmod) {
+    __shared__ f32x4 red[2][8][32];
+    const int seq = blockIdx.x;
+    const int c4 = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(mod + (size_t)seq * MODROW + scale_off + c4 * 4);
+    f32x4 a_sh = {0.f, 0.f, 0.f, 0.f}, a_sc = {0.f, 0.f, 0.f, 0.f};
+    for (int tok = rg; tok < NTOK; tok += 8) {
+        const size_t idx = ((size_t)seq * NTOK + tok) * 32 + c4;
+        const f32x4 xv = reinterpret_cast<const f32x4*>(x)[idx];
+        const f32x4 g = reinterpret_cast<const f32x4*>(da)[idx];
+        float s = (xv.x + xv.y) + (xv.z + xv.w);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s * (1.0f / 128.0f);
+        const f32x4 d = xv - mean;
+        float ss = (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float rstd = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+        const f32x4 n = d * rstd;
+        a_sh += g;
+        a_sc += g * n;
+        const f32x4 dn = g * (1.0f + sc);
+        float m1 = (dn.x + dn.y) + (dn.z + dn.w);
+        float m2 = (dn.x * n.x + dn.y * n.y) + (dn.z * n.z + dn.w * n.w);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) {
+            m1 += __shfl_xor(m1, o, 64);
+            m2 += __shfl_xor(m2, o, 64);
+        }
+        m1 *= (1.0f / 128.0f);
+        m2 *= (1.0f / 128.0f);
+        const f32x4 r = (dn - m1 - n * m2) * rstd;
+        reinterpret_cast<f32x4*>(dx)[idx] = reinterpret_cast<const f32x4*>(dx)[idx] + r;
+    }
+    red[0][rg][c4] = a_sh;
+    red[1][rg][c4] = a_sc;
+    __syncthreads();
+    if (rg < 2) {
+        f32x4 s = red[rg][0][c4];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) s += red[rg][i][c4];
+        const int off = rg == 0 ? shift_off : scale_off;
+        *reinterpret_cast<f32x4*>(dmod + (size_t)seq * MODROW + off + c4 * 4) = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ u, float* __restrict__ out, size_t n4) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n4) return;
+    f32x4 v = reinterpret_cast<const f32x4*>(u)[idx];
+    v.x = gelu_tanh(v.x); v.y = gelu_tanh(v.y); v.z = gelu_tanh(v.z); v.w = gelu_tanh(v.w);
+    reinterpret_cast<f32x4*>(out)[idx] = v;
+}
+
+__global__ __launch_bounds__(256) void silu_kernel(const float* __restrict__ c, float* __restrict__ out, int n) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const float v = c[idx];
+    out[idx] = v / (1.0f + __expf(-v));
+}
+
+// out[n] += sum_rows Y[row][n]   (N <= 3072, N % 4 == 0); slab of rows per workgroup, fp32 atomics
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ Y, float* __restrict__ out, int M, int N,
+                                                     int rows_per_wg) {
+    const int r0 = blockIdx.x * rows_per_wg;
+    const int r1 = min(M, r0 + rows_per_wg);
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float acc = 0.f;
+        for (int r = r0; r < r1; ++r) acc += Y[(size_t)r * N + n];
+        atomicAdd(out + n, acc);
+    }
+}
+
+// dW[n][k] += sum_rows dY[row][n] * X[row][k]    (weight gradient, N % 32 == 0, K % 128 == 0)
+// A operand = dY^T, B operand = X: both straight from row-major global memory (lane = feature:
+// 128-B coalesced segments, two token rows per MFMA).  A wave owns one 32-wide n-tile x four
+// k-tiles; a workgroup covers `rows_per_wg` token rows and adds its partial tile with atomics.
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                    float* __restrict__ dW, int M, int N, int K, int rows_per_wg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, j = lane & 31;
+    const int job = blockIdx.y * 4 + wave;          // (n-tile, k-chunk of 128)
+    const int n_tiles = N >> 5;
+    if (job >= n_tiles * (K >> 7)) return;
+    const int nt = job % n_tiles, kc = job / n_tiles;
+    const int r0 = blockIdx.x * rows_per_wg;
+    const int r1 = min(M, r0 + rows_per_wg);
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const float* ya = dY + nt * 32 + j;
+    const float* xb = X + kc * 128 + j;
+    for (int r = r0; r < r1; r += 2) {
+        const int row = r + half;
+        const bool ok = row < r1;
+        const float a = ok ? ya[(size_t)row * N] : 0.f;
+        float b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = ok ? xb[(size_t)row * K + t * 32] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma32(a, b[t], acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            atomicAdd(dW + (size_t)(nt * 32 + acc_row(r, half)) * K + kc * 128 + t * 32 + j, acc[t][r]);
+}
+
+// final layer backward (transformer.py:182-191): dout (S,64,30) -> dx (M,128) and grads of
+// ln.weight, ln.bias, linear_emb_to_patch.{weight,bias}.  32 lanes per token row.
+__global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                                        const float* __restrict__ lng, const float* __restrict__ lnb,
+                                                        const float* __restrict__ ow, float* __restrict__ dx,
+                                                        float* __restrict__ g_lnw, float* __restrict__ g_lnb,
+                                                        float* __restrict__ g_ow, float* __restrict__ g_ob, int M) {
+    __shared__ f32x4 red[6][8][32];
+    __shared__ float redb[8][4];
+    const int c4 = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const f32x4 gam = *reinterpret_cast<const f32x4*>(lng + c4 * 4);
+    const f32x4 bet = *reinterpret_cast<const f32x4*>(lnb + c4 * 4);
+    f32x4 w[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) w[p] = *reinterpret_cast<const f32x4*>(ow + p * D + c4 * 4);
+    f32x4 a_g = {0, 0, 0, 0}, a_b = {0, 0, 0, 0}, a_w[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    float a_ob[4] = {0.f, 0.f, 0.f, 0.f};
+    const int row0 = blockIdx.x * 64;
+    for (int rr = rg; rr < 64; rr += 8) {
+        const int row = row0 + rr;
+        if (row >= M) break;   // uniform per 32-lane group; shuffles below stay inside the group
+        const size_t idx = (size_t)row * 32 + c4;
+        const f32x4 xv = reinterpret_cast<const f32x4*>(x)[idx];
+        float s = (xv.x + xv.y) + (xv.z + xv.w);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s * (1.0f / 128.0f);
+        const f32x4 d = xv - mean;
+        float ss = (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float rstd = rsqrtf(ss * (1.0f / 128.0f) + 1e-5f);
+        const f32x4 n = d * rstd;
+        const f32x4 y = n * gam + bet;
+        // gather d(lin)[p] from the unpatchified output gradient
+        const int seq = row / NTOK, tok = row - seq * NTOK;
+        const int hh = tok >> 5, ww = tok & 31;
+        float dl[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            dl[p] = dout[(size_t)seq * LAT + (2 * ww + (p & 1)) * LATW + 2 * hh + (p >> 1)];
+        f32x4 dy = {0, 0, 0, 0};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            dy += w[p] * dl[p];
+            a_w[p] += y * dl[p];
+            a_ob[p] += dl[p];
+        }
+        a_g += dy * n;
+        a_b += dy;
+        const f32x4 dn = dy * gam;
+        float m1 = (dn.x + dn.y) + (dn.z + dn.w);
+        float m2 = (dn.x * n.x + dn.y * n.y) + (dn.z * n.z + dn.w * n.w);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) {
+            m1 += __shfl_xor(m1, o, 64);
+            m2 += __shfl_xor(m2, o, 64);
+        }
+        m1 *= (1.0f / 128.0f);
+        m2 *= (1.0f / 128.0f);
+        reinterpret_cast<f32x4*>(dx)[idx] = (dn - m1 - n * m2) * rstd;
+    }
+    red[0][rg][c4] = a_g;
+    red[1][rg][c4] = a_b;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) red[2 + p][rg][c4] = a_w[p];
+    if (c4 == 0)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) redb[rg][p] = a_ob[p];
+    __syncthreads();
+    if (rg < 6) {
+        f32x4 s = red[rg][0][c4];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) s += red[rg][i][c4];
+        float* dst = rg == 0 ? g_lnw + c4 * 4 : (rg == 1 ? g_lnb + c4 * 4 : g_ow + (rg - 2) * D + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(dst + e, s[e]);
+    } else if (rg == 6 && c4 < 4) {
+        float s = 0.f;
+        for (int i = 0; i < 8; ++i) s += redb[i][c4];
+        atomicAdd(g_ob + c4, s);
+    }
+}
+
+// patchify backward (transformer.py:166-172): dtok (M,128) -> grads of patch_emb.{weight,bias}, conv.{weight,bias}
+__global__ __launch_bounds__(256) void patchify_bwd_kernel(const float* __restrict__ dtok, const float* __restrict__ lat,
+                                                           int B, const float* __restrict__ cw, const float* __restrict__ cb,
+                                                           const float* __restrict__ pw, float* __restrict__ g_pw,
+                                                           float* __restrict__ g_pb, float* __restrict__ g_cw,
+                                                           float* __restrict__ g_cb, int M) {
+    __shared__ f32x4 red[5][8][32];
+    __shared__ float redc[8][20];
+    const int c4 = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    f32x4 wpe[4];   // patch_emb.weight[d][c] for d = 4*c4+e
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wpe[e] = *reinterpret_cast<const f32x4*>(pw + (c4 * 4 + e) * 4);
+    f32x4 a_pw[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // [c] over the lane's 4 features
+    f32x4 a_pb = {0, 0, 0, 0};
+    float a_cw[16], a_cb[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a_cw[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_cb[i] = 0.f;
+    const int row0 = blockIdx.x * 64;
+    for (int rr = rg; rr < 64; rr += 8) {
+        const int row = row0 + rr;
+        if (row >= M) break;
+        const f32x4 g = reinterpret_cast<const f32x4*>(dtok)[(size_t)row * 32 + c4];
+        const int seq = row / NTOK, tok = row - seq * NTOK;
+        const int hh = tok >> 5, ww = tok & 31;
+        const float* xin = lat + (size_t)(seq % B) * LAT;
+        float px[4];   // [i*2+j] = in[2hh+i][2ww+j]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) px[i * 2 + jj] = xin[(2 * ww + jj) * LATW + 2 * hh + i];
+        float cv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            cv[c] = cw[c * 4] * px[0] + cw[c * 4 + 1] * px[1] + cw[c * 4 + 2] * px[2] + cw[c * 4 + 3] * px[3] + cb[c];
+        float dc[4];   // dconv[c] = sum_d dtok[d] * Wpe[d][c]
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float s = g.x * wpe[0][c] + g.y * wpe[1][c] + g.z * wpe[2][c] + g.w * wpe[3][c];
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+            dc[c] = s;
+            a_pw[c] += g * cv[c];
+        }
+        a_pb += g;
+        if (c4 == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                a_cb[c] += dc[c];
+#pragma unroll
+                for (int ij = 0; ij < 4; ++ij) a_cw[c * 4 + ij] += dc[c] * px[ij];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[c][rg][c4] = a_pw[c];
+    red[4][rg][c4] = a_pb;
+    if (c4 == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) redc[rg][i] = a_cw[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) redc[rg][16 + i] = a_cb[i];
+    }
+    __syncthreads();
+    if (rg < 5) {
+        f32x4 s = red[rg][0][c4];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) s += red[rg][i][c4];
+        if (rg < 4) {   // g_pw[d][c], d = 4*c4+e, c = rg
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(g_pw + (c4 * 4 + e) * 4 + rg, s[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(g_pb + c4 * 4 + e, s[e]);
+        }
+    } else if (rg == 5 && c4 < 20) {
+        float s = 0.f;
+        for (int i = 0; i < 8; ++i) s += redc[i][c4];
+        atomicAdd(c4 < 16 ? g_cw + c4 : g_cb + (c4 - 16), s);
+    }
+}
+
+// fused AdamW (torch.optim.AdamW semantics, decoupled weight decay, bias-corrected moments)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
+                                                    float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float pv = p[i];
+    const float gv = g[i];
+    pv *= 1.0f - lr * wd;
+    const float mv = b1 * m[i] + (1.0f - b1) * gv;
+    const float vv = b2 * v[i] + (1.0f - b2) * gv * gv;
+    m[i] = mv;
+    v[i] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p[i] = pv - (lr / bc1) * mv / denom;
+}
+
+__global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      const float* __restrict__ gout, float* __restrict__ da, size_t n,
+                                                      float sign) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    da[i] = sign * 2.0f * (a[i] - b[i]) * (gout[0] / (float)n);
+}
+
+// c = temb (+ text)   (transformer.py:176-178)
+__global__ void cond_rows_kernel(float* __restrict__ c, const float* __restrict__ temb, int temb_rows,
+                                 const float* __restrict__ text, int S) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * D) return;
+    const int s = idx >> 7, d = idx & 127;
+    float val = temb[(size_t)(temb_rows == 1 ? 0 : s) * D + d];
+    if (text) val += text[idx];
+    c[idx] = val;
+}
+
+// patchify, row-major output (transformer.py:166-172)
+__global__ __launch_bounds__(256) void patchify_rows_kernel(const float* __restrict__ x, float* __restrict__ h, int S,
+                                                            const float* __restrict__ cw, const float* __restrict__ cb,
+                                                            const float* __restrict__ pw, const float* __restrict__ pb,
+                                                            const float* __restrict__ pos) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= S * NTOK * 32) return;
+    const int c4 = gid & 31, tokg = gid >> 5;
+    const int s = tokg / NTOK, n = tokg - s * NTOK;
+    const int hh = n >> 5, ww = n & 31;
+    const float* xin = x + (size_t)s * LAT;
+    float px[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) px[i * 2 + j] = xin[(2 * ww + j) * LATW + 2 * hh + i];
+    float cv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float acc = cw[c * 4 + 0] * px[0];
+        acc += cw[c * 4 + 1] * px[1];
+        acc += cw[c * 4 + 2] * px[2];
+        acc += cw[c * 4 + 3] * px[3];
+        cv[c] = acc + cb[c];
+    }
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int d = c4 * 4 + e;
+        const f32x4 w = *reinterpret_cast<const f32x4*>(pw + d * 4);
+        float acc = w.x * cv[0];
+        acc += w.y * cv[1];
+        acc += w.z * cv[2];
+        acc += w.w * cv[3];
+        o[e] = acc + pb[d] + pos[n * D + d];
+    }
+    reinterpret_cast<f32x4*>(h)[gid] = o;
+}
+
+// final layer, row-major input (transformer.py:182-191)
+__global__ __launch_bounds__(256) void final_rows_kernel(const float* __restrict__ h, int S, const float* __restrict__ lnw,
+                                                         const float* __restrict__ lnb, const float* __restrict__ ow,
+                                                         const float* __restrict__ ob, float* __restrict__ out) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4 = gid & 31;
+    int tokg = gid >> 5;
+    const bool valid = tokg < S * NTOK;
+    if (!valid) tokg = S * NTOK - 1;
+    const f32x4 v = reinterpret_cast<const f32x4*>(h)[(size_t)tokg * 32 + c4];
+    float s1 = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+    const float mean = s1 * (1.0f / 128.0f);
+    const f32x4 d = v - mean;
+    float s2 = (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+    const float rstd = rsqrtf(s2 * (1.0f / 128.0f) + 1e-5f);
+    const f32x4 y = (d * rstd) * *reinterpret_cast<const f32x4*>(lnw + c4 * 4) + *reinterpret_cast<const f32x4*>(lnb + c4 * 4);
+    float acc[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(ow + p * D + c4 * 4);
+        float a = (y.x * w.x + y.y * w.y) + (y.z * w.z + y.w * w.w);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
+        acc[p] = a + ob[p];
+    }
+    if (valid && c4 < 4) {
+        const int s = tokg / NTOK, n = tokg - s * NTOK;
+        const int hh = n >> 5, ww = n & 31;
+        out[(size_t)s * LAT + (2 * ww + (c4 & 1)) * LATW + 2 * hh + (c4 >> 1)] = acc[c4];
+    }
+}
+
+// ---------------------------------------------------------------- workspace management
+int ensure_ws(t2s_dit* h, int S) {
+    if (h->train && h->train->cap_seqs >= S) return T2S_OK;
+    if (h->train) {
+        t2s_train_ws* w = h->train;
+        float* bufs[] = {w->warena, w->act};
+        for (float* b : bufs)
+            if (b) (void)hipFree(b);
+        delete w;
+        h->train = nullptr;
+    }
+    t2s_train_ws* w = new t2s_train_ws();
+    w->cap_seqs = S;
+    // ---- packed weights
+    size_t woff = 0;
+    auto wtake = [&](size_t n) { size_t o = woff; woff += r64(n); return o; };
+    size_t o_qkv_f[NBLK], o_proj_f[NBLK], o_fc1_f[NBLK], o_fc2_f[NBLK], o_qkv_t[NBLK], o_proj_t[NBLK], o_fc1_t[NBLK],
+        o_fc2_t[NBLK];
+    for (int i = 0; i < NBLK; ++i) {
+        o_qkv_f[i] = wtake(3 * D * D); o_proj_f[i] = wtake(D * D); o_fc1_f[i] = wtake(2 * D * D); o_fc2_f[i] = wtake(2 * D * D);
+        o_qkv_t[i] = wtake(3 * D * D); o_proj_t[i] = wtake(D * D); o_fc1_t[i] = wtake(2 * D * D); o_fc2_t[i] = wtake(2 * D * D);
+    }
+    if (hipMalloc(&w->warena, woff * sizeof(float)) != hipSuccess) {
+        set_error("t2s train: hipMalloc(packed weights) failed");
+        delete w;
+        return T2S_E_HIP;
+    }
+    for (int i = 0; i < NBLK; ++i) {
+        w->qkv_f[i] = (f32x4*)(w->warena + o_qkv_f[i]); w->proj_f[i] = (f32x4*)(w->warena + o_proj_f[i]);
+        w->fc1_f[i] = (f32x4*)(w->warena + o_fc1_f[i]); w->fc2_f[i] = (f32x4*)(w->warena + o_fc2_f[i]);
+        w->qkv_t[i] = (f32x4*)(w->warena + o_qkv_t[i]); w->proj_t[i] = (f32x4*)(w->warena + o_proj_t[i]);
+        w->fc1_t[i] = (f32x4*)(w->warena + o_fc1_t[i]); w->fc2_t[i] = (f32x4*)(w->warena + o_fc2_t[i]);
+    }
+    // ---- activations + temporaries
+    const size_t M = (size_t)S * NTOK;
+    size_t aoff = 0;
+    auto atake = [&](size_t n) { size_t o = aoff; aoff += r64(n); return o; };
+    size_t o_xin[NBLK + 1], o_a1[NBLK], o_q[NBLK], o_k[NBLK], o_v[NBLK], o_o[NBLK], o_lse[NBLK], o_p[NBLK], o_xm[NBLK],
+        o_a2[NBLK], o_u[NBLK], o_f[NBLK];
+    for (int i = 0; i <= NBLK; ++i) o_xin[i] = atake(M * D);
+    for (int i = 0; i < NBLK; ++i) {
+        o_a1[i] = atake(M * D); o_q[i] = atake(M * D); o_k[i] = atake(M * D); o_v[i] = atake(M * D); o_o[i] = atake(M * D);
+        o_lse[i] = atake(M * NH); o_p[i] = atake(M * D); o_xm[i] = atake(M * D); o_a2[i] = atake(M * D);
+        o_u[i] = atake(M * 2 * D); o_f[i] = atake(M * D);
+    }
+    const size_t o_silu = atake((size_t)S * D), o_mod = atake((size_t)S * MODROW), o_c = atake((size_t)S * D),
+                 o_lat = atake((size_t)S * LAT), o_dx = atake(M * D), o_t1 = atake(M * D), o_t2a = atake(M * 2 * D),
+                 o_t2b = atake(M * 2 * D), o_t3 = atake(M * 3 * D), o_t4 = atake(M * D), o_dsum = atake(M * NH),
+                 o_dmod = atake((size_t)S * MODROW);
+    if (hipMalloc(&w->act, aoff * sizeof(float)) != hipSuccess) {
+        set_error("t2s train: hipMalloc(activations, %.1f MB) failed", aoff * 4 / 1e6);
+        (void)hipFree(w->warena);
+        delete w;
+        return T2S_E_HIP;
+    }
+    float* A = w->act;
+    for (int i = 0; i <= NBLK; ++i) w->x_in[i] = A + o_xin[i];
+    for (int i = 0; i < NBLK; ++i) {
+        w->a1[i] = A + o_a1[i]; w->q[i] = A + o_q[i]; w->k[i] = A + o_k[i]; w->v[i] = A + o_v[i]; w->o[i] = A + o_o[i];
+        w->lse[i] = A + o_lse[i]; w->p[i] = A + o_p[i]; w->x_mid[i] = A + o_xm[i]; w->a2[i] = A + o_a2[i];
+        w->u[i] = A + o_u[i]; w->f[i] = A + o_f[i];
+    }
+    w->silu_c = A + o_silu; w->mod = A + o_mod; w->c = A + o_c; w->lat = A + o_lat; w->dx = A + o_dx; w->t1 = A + o_t1;
+    w->t2a = A + o_t2a; w->t2b = A + o_t2b; w->t3 = A + o_t3; w->t4 = A + o_t4; w->dsum = A + o_dsum; w->dmod = A + o_dmod;
+    h->train = w;
+    return T2S_OK;
+}
+
+template <int K, int NT, int PRO, int EPI>
+int gemm(const float* A, const f32x4* Wp, const float* bias, float* out, int M, int N, hipStream_t st,
+         const float* mod = nullptr, int shift_off = 0, int scale_off = 0, float* save_A = nullptr,
+         const float* aux = nullptr, float* q = nullptr, float* k = nullptr, float* v = nullptr) {
+    GemmArgs a{};
+    a.A = A; a.Wp = Wp; a.bias = bias; a.out = out; a.M = M; a.N = N; a.mod = mod; a.shift_off = shift_off;
+    a.scale_off = scale_off; a.save_A = save_A; a.aux = aux; a.q = q; a.k = k; a.v = v;
+    return launch_gemm_rows<K, NT, PRO, EPI>(a, st);
+}
+
+int wgrad(const float* dY, const float* X, float* dW, int M, int N, int K, hipStream_t st) {
+    const int rows_per_wg = 1024;
+    const int jobs = (N / 32) * (K / 128);
+    dim3 grid((M + rows_per_wg - 1) / rows_per_wg, (jobs + 3) / 4);
+    wgrad_kernel<<<grid, 256, 0, st>>>(dY, X, dW, M, N, K, rows_per_wg);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+int colsum(const float* Y, float* out, int M, int N, hipStream_t st) {
+    const int rows_per_wg = 512;
+    colsum_kernel<<<(M + rows_per_wg - 1) / rows_per_wg, 256, 0, st>>>(Y, out, M, N, rows_per_wg);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+}  // namespace
+
+namespace t2s {
+void train_free(t2s_dit* h) {
+    if (!h || !h->train) return;
+    if (h->train->warena) (void)hipFree(h->train->warena);
+    if (h->train->act) (void)hipFree(h->train->act);
+    delete h->train;
+    h->train = nullptr;
+}
+}  // namespace t2s
+
+// ------------------------------------------------------------------ C ABI
+extern "C" {
+
+int t2s_dit_train_forward(t2s_dit* h, const t2s_dit_weights* w, const float* x, const float* temb, int temb_rows,
+                          const float* text, float* out, int B, void* stream) {
+    T2S_REQUIRE(h && w && x && temb && out, "t2s_dit_train_forward: NULL argument");
+    T2S_REQUIRE(B > 0 && B <= h->max_seqs, "t2s_dit_train_forward: B=%d exceeds max_seqs=%d", B, h->max_seqs);
+    T2S_REQUIRE(temb_rows == 1 || temb_rows == B, "t2s_dit_train_forward: temb_rows=%d", temb_rows);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_ws(h, B);
+    if (rc != T2S_OK) return rc;
+    t2s_train_ws* ws = h->train;
+    const int S = B, M = S * NTOK;
+    ws->S = S;
+    ws->has_text = text != nullptr;
+    // the handle's own parameter copies / forward packs must be current: the caller refreshes them
+    // with t2s_dit_update_weights; here only the training-specific packs (fc2 tile-major, all W^T)
+    for (int i = 0; i < NBLK; ++i) {
+        const t2s_dit_block_weights& b = w->blk[i];
+        if ((rc = pack_any(b.qkv_w, ws->qkv_t[i], 3 * D, D, 1, st)) || (rc = pack_any(b.proj_w, ws->proj_t[i], D, D, 1, st)) ||
+            (rc = pack_any(b.fc1_w, ws->fc1_t[i], 2 * D, D, 1, st)) || (rc = pack_any(b.fc2_w, ws->fc2_f[i], D, 2 * D, 0, st)) ||
+            (rc = pack_any(b.fc2_w, ws->fc2_t[i], D, 2 * D, 1, st)))
+            return rc;
+    }
+    T2S_HIP_CHECK(hipMemcpyAsync(ws->lat, x, (size_t)S * LAT * sizeof(float), hipMemcpyDeviceToDevice, st));
+    cond_rows_kernel<<<(S * D + 255) / 256, 256, 0, st>>>(ws->c, temb, temb_rows, text, S);
+    T2S_LAUNCH_CHECK();
+    silu_kernel<<<(S * D + 255) / 256, 256, 0, st>>>(ws->c, ws->silu_c, S * D);
+    T2S_LAUNCH_CHECK();
+    if ((rc = gemm<128, 3, PRO_PLAIN, EPI_BIAS>(ws->silu_c, h->ada_p, h->ada_b, ws->mod, S, MODROW, st))) return rc;
+    patchify_rows_kernel<<<(S * NTOK * 32 + 255) / 256, 256, 0, st>>>(x, ws->x_in[0], S, h->conv_w, h->conv_b, h->patch_w,
+                                                                      h->patch_b, h->pos);
+    T2S_LAUNCH_CHECK();
+    for (int i = 0; i < NBLK; ++i) {
+        const int base = i * MODW;
+        // a1 = mod(LN1(x_in)); q,k,v = a1 Wqkv^T + b
+        if ((rc = gemm<128, 3, PRO_LNMOD, EPI_QKV>(ws->x_in[i], h->qkv_p[i], h->qkv_b[i], nullptr, M, 3 * D, st, ws->mod,
+                                                    base + 0 * D, base + 1 * D, ws->a1[i], nullptr, ws->q[i], ws->k[i], ws->v[i])))
+            return rc;
+        if ((rc = attn_plain_train_fwd(ws->q[i], ws->k[i], ws->v[i], ws->o[i], ws->lse[i], S * NH, st))) return rc;
+        if ((rc = gemm<128, 1, PRO_PLAIN, EPI_BIAS>(ws->o[i], h->proj_p[i], h->proj_b[i], ws->p[i], M, D, st))) return rc;
+        gate_res_kernel<<<(M * 32 + 255) / 256, 256, 0, st>>>(ws->x_in[i], ws->p[i], ws->mod, base + 2 * D, ws->x_mid[i], M);
+        T2S_LAUNCH_CHECK();
+        // a2 = mod(LN2(x_mid)); u = a2 W1^T + b1; f = gelu(u) W2^T + b2
+        if ((rc = gemm<128, 2, PRO_LNMOD, EPI_BIAS>(ws->x_mid[i], h->fc1_p[i], h->fc1_b[i], ws->u[i], M, 2 * D, st, ws->mod,
+                                                     base + 3 * D, base + 4 * D, ws->a2[i])))
+            return rc;
+        if ((rc = gemm<256, 1, PRO_GELU, EPI_BIAS>(ws->u[i], ws->fc2_f[i], h->fc2_b[i], ws->f[i], M, D, st))) return rc;
+        gate_res_kernel<<<(M * 32 + 255) / 256, 256, 0, st>>>(ws->x_mid[i], ws->f[i], ws->mod, base + 5 * D, ws->x_in[i + 1], M);
+        T2S_LAUNCH_CHECK();
+    }
+    final_rows_kernel<<<(M * 32 + 255) / 256, 256, 0, st>>>(ws->x_in[NBLK], S, h->ln_w, h->ln_b, h->out_w, h->out_b, out);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g, int B, void* stream) {
+    T2S_REQUIRE(h && dout && g, "t2s_dit_train_backward: NULL argument");
+    T2S_REQUIRE(h->train && h->train->S == B, "t2s_dit_train_backward: no matching t2s_dit_train_forward (B=%d)", B);
+    hipStream_t st = (hipStream_t)stream;
+    t2s_train_ws* ws = h->train;
+    const int S = B, M = S * NTOK;
+    int rc;
+    // ---- zero every gradient (the kernels accumulate with atomics)
+    struct Z { float* p; size_t n; };
+    std::vector<Z> zs = {{g->conv_w, 16}, {g->conv_b, 4}, {g->patch_w, 512}, {g->patch_b, 128}, {g->ln_w, 128},
+                         {g->ln_b, 128}, {g->out_w, 512}, {g->out_b, 4}};
+    for (int i = 0; i < NBLK; ++i) {
+        const t2s_dit_block_grads& b = g->blk[i];
+        zs.insert(zs.end(), {{b.qkv_w, 3 * D * D}, {b.qkv_b, 3 * D}, {b.proj_w, D * D}, {b.proj_b, D}, {b.fc1_w, 2 * D * D},
+                             {b.fc1_b, 2 * D}, {b.fc2_w, 2 * D * D}, {b.fc2_b, D}, {b.ada_w, MODW * D}, {b.ada_b, MODW}});
+    }
+    for (const Z& z : zs) {
+        T2S_REQUIRE(z.p, "t2s_dit_train_backward: NULL gradient pointer");
+        T2S_HIP_CHECK(hipMemsetAsync(z.p, 0, z.n * sizeof(float), st));
+    }
+    // ---- final layer
+    final_bwd_kernel<<<(M + 63) / 64, 256, 0, st>>>(ws->x_in[NBLK], dout, h->ln_w, h->ln_b, h->out_w, ws->dx, g->ln_w,
+                                                    g->ln_b, g->out_w, g->out_b, M);
+    T2S_LAUNCH_CHECK();
+    for (int i = NBLK - 1; i >= 0; --i) {
+        const int base = i * MODW;
+        const t2s_dit_block_grads& b = g->blk[i];
+        // ---- MLP branch: x_out = x_mid + g2 * f
+        gate_bwd_kernel<<<S, 256, 0, st>>>(ws->dx, ws->f[i], ws->mod, base + 5 * D, ws->t1, ws->dmod);      // t1 = df
+        T2S_LAUNCH_CHECK();
+        gelu_kernel<<<((size_t)M * 64 + 255) / 256, 256, 0, st>>>(ws->u[i], ws->t2a, (size_t)M * 64);        // t2a = gelu(u)
+        T2S_LAUNCH_CHECK();
+        if ((rc = wgrad(ws->t1, ws->t2a, b.fc2_w, M, D, 2 * D, st)) || (rc = colsum(ws->t1, b.fc2_b, M, D, st))) return rc;
+        // du = (df W2) * gelu'(u)      (dgrad = row GEMM on W2^T: out 256 <- in 128)
+        if ((rc = gemm<128, 2, PRO_PLAIN, EPI_GELUBWD>(ws->t1, ws->fc2_t[i], nullptr, ws->t2b, M, 2 * D, st, nullptr, 0, 0,
+                                                        nullptr, ws->u[i])))
+            return rc;
+        if ((rc = wgrad(ws->t2b, ws->a2[i], b.fc1_w, M, 2 * D, D, st)) || (rc = colsum(ws->t2b, b.fc1_b, M, 2 * D, st))) return rc;
+        // da2 = du W1 (out 128 <- in 256)
+        if ((rc = gemm<256, 1, PRO_PLAIN, EPI_BIAS>(ws->t2b, ws->fc1_t[i], nullptr, ws->t1, M, D, st))) return rc;
+        ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t1, ws->x_mid[i], ws->mod, base + 3 * D, base + 4 * D, ws->dx, ws->dmod);
+        T2S_LAUNCH_CHECK();
+        // ---- attention branch: x_mid = x_in + g1 * p
+        gate_bwd_kernel<<<S, 256, 0, st>>>(ws->dx, ws->p[i], ws->mod, base + 2 * D, ws->t1, ws->dmod);       // t1 = dp
+        T2S_LAUNCH_CHECK();
+        if ((rc = wgrad(ws->t1, ws->o[i], b.proj_w, M, D, D, st)) || (rc = colsum(ws->t1, b.proj_b, M, D, st))) return rc;
+        if ((rc = gemm<128, 1, PRO_PLAIN, EPI_BIAS>(ws->t1, ws->proj_t[i], nullptr, ws->t4, M, D, st))) return rc;   // do
+        if ((rc = attn_bwd(ws->q[i], ws->k[i], ws->v[i], ws->o[i], ws->t4, ws->lse[i], ws->dsum, ws->t3, S * NH, st))) return rc;
+        if ((rc = wgrad(ws->t3, ws->a1[i], b.qkv_w, M, 3 * D, D, st)) || (rc = colsum(ws->t3, b.qkv_b, M, 3 * D, st))) return rc;
+        // da1 = dqkv Wqkv (out 128 <- in 384)
+        if ((rc = gemm<384, 1, PRO_PLAIN, EPI_BIAS>(ws->t3, ws->qkv_t[i], nullptr, ws->t1, M, D, st))) return rc;
+        ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t1, ws->x_in[i], ws->mod, base + 0 * D, base + 1 * D, ws->dx, ws->dmod);
+        T2S_LAUNCH_CHECK();
+    }
+    // ---- patchify
+    patchify_bwd_kernel<<<(M + 63) / 64, 256, 0, st>>>(ws->dx, ws->lat, S, h->conv_w, h->conv_b, h->patch_w, g->patch_w,
+                                                       g->patch_b, g->conv_w, g->conv_b, M);
+    T2S_LAUNCH_CHECK();
+    // ---- adaLN linear: mod = silu(c) W_ada^T + b_ada  (per block rows [768 i, 768 i + 768) of the (3072,128) stack)
+    for (int i = 0; i < NBLK; ++i) {
+        // dmod block slice is strided (row stride MODROW): copy to a dense (S,768) temp first
+        T2S_HIP_CHECK(hipMemcpy2DAsync(ws->t1, MODW * sizeof(float), ws->dmod + i * MODW, MODROW * sizeof(float),
+                                       MODW * sizeof(float), S, hipMemcpyDeviceToDevice, st));
+        if ((rc = wgrad(ws->t1, ws->silu_c, g->blk[i].ada_w, S, MODW, D, st)) ||
+            (rc = colsum(ws->t1, g->blk[i].ada_b, S, MODW, st)))
+            return rc;
+    }
+    return T2S_OK;
+}
+
+int t2s_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, void* stream) {
+    T2S_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step > 0, "t2s_adamw_step: bad argument");
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2 = 1.0f - powf(beta2, (float)step);
+    adamw_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, (size_t)n, lr,
+                                                                                beta1, beta2, eps, weight_decay, bc1,
+                                                                                sqrtf(bc2));
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+int t2s_mse_backward(const float* a, const float* b, const float* grad_out, float* da, float* db, uint64_t n, void* stream) {
+    T2S_REQUIRE(a && b && grad_out && n > 0 && (da || db), "t2s_mse_backward: bad argument");
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (da) mse_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(a, b, grad_out, da, (size_t)n, 1.0f);
+    if (db) mse_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(a, b, grad_out, db, (size_t)n, -1.0f);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+}  // extern "C"

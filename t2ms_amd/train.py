@@ -1,11 +1,23 @@
-"""Training-side pieces of the T2S path (train.py:101-131): loss and, later, the DiT backward."""
+"""Training-side host glue of the T2S path (reference train.py:101-136): autograd bridge to the HIP
+training kernels, MSE loss, fused AdamW with torch-compatible state, flat-bucket gradient all-reduce.
+
+All arithmetic is in libt2s_hip.so (t2s_dit_train_forward/_backward, t2s_mse[_backward],
+t2s_adamw_step); torch provides the autograd graph, the optimizer/scheduler bookkeeping and
+torch.distributed (RCCL) for the one gradient all-reduce per step.
+"""
 from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
 
 import torch
 
 from . import _lib as L
 
+N_GRAD = 925592   # values that receive a gradient: DiT minus pos_embed minus unpatch.*
 
+
+# ---------------------------------------------------------------------------- loss
 def mse_loss(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """F.mse_loss(a, b) (DDPM.py:37-38, rectified_flow.py:13-16) via t2s_mse (deterministic order)."""
     if not (a.is_cuda and b.is_cuda):
@@ -34,10 +46,146 @@ class _MseFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        raise L.T2SError("mse backward: the training path (DiT backward kernels) is not built yet")
+        a, b = ctx.saved_tensors
+        ac, bc, gc = L.as_f32(a.detach()), L.as_f32(b.detach()), L.as_f32(g.detach()).reshape(1)
+        da = torch.empty_like(ac) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(bc) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(a.device):
+            L.check(L.lib().t2s_mse_backward(L.dev_ptr(ac), L.dev_ptr(bc), L.dev_ptr(gc), L.dev_ptr(da),
+                                             L.dev_ptr(db), ac.numel(), L.stream_ptr(a.device)), "t2s_mse_backward")
+        return da, db
+
+
+# ---------------------------------------------------------------------------- DiT forward/backward
+_GRAD_TOP = ("conv_w", "conv_b", "patch_w", "patch_b", None, "ln_w", "ln_b", "out_w", "out_b")   # None = pos_embed
+_GRAD_BLK = ("qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ada_w", "ada_b")
+
+
+class _DitTrainFn(torch.autograd.Function):
+    """pred = Transformer(input, t, text) with a hand-written backward (train.py:123-125)."""
+
+    @staticmethod
+    def forward(ctx, model, x, temb, text, *params):
+        dev = x.device
+        B = x.shape[0]
+        with torch.cuda.device(dev):
+            h = model.t2s_handle(dev, B)                    # refreshes the packed weights if they changed
+            w, keep, _ = model._weights_struct(dev)
+            out = torch.empty(B, L.LAT_C, L.LAT_W, device=dev, dtype=torch.float32)
+            L.check(L.lib().t2s_dit_train_forward(h, C.byref(w), L.dev_ptr(x, "input"), L.dev_ptr(temb), B,
+                                                  L.dev_ptr(text, "text_input"), L.dev_ptr(out), B,
+                                                  L.stream_ptr(dev)), "t2s_dit_train_forward")
+        ctx.model, ctx.B, ctx.keep = model, B, keep
+        ctx.param_shapes = [tuple(p.shape) for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        model, B = ctx.model, ctx.B
+        dev = dout.device
+        flat = torch.empty(N_GRAD, device=dev, dtype=torch.float32)
+        model.__dict__["_t2s_flat_grad"] = flat           # one bucket: what the DDP all-reduce sends
+        g = L.DitGrads()
+        grads, off = [], 0
+        names = list(_GRAD_TOP) + [None] * 0
+        for name, shp in zip(names, ctx.param_shapes[:9]):
+            if name is None:
+                grads.append(None)
+                continue
+            n = 1
+            for s in shp:
+                n *= s
+            view = flat[off:off + n].view(shp)
+            setattr(g, name, view.data_ptr())
+            grads.append(view)
+            off += n
+        for i in range(4):
+            for j, name in enumerate(_GRAD_BLK):
+                shp = ctx.param_shapes[9 + 10 * i + j]
+                n = 1
+                for s in shp:
+                    n *= s
+                view = flat[off:off + n].view(shp)
+                setattr(g.blk[i], name, view.data_ptr())
+                grads.append(view)
+                off += n
+        assert off == N_GRAD, off
+        d = L.as_f32(dout)
+        with torch.cuda.device(dev):
+            h = model.t2s_handle(dev, B)
+            L.check(L.lib().t2s_dit_train_backward(h, L.dev_ptr(d, "grad_output"), C.byref(g), B,
+                                                   L.stream_ptr(dev)), "t2s_dit_train_backward")
+        return (None, None, None, None) + tuple(grads)
 
 
 def dit_forward_autograd(model, input, t, text_input):
-    raise L.T2SError(
-        "Transformer.forward was called with autograd enabled, but the DiT backward kernels are not built "
-        "yet (SURVEY.md 8f rank 1).  Wrap sampling in torch.no_grad() (as infer.py:65 does).")
+    """Transformer.forward under autograd (called from the mirror's forward when grads are on)."""
+    if input.requires_grad:
+        raise L.T2SError("Transformer.forward: a gradient w.r.t. the latent input is not provided "
+                         "(train.py feeds a constant noised latent)")
+    dev = input.device
+    B = input.shape[0]
+    x = L.as_f32(input.detach())
+    tf = L.as_f32(t.to(dev))
+    if tf.shape != (B,):
+        raise L.T2SError(f"Transformer.forward: t must be ({B},), got {tuple(tf.shape)}")
+    text = None
+    if text_input is not None:
+        text = L.as_f32(text_input.detach())
+        if tuple(text.shape) != (B, L.D_MODEL):
+            raise L.T2SError(f"Transformer.forward: text_input must be ({B},128), got {tuple(text.shape)}")
+    temb = model.time_emb(tf)
+    return _DitTrainFn.apply(model, x, temb, text, *model._dit_tensors())
+
+
+# ---------------------------------------------------------------------------- optimizer
+class T2SAdamW(torch.optim.Optimizer):
+    """AdamW whose update runs in one fused HIP kernel per tensor (t2s_adamw_step).  Defaults and the
+    per-parameter state keys (step, exp_avg, exp_avg_sq) equal torch.optim.AdamW's, so
+    optimizer.state_dict() / load_state_dict() interchange with the reference's checkpoints
+    (train.py:37,44,94)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        lib = L.lib()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise L.T2SError("T2SAdamW: parameters must live on a GPU")
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                g = L.as_f32(p.grad)
+                with torch.cuda.device(p.device):
+                    L.check(lib.t2s_adamw_step(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
+                                               st["exp_avg_sq"].data_ptr(), p.numel(), float(group["lr"]),
+                                               float(b1), float(b2), float(group["eps"]),
+                                               float(group["weight_decay"]), int(st["step"].item()),
+                                               L.stream_ptr(p.device)), "t2s_adamw_step")
+                # the kernel wrote p in place behind autograd's back: bump the version counter so the
+                # mirror's packed-weight cache (keyed on data_ptr + _version) notices
+                torch.autograd.graph.increment_version(p)
+        return loss
+
+
+# ---------------------------------------------------------------------------- data parallel
+def allreduce_gradients(model, dist) -> Optional[torch.Tensor]:
+    """Average the DiT gradients over ranks with ONE all-reduce of the flat 3.7 MB bucket the backward
+    filled (latency-bound, a single bucket beats stock DDP's many).  No-op when
+    `dist` is None."""
+    flat = model.__dict__.get("_t2s_flat_grad")
+    if dist is None or flat is None:
+        return flat
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(dist.get_world_size())
+    return flat

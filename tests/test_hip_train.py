@@ -1,0 +1,137 @@
+"""Training path: DiT backward, MSE, fused AdamW against autograd through the
+CPU oracle and the reference-generated fixture tests/golden/train_step.npz.  Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import t2s_oracle as O
+from t2ms_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _model(dev, seed=2025):
+    from model.denoiser.transformer import Transformer
+    m = Transformer()
+    m.load_state_dict(synth.make_dit_state_dict(seed), strict=True)
+    return m.to(dev).train()
+
+
+def _oracle_grads(seed, x, t, text, target):
+    sd = {k: v.clone().requires_grad_(k != "pos_embed") for k, v in synth.make_dit_state_dict(seed).items()}
+    pred = O.dit_forward(sd, x, t, text)
+    loss = O.mse_loss(pred, target)
+    loss.backward()
+    return pred.detach(), loss.detach(), {k: v.grad for k, v in sd.items() if v.grad is not None}
+
+
+@pytest.mark.parametrize("with_text", [True, False])
+def test_backward_matches_oracle_autograd(dev, with_text):
+    B = 3
+    x = synth.make_latents(71, B)
+    t = torch.tensor([5, 50, 99])
+    text = synth.make_text_embeddings(71, B) if with_text else None
+    target = synth.make_latents(72, B)
+    pred_ref, loss_ref, g_ref = _oracle_grads(2025, x, t, text, target)
+    m = _model(dev)
+    from t2ms_amd.train import mse_loss
+    pred = m(input=x.to(dev), t=t.to(dev), text_input=None if text is None else text.to(dev))
+    assert float((pred.detach().cpu() - pred_ref).abs().max()) < 1e-4
+    loss = mse_loss(pred, target.to(dev))
+    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=1e-5)
+    loss.backward()
+    checked = 0
+    for name, p in m.named_parameters():
+        if name.startswith("unpatch") or name == "pos_embed":
+            assert p.grad is None
+            continue
+        ref = g_ref[name]
+        got = p.grad.detach().cpu()
+        scale = float(ref.abs().max()) + 1e-12
+        err = float((got - ref).abs().max())
+        assert err < 2e-4 * scale + 1e-9, (name, err, scale)
+        checked += 1
+    assert checked == 48
+
+
+def test_train_step_reference_fixture(golden_dir, dev):
+    """Fixture (9): loss and the 48 per-parameter gradient norms produced by the reference itself."""
+    g = np.load(os.path.join(golden_dir, "train_step.npz"))
+    from model.backbone.DDPM import DDPM
+    m = _model(dev)
+    d100 = DDPM(100, dev)
+    x1 = synth.make_latents(555, 4).to(dev)
+    tt = torch.tensor([3, 50, 77, 99], device=dev)
+    eps = synth.make_latents(556, 4).to(dev)
+    xt, _ = d100.q_sample(x1, tt, eps)
+    pred = m(input=xt, t=tt, text_input=synth.make_text_embeddings(555, 4).to(dev))
+    loss = d100.loss(pred, eps)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=2e-5)
+    n = 0
+    for name, p in m.named_parameters():
+        key = "gn_" + name.replace(".", "__")
+        if key in g.files:
+            np.testing.assert_allclose(p.grad.norm().item(), g[key], rtol=5e-4, atol=1e-7, err_msg=name)
+            n += 1
+    assert n == 48
+    got = m.layers[0].attn.qkv.weight.grad[::16, ::8].cpu().numpy()
+    np.testing.assert_allclose(got, g["grad_qkv0_sample"], atol=2e-6, rtol=2e-3)
+
+
+def test_fused_adamw_matches_torch(dev):
+    from t2ms_amd.train import T2SAdamW
+    rs = np.random.RandomState(4)
+    p0 = torch.from_numpy(rs.randn(1000).astype(np.float32))
+    pa = torch.nn.Parameter(p0.clone())
+    pb = torch.nn.Parameter(p0.clone().to(dev))
+    oa = torch.optim.AdamW([pa], lr=1e-2, weight_decay=0.1)
+    ob = T2SAdamW([pb], lr=1e-2, weight_decay=0.1)
+    for _ in range(5):
+        g = torch.from_numpy(rs.randn(1000).astype(np.float32))
+        pa.grad, pb.grad = g.clone(), g.clone().to(dev)
+        oa.step()
+        ob.step()
+    assert float((pb.detach().cpu() - pa.detach()).abs().max()) < 1e-6
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert set(sa["state"][0]) == set(sb["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    ob2 = T2SAdamW([pb], lr=1e-2, weight_decay=0.1)
+    ob2.load_state_dict(sb)          # round trip
+
+
+def test_few_training_steps_reduce_loss_and_refresh_weights(dev):
+    """train.py:101-127 in miniature: q_sample -> forward -> mse -> backward -> AdamW; the sampler's
+    packed weights follow the optimizer's in-place updates."""
+    from model.backbone.DDPM import DDPM
+    from t2ms_amd.train import T2SAdamW
+    m = _model(dev, seed=9)
+    opt = T2SAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3, weight_decay=0.0)
+    ddpm = DDPM(100, dev)
+    x1 = synth.make_latents(1, 8).to(dev) * 0.5
+    text = synth.make_text_embeddings(1, 8).to(dev)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    losses = []
+    for it in range(12):
+        t = torch.randint(0, 100, (8,), generator=g).to(dev)
+        eps = torch.randn(8, 64, 30, generator=g).to(dev)
+        xt, _ = ddpm.q_sample(x1, t, eps)
+        opt.zero_grad()
+        loss = ddpm.loss(m(input=xt, t=t, text_input=text), eps)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert np.isfinite(losses).all() and np.mean(losses[-3:]) < np.mean(losses[:3])
+    # inference forward after training uses the UPDATED weights (packed-weight cache invalidated)
+    with torch.no_grad():
+        y = m(input=x1, t=torch.zeros(8, dtype=torch.long, device=dev), text_input=text)
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        ref = O.dit_forward(sd, x1.cpu(), torch.zeros(8, dtype=torch.long), text.cpu())
+    assert float((y.cpu() - ref).abs().max()) < 1e-4
