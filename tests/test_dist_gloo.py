@@ -42,6 +42,13 @@ WORKER = textwrap.dedent("""
     assert t == 2.0, t
     full = tdist.gather_rows(d, local, total, rank, world)
     ftext = tdist.gather_rows(d, text, total, rank, world)
+    # the training all-reduce: ONE flat bucket, averaged (t2ms_amd.train.allreduce_gradients)
+    import types as _types
+    from t2ms_amd.train import allreduce_gradients, N_GRAD
+    fake = _types.SimpleNamespace()
+    fake.__dict__["_t2s_flat_grad"] = torch.full((N_GRAD,), float(rank + 1))
+    avg = allreduce_gradients(fake, d)
+    assert avg.numel() == 925592 and torch.all(avg == 1.5), avg[:4]
     if rank == 0:
         ref = torch.from_numpy(O.device_normal(2025, 3, 0, total))
         assert torch.equal(full, ref), "sharded draws differ from the single-process stream"

@@ -135,3 +135,29 @@ def test_few_training_steps_reduce_loss_and_refresh_weights(dev):
         sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
         ref = O.dit_forward(sd, x1.cpu(), torch.zeros(8, dtype=torch.long), text.cpu())
     assert float((y.cpu() - ref).abs().max()) < 1e-4
+
+
+def test_train_driver_checkpoint_and_resume(dev, tmp_path, monkeypatch):
+    """train.py drop-in: reference flags / path derivation / checkpoint dict (train.py:94,134-136,157),
+    mix-train over three lengths, then resume from the written checkpoint."""
+    import train as drv
+    monkeypatch.chdir(tmp_path)
+    save = str(tmp_path / "results")
+    argv = ["--dataset_name", "ETTh1", "--backbone", "ddpm", "--denoiser", "DiT", "--total_step", "100",
+            "--batch_size", "12", "--epochs", "2", "--save_path", save, "--synthetic", "16", "--random_init",
+            "--checkpoint_path", ""]
+    monkeypatch.setattr("sys.argv", ["train.py"] + argv)
+    args = drv.get_args(argv)
+    assert args.save_path.endswith(os.path.join("checkpoints", "ddpm_DiT_ETTh1")) and args.mix_train
+    losses = drv.train(args)
+    ck_path = os.path.join(args.save_path, "model_1.pth")
+    ck = torch.load(ck_path, map_location="cpu")
+    assert set(ck) == {"model", "optimizer", "epoch", "loss_list"} and ck["epoch"] == 1
+    assert len(ck["loss_list"]) == len(losses) > 0 and np.isfinite(losses).all()
+    assert sum(1 for k in ck["model"] if k.startswith("encoder.")) == 12 and "layers.3.mlp.fc2.weight" in ck["model"]
+    st = ck["optimizer"]["state"]
+    assert len(st) == 48 and set(next(iter(st.values()))) == {"step", "exp_avg", "exp_avg_sq"}
+    # resume for one more epoch
+    args2 = drv.get_args(argv[:-1] + [ck_path] + ["--epochs", "3"])
+    losses2 = drv.train(args2)
+    assert len(losses2) > len(losses)

@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Drop-in DiT training driver (reference train.py): same flags, optimizer / scheduler settings,
+checkpoint dict and paths -- with the step of train.py:103-127 on the HIP kernels and data
+parallelism over GPUs (one process per GPU, ONE flat-bucket RCCL all-reduce per step).
+
+    python train.py --dataset_name ETTh1 --backbone ddpm --denoiser DiT --checkpoint_path ""
+    python -m torch.distributed.run --nproc-per-node 8 train.py ...
+
+Kept from the reference: AdamW(lr 1e-4, weight_decay 0) + OneCycleLR(max_lr 1e-4, total_steps =
+len(loader) * epochs) stepped per outer batch (mix) / per epoch (split) (train.py:37-38,90,131);
+frozen LA-VAE encoder grafted as `model.encoder` (train.py:30-33); the 30 % per-batch
+classifier-free text drop drawn from the CPU generator (train.py:120-122); checkpoint
+dict(model, optimizer, epoch, loss_list) every 1000 epochs and at the end (train.py:132-136).
+Additions: `--synthetic N`, `--random_init`, `--seed`; under torchrun each rank trains on its
+slice of every batch and gradients are averaged.
+"""
+import argparse
+import os
+import sys
+import time
+import types
+
+import torch
+from torch.optim import lr_scheduler
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from datafactory.dataloader import loader_provider            # noqa: E402
+from model.backbone.DDPM import DDPM                          # noqa: E402
+from model.backbone.rectified_flow import RectifiedFlow      # noqa: E402
+from model.denoiser.transformer import Transformer            # noqa: E402
+from t2ms_amd import dist as tdist                            # noqa: E402
+from t2ms_amd import synth                                    # noqa: E402
+from t2ms_amd.train import T2SAdamW, allreduce_gradients      # noqa: E402
+
+
+def _load_vae(args, device):
+    if args.random_init:
+        from model.pretrained.vqvae import vqvae
+        vae = vqvae(types.SimpleNamespace(block_hidden_size=128, num_residual_layers=2, res_hidden_size=256,
+                                          embedding_dim=64))
+        vae.load_state_dict(synth.make_vae_state_dict(args.seed), strict=True)
+    else:
+        vae = torch.load(args.pretrained_model_path, map_location="cpu", weights_only=False)   # train.py:22
+    return vae.float().to(device).eval()
+
+
+def train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world):
+    """One optimisation step on this rank's slice of the batch (train.py:103-127 / 60-87)."""
+    lo, hi = tdist.shard_rows(x_1.shape[0], rank, world)
+    if hi == lo:
+        return None
+    emb = emb[lo:hi].float().to(device)
+    with torch.no_grad():
+        z, _ = model.encoder(x_1[lo:hi].float().to(device).contiguous())      # frozen LA-VAE (train.py:31-33,106)
+    n = z.shape[0]
+    if args.backbone == "flowmatching":
+        t = torch.round(torch.rand(n, device=device) * args.total_step) / args.total_step
+        x_t, x_0 = backbone.create_flow(z, t)
+        target = z - x_0
+    elif args.backbone == "ddpm":
+        t = torch.floor(torch.rand(n).to(device) * args.total_step).long()
+        target = torch.randn_like(z)
+        x_t, _ = backbone.q_sample(z, t, target)
+    else:
+        raise ValueError(f"Unsupported backbone type: {args.backbone}")
+    opt.zero_grad()
+    if bool(torch.rand(1) < 0.3):            # classifier-free guidance: drop the text for the whole batch
+        emb = None
+    pred = model(input=x_t, t=t, text_input=emb)
+    loss = backbone.loss(pred, target)
+    loss.backward()
+    allreduce_gradients(model, dist)
+    opt.step()
+    return loss
+
+
+def train(args):
+    device = torch.device(args.device)
+    rank, _, world = tdist.env_world()
+    dist = tdist.init("nccl", device)
+    if rank == 0:
+        print(f"Training config::\tepoch: {args.epochs}\tsave_path: {args.save_path}\tdevice: {args.device}\tGPUs: {world}")
+        os.makedirs(args.save_path, exist_ok=True)
+    torch.manual_seed(args.seed)              # identical shuffles / CFG coin on every rank (CPU generator)
+    torch.cuda.manual_seed(args.seed + 7919 * rank)   # ...but independent t / noise draws per rank (device generator)
+    dataset, dataloader = loader_provider(args, period="train")
+    model = {"DiT": Transformer}.get(args.denoiser)
+    if model is None:
+        raise ValueError("No denoiser found" if args.denoiser != "MLP" else
+                         "the MLP denoiser is config-1 plumbing (t2ms_amd.model.denoiser.mlp); train.py drives the DiT")
+    model = model()
+    if args.random_init:
+        sd = synth.make_dit_state_dict(args.seed)
+        model.load_state_dict(sd, strict=True)
+    model = model.to(device)
+    vae = _load_vae(args, device)
+    backbone = {"flowmatching": RectifiedFlow(), "ddpm": DDPM(args.total_step, args.device)}.get(args.backbone)
+    if backbone is None:
+        raise ValueError("No backbone found")
+    model.encoder = vae.encoder
+    for name, p in model.named_parameters():
+        if "encoder" in name:
+            p.requires_grad = not args.usepretrainedvae
+    if not args.usepretrainedvae:
+        raise ValueError("training the LA-VAE encoder jointly is outside the accelerated path (frozen codec)")
+    if rank == 0:
+        print(f"Total learnable parameters: {sum(p.numel() for p in model.parameters() if p.requires_grad)}")
+    opt = T2SAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.0)
+    sched = lr_scheduler.OneCycleLR(opt, max_lr=1e-4, total_steps=max(1, len(dataloader) * args.epochs))
+    loss_list, start_epoch = [], 0
+    if args.checkpoint_path:
+        ck = torch.load(args.checkpoint_path, map_location=device)
+        model.load_state_dict(ck["model"])
+        opt.load_state_dict(ck["optimizer"])
+        start_epoch, loss_list = ck["epoch"] + 1, ck["loss_list"]
+    model.train()
+    t0, seen = time.time(), 0
+    for epoch in range(start_epoch, args.epochs):
+        for batch, data in enumerate(dataloader):
+            groups = data if args.mix_train else [data]
+            for (_, x_1, emb) in groups:
+                loss = train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world)
+                if loss is None:
+                    continue
+                seen += x_1.shape[0]
+                loss_list.append(loss.item())
+                if batch % 100 == 0 and rank == 0:
+                    print(f"[Epoch {epoch}] [batch {batch}] loss: {loss_list[-1]:.6f}  "
+                          f"({seen / (time.time() - t0):.1f} samples/s)")
+            if args.mix_train:
+                sched.step()
+        if not args.mix_train:
+            sched.step()
+        if (epoch % 1000 == 0 or epoch == args.epochs - 1) and rank == 0:
+            print(f"Saving model {epoch} to {args.save_path}...")
+            torch.save(dict(model=model.state_dict(), optimizer=opt.state_dict(), epoch=epoch, loss_list=loss_list),
+                       os.path.join(args.save_path, f"model_{epoch}.pth"))
+    tdist.barrier(dist, device)
+    return loss_list
+
+
+def get_args(argv=None):
+    p = argparse.ArgumentParser(description="Train T2S model")
+    p.add_argument("--checkpoint_path", type=str,
+                   default="./results/denoiser_results/checkpoints/flowmatching_DiT_weather/model_6000.pth")
+    p.add_argument("--dataset_name", type=str, default="weather", help="dataset name")
+    p.add_argument("--batch_size", type=int, default=9216, help="batch_size")
+    p.add_argument("--epochs", type=int, default=20000, help="training epochs")
+    p.add_argument("--save_path", type=str, default="./results/denoiser_results", help="denoiser model save path")
+    p.add_argument("--mix_train", type=bool, default=True, help="mixture train or not")
+    p.add_argument("--usepretrainedvae", default=True, help="pretrained vae")
+    p.add_argument("--total_step", type=int, default=100, help="sampling from [0,1]")
+    p.add_argument("--backbone", type=str, default="flowmatching", help="flowmatching or ddpm or edm")
+    p.add_argument("--denoiser", type=str, default="DiT", help="DiT or MLP")
+    p.add_argument("--seed", type=int, default=2025)
+    p.add_argument("--synthetic", type=int, default=0, help="serve N synthetic rows per length instead of the CSVs")
+    p.add_argument("--random_init", action="store_true", help="seeded synthetic LA-VAE / DiT weights")
+    p.add_argument("--split_train", action="store_true", help="mix_train=False (argparse type=bool cannot be switched off)")
+    args = p.parse_args(argv)
+    if args.split_train:
+        args.mix_train = False
+    if not torch.cuda.is_available():
+        sys.exit("train.py: no GPU visible -- this build runs the HIP path only (no CPU fallback)")
+    _, local_rank, _ = tdist.env_world()
+    torch.cuda.set_device(local_rank)
+    args.device = f"cuda:{local_rank}"
+    if args.mix_train:
+        args.data_length = 0
+    root = args.dataset_name.split("_")[0]
+    args.pretrained_model_path = f"results/saved_pretrained_models/dataset{root}_epoch2000/final_model.pth"
+    args.save_path = os.path.join(args.save_path, "checkpoints",
+                                  "{}_{}_{}".format(args.backbone, args.denoiser, args.dataset_name))
+    return args
+
+
+if __name__ == "__main__":
+    a = get_args()
+    t_start = time.time()
+    train(a)
+    print(time.time() - t_start)
