@@ -191,18 +191,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ Y
     }
 }
 
-// dW[n][k] += sum_rows dY[row][n] * X[row][k]    (weight gradient, N % 32 == 0, K % 128 == 0)
-// A operand = dY^T, B operand = X: both straight from row-major global memory (lane = feature:
-// 128-B coalesced segments, two token rows per MFMA).  A wave owns one 32-wide n-tile x four
-// k-tiles; a workgroup covers `rows_per_wg` token rows and adds its partial tile with atomics.
+// dW[n][k] += sum_rows dY[row][n] * X[row][k]   and   db[n] += sum_rows dY[row][n]
+// (weight + bias gradient of a linear; N % 32 == 0, K % 128 == 0).
+// A operand = dY^T straight from row-major global memory (lane = output feature n: 128-B coalesced
+// segments, two token rows per MFMA); B operand = X rows, staged ONCE per workgroup in LDS
+// (64-row sub-slabs, coalesced float4) and shared by the 4 waves, which own different n-tiles of
+// the same 128-wide k-chunk.  Partial tiles are added to the gradient with fp32 atomics (full
+// 128-B rows per wave instruction).  The bias gradient falls out of the A operand for free.
+constexpr int WG_ROWS = 64;   // rows staged per LDS pass
 __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dY, const float* __restrict__ X,
-                                                    float* __restrict__ dW, int M, int N, int K, int rows_per_wg) {
+                                                    float* __restrict__ dW, float* __restrict__ db, int M, int N,
+                                                    int K, int rows_per_wg) {
+    __shared__ __attribute__((aligned(16))) float xs[WG_ROWS * 132];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5, j = lane & 31;
-    const int job = blockIdx.y * 4 + wave;          // (n-tile, k-chunk of 128)
     const int n_tiles = N >> 5;
-    if (job >= n_tiles * (K >> 7)) return;
-    const int nt = job % n_tiles, kc = job / n_tiles;
+    const int ngroups = (n_tiles + 3) >> 2;           // groups of 4 n-tiles (one per wave)
+    const int kc = blockIdx.y / ngroups;              // 128-wide k-chunk
+    const int nt = (blockIdx.y % ngroups) * 4 + wave; // this wave's n-tile (may be past the end)
+    const bool live = nt < n_tiles;
     const int r0 = blockIdx.x * rows_per_wg;
     const int r1 = min(M, r0 + rows_per_wg);
     f32x16 acc[4];
@@ -210,23 +217,40 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dY
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const float* ya = dY + nt * 32 + j;
-    const float* xb = X + kc * 128 + j;
-    for (int r = r0; r < r1; r += 2) {
-        const int row = r + half;
-        const bool ok = row < r1;
-        const float a = ok ? ya[(size_t)row * N] : 0.f;
-        float b[4];
+    float bsum = 0.f;
+    const float* ya = dY + (live ? nt * 32 + j : 0);
+    for (int rs = r0; rs < r1; rs += WG_ROWS) {
+        __syncthreads();   // previous sub-slab fully consumed
+        for (int idx = threadIdx.x; idx < WG_ROWS * 32; idx += 256) {
+            const int rr = idx >> 5, c4 = idx & 31;
+            const int row = rs + rr;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < r1) v = *reinterpret_cast<const f32x4*>(X + (size_t)row * K + kc * 128 + c4 * 4);
+            *reinterpret_cast<f32x4*>(xs + rr * 132 + c4 * 4) = v;
+        }
+        __syncthreads();
+        if (live) {
+#pragma unroll 4
+            for (int rr = 0; rr < WG_ROWS; rr += 2) {
+                const int row = rs + rr + half;
+                const float a = row < r1 ? ya[(size_t)row * N] : 0.f;
+                bsum += a;
+                const float* xb = xs + (rr + half) * 132 + j;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) b[t] = ok ? xb[(size_t)row * K + t * 32] : 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = mfma32(a, b[t], acc[t]);
+                for (int t = 0; t < 4; ++t) acc[t] = mfma32(a, xb[t * 32], acc[t]);
+            }
+        }
     }
+    if (!live) return;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             atomicAdd(dW + (size_t)(nt * 32 + acc_row(r, half)) * K + kc * 128 + t * 32 + j, acc[t][r]);
+    if (db != nullptr && kc == 0) {
+        bsum += xhalf(bsum);
+        if (half == 0) atomicAdd(db + nt * 32 + j, bsum);
+    }
 }
 
 // final layer backward (transformer.py:182-191): dout (S,64,30) -> dx (M,128) and grads of
@@ -585,11 +609,12 @@ int gemm(const float* A, const f32x4* Wp, const float* bias, float* out, int M, 
     return launch_gemm_rows<K, NT, PRO, EPI>(a, st);
 }
 
-int wgrad(const float* dY, const float* X, float* dW, int M, int N, int K, hipStream_t st) {
+// weight (and, if db != NULL, bias) gradient of a linear layer
+int wgrad(const float* dY, const float* X, float* dW, float* db, int M, int N, int K, hipStream_t st) {
     const int rows_per_wg = 1024;
-    const int jobs = (N / 32) * (K / 128);
-    dim3 grid((M + rows_per_wg - 1) / rows_per_wg, (jobs + 3) / 4);
-    wgrad_kernel<<<grid, 256, 0, st>>>(dY, X, dW, M, N, K, rows_per_wg);
+    const int ngroups = (N / 32 + 3) / 4;
+    dim3 grid((M + rows_per_wg - 1) / rows_per_wg, ngroups * (K / 128));
+    wgrad_kernel<<<grid, 256, 0, st>>>(dY, X, dW, db, M, N, K, rows_per_wg);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }
@@ -701,12 +726,12 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
         T2S_LAUNCH_CHECK();
         gelu_kernel<<<((size_t)M * 64 + 255) / 256, 256, 0, st>>>(ws->u[i], ws->t2a, (size_t)M * 64);        // t2a = gelu(u)
         T2S_LAUNCH_CHECK();
-        if ((rc = wgrad(ws->t1, ws->t2a, b.fc2_w, M, D, 2 * D, st)) || (rc = colsum(ws->t1, b.fc2_b, M, D, st))) return rc;
+        if ((rc = wgrad(ws->t1, ws->t2a, b.fc2_w, b.fc2_b, M, D, 2 * D, st))) return rc;
         // du = (df W2) * gelu'(u)      (dgrad = row GEMM on W2^T: out 256 <- in 128)
         if ((rc = gemm<128, 2, PRO_PLAIN, EPI_GELUBWD>(ws->t1, ws->fc2_t[i], nullptr, ws->t2b, M, 2 * D, st, nullptr, 0, 0,
                                                         nullptr, ws->u[i])))
             return rc;
-        if ((rc = wgrad(ws->t2b, ws->a2[i], b.fc1_w, M, 2 * D, D, st)) || (rc = colsum(ws->t2b, b.fc1_b, M, 2 * D, st))) return rc;
+        if ((rc = wgrad(ws->t2b, ws->a2[i], b.fc1_w, b.fc1_b, M, 2 * D, D, st))) return rc;
         // da2 = du W1 (out 128 <- in 256)
         if ((rc = gemm<256, 1, PRO_PLAIN, EPI_BIAS>(ws->t2b, ws->fc1_t[i], nullptr, ws->t1, M, D, st))) return rc;
         ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t1, ws->x_mid[i], ws->mod, base + 3 * D, base + 4 * D, ws->dx, ws->dmod);
@@ -714,10 +739,10 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
         // ---- attention branch: x_mid = x_in + g1 * p
         gate_bwd_kernel<<<S, 256, 0, st>>>(ws->dx, ws->p[i], ws->mod, base + 2 * D, ws->t1, ws->dmod);       // t1 = dp
         T2S_LAUNCH_CHECK();
-        if ((rc = wgrad(ws->t1, ws->o[i], b.proj_w, M, D, D, st)) || (rc = colsum(ws->t1, b.proj_b, M, D, st))) return rc;
+        if ((rc = wgrad(ws->t1, ws->o[i], b.proj_w, b.proj_b, M, D, D, st))) return rc;
         if ((rc = gemm<128, 1, PRO_PLAIN, EPI_BIAS>(ws->t1, ws->proj_t[i], nullptr, ws->t4, M, D, st))) return rc;   // do
         if ((rc = attn_bwd(ws->q[i], ws->k[i], ws->v[i], ws->o[i], ws->t4, ws->lse[i], ws->dsum, ws->t3, S * NH, st))) return rc;
-        if ((rc = wgrad(ws->t3, ws->a1[i], b.qkv_w, M, 3 * D, D, st)) || (rc = colsum(ws->t3, b.qkv_b, M, 3 * D, st))) return rc;
+        if ((rc = wgrad(ws->t3, ws->a1[i], b.qkv_w, b.qkv_b, M, 3 * D, D, st))) return rc;
         // da1 = dqkv Wqkv (out 128 <- in 384)
         if ((rc = gemm<384, 1, PRO_PLAIN, EPI_BIAS>(ws->t3, ws->qkv_t[i], nullptr, ws->t1, M, D, st))) return rc;
         ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t1, ws->x_in[i], ws->mod, base + 0 * D, base + 1 * D, ws->dx, ws->dmod);
@@ -732,9 +757,7 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
         // dmod block slice is strided (row stride MODROW): copy to a dense (S,768) temp first
         T2S_HIP_CHECK(hipMemcpy2DAsync(ws->t1, MODW * sizeof(float), ws->dmod + i * MODW, MODROW * sizeof(float),
                                        MODW * sizeof(float), S, hipMemcpyDeviceToDevice, st));
-        if ((rc = wgrad(ws->t1, ws->silu_c, g->blk[i].ada_w, S, MODW, D, st)) ||
-            (rc = colsum(ws->t1, g->blk[i].ada_b, S, MODW, st)))
-            return rc;
+        if ((rc = wgrad(ws->t1, ws->silu_c, g->blk[i].ada_w, g->blk[i].ada_b, S, MODW, D, st))) return rc;
     }
     return T2S_OK;
 }
