@@ -26,6 +26,7 @@
 // Per 32-token tile: 256 (proj) + 512 (fc1) + 512 (fc2) + 768 (qkv) MFMAs of 32x32x2.
 #pragma once
 #include "t2s_common.h"
+#include <stdlib.h>
 
 namespace t2s {
 
@@ -101,11 +102,22 @@ __device__ __forceinline__ void ln_modulate(const f32x16 (&x)[4], f32x16 (&y)[4]
         }
 }
 
+#if defined(T2S_EXP) && (T2S_EXP & 64)
+__device__ unsigned long long t2s_rows_dbg[8 * 8192];
+#define ROWS_STAMP(i) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); if (DO_MLP && DO_QKV) stamp[i] = _t; }
+#else
+#define ROWS_STAMP(i)
+#endif
+
 template <bool DO_MLP, bool DO_QKV>
 __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
     extern __shared__ __attribute__((aligned(16))) f32x4 wring[];  // [2][1024]
+#if defined(T2S_EXP) && (T2S_EXP & 64)
+    unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    ROWS_STAMP(0)
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: scalar addressing
     const int half = lane >> 5;
     const int n_tiles = a.M >> 5;
     int tile = blockIdx.x * 4 + wave;             // 32-token tile of this wave
@@ -183,6 +195,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
                 for (int e = 0; e < 4; ++e) bop[G >> 2][4 * (G & 3) + e] = t[e];
             }
             __syncthreads();  // chunk 0 landed (vmcnt(0) + barrier)
+            ROWS_STAMP(1)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 fill(ci + 1);
@@ -207,6 +220,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
                 ++ci;
             }
         }
+        ROWS_STAMP(2)
         // ---------------- x += gate_mlp * (fc2(gelu(fc1(mod(LN(x))))) + b2) ----------------
         f32x4* xw = reinterpret_cast<f32x4*>(a.x) + (size_t)tile * 16 * 64 + lane;
         {
@@ -228,6 +242,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+            ROWS_STAMP(3)
 #pragma unroll 1
             for (int c = 0; c < 8; ++c) {  // 32 hidden units per chunk; ci = 4 + 2c (even) here
                 fill(ci + 1);
@@ -287,9 +302,11 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
         __syncthreads();  // chunk 0 landed
     }
 
+    ROWS_STAMP(4)
     if constexpr (DO_QKV) {
         f32x16 xm[4];
         ln_modulate(x, xm, cm + 768, cm + 768 + D, half, 1e-6f);
+        ROWS_STAMP(5)
         const int tile_in_seq = tile - seq * (NTOK / 32);
 #pragma unroll 1
         for (int t = 0; t < 12; ++t) {  // output tile t = which*4 + head
@@ -366,6 +383,15 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
             ++ci;
         }
     }
+    ROWS_STAMP(6)
+#if defined(T2S_EXP) && (T2S_EXP & 64)
+    if (DO_MLP && DO_QKV && lane == 0 && blockIdx.x < 2048) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp[7] = __builtin_amdgcn_s_memtime();
+        unsigned long long* d = t2s_rows_dbg + (size_t)(blockIdx.x * 4 + wave) * 8;
+        for (int i = 0; i < 8; ++i) d[i] = stamp[i];
+    }
+#endif
 }
 
 template <bool DO_MLP, bool DO_QKV>
@@ -375,7 +401,9 @@ inline int launch_dit_rows(const RowArgs& a, hipStream_t st) {
         return T2S_E_INVALID;
     }
     const int tiles = a.M / 32;
-    dit_rows_kernel<DO_MLP, DO_QKV><<<(tiles + 3) / 4, 256, ROWS_LDS_BYTES, st>>>(a);
+    static const int extra_lds = getenv("T2S_ROWS_EXTRA_LDS") ? atoi(getenv("T2S_ROWS_EXTRA_LDS")) : 0;  // diagnostic: force fewer workgroups per CU
+    if (extra_lds > 0) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dit_rows_kernel<DO_MLP, DO_QKV>), hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_LDS_BYTES + extra_lds);
+    dit_rows_kernel<DO_MLP, DO_QKV><<<(tiles + 3) / 4, 256, ROWS_LDS_BYTES + extra_lds, st>>>(a);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }
