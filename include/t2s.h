@@ -149,7 +149,15 @@ typedef struct t2s_dit_grads { /* every tensor that receives a gradient (925,592
     t2s_dit_block_grads blk[T2S_N_BLOCKS];
 } t2s_dit_grads;
 
-/* Transformer.forward that keeps the activations for a following backward (fp32, plain layouts).
+/* Arithmetic of the training path.  T2S_TRAIN_F32 (default): fp32 end to end, gradients equal
+ * autograd through the fp32 reference to ~1e-6 relative.  T2S_TRAIN_BF16 (BASELINE config 4,
+ * "train.py bf16"): every contraction on bf16 MFMA with fp32 accumulation, saved activations in
+ * bf16; master weights, residual stream, LayerNorm / softmax statistics, gradients and the
+ * optimizer stay fp32.  Takes effect at the next t2s_dit_train_forward. */
+#define T2S_TRAIN_F32 0
+#define T2S_TRAIN_BF16 1
+int t2s_dit_set_train_dtype(t2s_dit* h, int dtype);
+/* Transformer.forward that keeps the activations for a following backward (plain layouts).
  * `w` are the caller's CURRENT weights (call t2s_dit_update_weights first if they changed since
  * the handle was created/updated); arguments otherwise as t2s_dit_forward.  Allocates its
  * workspace on first use (not capturable). */

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libt2s_hip.so")
 N_BLOCKS = 4
 LAT_C, LAT_W, LAT = 64, 30, 1920
 D_MODEL, N_TOK = 128, 480
+TRAIN_F32, TRAIN_BF16 = 0, 1   # t2s.h: T2S_TRAIN_F32 / T2S_TRAIN_BF16
 
 c_float_p = C.c_void_p  # device pointers travel as opaque addresses
 
@@ -79,6 +80,7 @@ SYMBOLS = {
     "t2s_dit_read_stream": (_I, [_VP, _VP, _I, _VP]),
     "t2s_dit_timing_begin": (_I, [_VP]),
     "t2s_dit_timing_end": (_I, [_VP, C.POINTER(C.c_double)]),
+    "t2s_dit_set_train_dtype": (_I, [_VP, _I]),
     "t2s_dit_train_forward": (_I, [_VP, C.POINTER(DitWeights), _VP, _VP, _I, _VP, _VP, _I, _VP]),
     "t2s_dit_train_backward": (_I, [_VP, _VP, C.POINTER(DitGrads), _I, _VP]),
     "t2s_adamw_step": (_I, [_VP, _VP, _VP, _VP, _U64, _F, _F, _F, _F, _F, _I, _VP]),

@@ -1,0 +1,289 @@
+// Attention of the bf16 TRAINING path: forward with log-sum-exp and the flash-style backward, all
+// contractions on v_mfma_f32_32x32x16_bf16 (fp32 accumulate), softmax statistics in fp32.
+// Same mathematics as t2s_attn_bwd.hip (timm 1.0.11 Attention core; reference call site
+// model/denoiser/transformer.py:116 under autograd, train.py:123-125).
+//
+// q, k, v: bf16 (BH, 480, 32), bh = seq*4 + head.  o, do: bf16 token rows (S*480, 128), head h at
+// columns 32h..32h+31.  dqkv: bf16 token rows (S*480, 384) = [dq | dk | dv] x heads.  lse: fp32
+// (BH, 480) in the log2 domain of the scaled scores.
+//
+// One workgroup (8 waves) per (sequence, head); two whole (480 x 32) operands live in LDS as bf16
+// "images" with 64-byte rows whose 16-byte chunks are XOR-swizzled by (row>>2)&3.  That one image
+// serves both kinds of read without bank conflicts:
+//   row read  (ds_read_b128)        -> MFMA operand with the image ROW on the lane     (K, Q, dO, V)
+//   col read  (ds_read_b64_tr_b16)  -> MFMA operand with the image COLUMN on the lane  (K^T, V^T, Q^T, dO^T)
+// The 32x32 score tile never leaves registers: the fp32 accumulator, converted pairwise to bf16,
+// is the next MFMA's operand (acc_frag; its permuted k order is matched by the column reads).
+#include "t2s_bf16.h"
+
+namespace t2s {
+
+namespace {
+constexpr int NKB = NTOK / 32;                 // 15 tiles of 32 tokens
+constexpr int IMG = NTOK * 64;                 // bytes of one (480 x 32) bf16 image
+constexpr float SCALE = 0.17677669529663687f;  // 32^-0.5
+constexpr float QS = SCALE * 1.4426950408889634f;
+
+__device__ __forceinline__ int img_off(int row, int chunk) { return row * 64 + 16 * (chunk ^ ((row >> 2) & 3)); }
+
+__device__ __forceinline__ float pair_max_f(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float pair_sum_f(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// stage 480 rows of 32 bf16 (64 B, src row stride in elements) into a swizzled image
+__device__ __forceinline__ void stage_img(char* img, const __bf16* src, int src_stride, int tid, int nthreads) {
+    for (int idx = tid; idx < NTOK * 4; idx += nthreads) {
+        const int row = idx >> 2, c = idx & 3;
+        *reinterpret_cast<bf16x8*>(img + img_off(row, c)) = *reinterpret_cast<const bf16x8*>(src + (size_t)row * src_stride + c * 8);
+    }
+}
+
+// operand with the image row (token base + lane&31) on the lane: k = feature 16s + 8h + 0..7
+__device__ __forceinline__ bf16x8 row_frag(const char* img, int base, int lane, int s) {
+    return *reinterpret_cast<const bf16x8*>(img + img_off(base + (lane & 31), 2 * s + (lane >> 5)));
+}
+
+// operand with the image column (feature lane&31) on the lane: k = token base + 16s + 8(j>>2) + 4h + (j&3)
+__device__ __forceinline__ bf16x8 col_frag(const char* img, int base, int lane, int s) {
+    const int grp = (lane >> 4) & 3, dhalf = grp & 1, h = grp >> 1, q = (lane & 15) >> 2, p = lane & 3;
+    const int row = base + 16 * s + 4 * h + q;                 // (row >> 2) & 3 is the same for the 4 rows of the block
+    const int chunk = 2 * dhalf + (p >> 1);
+    const char* a0 = img + img_off(row, chunk) + 8 * (p & 1);
+    const char* a1 = img + img_off(row + 8, chunk) + 8 * (p & 1);
+    return join_tr(lds_tr16(a0), lds_tr16(a1));
+}
+}  // namespace
+
+// ------------------------------------------------------------------ forward with lse
+__global__ __launch_bounds__(512) void attn16_fwd_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
+                                                         const __bf16* __restrict__ v, __bf16* __restrict__ o_rows,
+                                                         float* __restrict__ lse) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
+    char* Ks = smem;
+    char* Vs = smem + IMG;
+    const int bh = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, half = lane >> 5, i = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int seq = bh / NH, head = bh % NH;
+    stage_img(Ks, k + (size_t)bh * NTOK * DH, DH, tid, 512);
+    stage_img(Vs, v + (size_t)bh * NTOK * DH, DH, tid, 512);
+    __syncthreads();
+    const __bf16* qg = q + (size_t)bh * NTOK * DH;
+    for (int qt = wave; qt < NKB; qt += 8) {
+        const int tok = qt * 32 + i;
+        bf16x8 qf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qg + (size_t)tok * DH + 16 * s + 8 * half);
+        f32x16 ot;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[r] = 0.f;
+        float m_run = -INFINITY, l_lane = 0.f;
+        for (int jb = 0; jb < NKB; ++jb) {
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) st = mfma16(row_frag(Ks, jb * 32, lane, s), qf[s], st);   // S^T[key][query], raw
+            float mloc = st[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[r]);
+            mloc = pair_max_f(mloc);
+            const float m_new = fmaxf(m_run, mloc);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * QS);
+            m_run = m_new;
+            const float mq = m_new * QS;
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[r] = __builtin_amdgcn_exp2f(st[r] * QS - mq);
+                ps += st[r];
+                ot[r] *= alpha;
+            }
+            l_lane = l_lane * alpha + ps;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) ot = mfma16(col_frag(Vs, jb * 32, lane, s), acc_frag(st, s), ot);   // O^T += V^T P^T
+        }
+        const float l_tot = pair_sum_f(l_lane);
+        const float inv = 1.0f / l_tot;
+        __bf16* orow = o_rows + ((size_t)seq * NTOK + tok) * D + head * DH + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 w = {ot[4 * g] * inv, ot[4 * g + 1] * inv, ot[4 * g + 2] * inv, ot[4 * g + 3] * inv};
+            *reinterpret_cast<bf16x4*>(orow + 8 * g) = pack4(w);
+        }
+        if (half == 0) lse[(size_t)bh * NTOK + tok] = m_run * QS + __builtin_amdgcn_logf(l_tot);   // v_log_f32 = log2
+    }
+}
+
+// ------------------------------------------------------------------ D_i = sum_d dO[i][d] * O[i][d]
+__global__ __launch_bounds__(256) void attn16_dsum_kernel(const __bf16* __restrict__ o_rows, const __bf16* __restrict__ do_rows,
+                                                          float* __restrict__ dsum, int M) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (token row, head): 32 bf16 = 64 B
+    if (idx >= M * NH) return;
+    const int row = idx >> 2, head = idx & 3;
+    const bf16x8* a = reinterpret_cast<const bf16x8*>(o_rows + (size_t)row * D + head * DH);
+    const bf16x8* b = reinterpret_cast<const bf16x8*>(do_rows + (size_t)row * D + head * DH);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const f32x8 x = unpack8(a[c]), y = unpack8(b[c]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += x[e] * y[e];
+    }
+    const int seq = row / NTOK, tok = row - seq * NTOK;
+    dsum[((size_t)seq * NH + head) * NTOK + tok] = s;
+}
+
+// ------------------------------------------------------------------ kernel A: dQ (queries on lanes)
+__global__ __launch_bounds__(512) void attn16_bwd_dq_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
+                                                            const __bf16* __restrict__ v, const __bf16* __restrict__ do_rows,
+                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                            __bf16* __restrict__ dqkv) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
+    char* Ks = smem;
+    char* Vs = smem + IMG;
+    const int bh = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, half = lane >> 5, i = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int seq = bh / NH, head = bh % NH;
+    stage_img(Ks, k + (size_t)bh * NTOK * DH, DH, tid, 512);
+    stage_img(Vs, v + (size_t)bh * NTOK * DH, DH, tid, 512);
+    __syncthreads();
+    const __bf16* qg = q + (size_t)bh * NTOK * DH;
+    for (int qt = wave; qt < NKB; qt += 8) {
+        const int tok = qt * 32 + i;
+        const __bf16* dorow = do_rows + ((size_t)seq * NTOK + tok) * D + head * DH + 8 * half;
+        bf16x8 qf[2], dof[2];   // B operands: Q^T and dO^T of this lane's query
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            qf[s] = *reinterpret_cast<const bf16x8*>(qg + (size_t)tok * DH + 16 * s + 8 * half);
+            dof[s] = *reinterpret_cast<const bf16x8*>(dorow + 16 * s);
+        }
+        const float lse_i = lse[(size_t)bh * NTOK + tok];
+        const float d_i = dsum[(size_t)bh * NTOK + tok];
+        f32x16 dq;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+        for (int jb = 0; jb < NKB; ++jb) {
+            f32x16 st, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = dp[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                st = mfma16(row_frag(Ks, jb * 32, lane, s), qf[s], st);     // S^T[key][query], raw
+                dp = mfma16(row_frag(Vs, jb * 32, lane, s), dof[s], dp);    // dP^T[key][query] = V dO^T
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(st[r] * QS - lse_i);
+                st[r] = p * (dp[r] - d_i);                                   // dS^T
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) dq = mfma16(col_frag(Ks, jb * 32, lane, s), acc_frag(st, s), dq);   // dQ^T += K^T dS^T
+        }
+        __bf16* dst = dqkv + ((size_t)seq * NTOK + tok) * (3 * D) + head * DH + 4 * half;   // dq block
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 w = {dq[4 * g] * SCALE, dq[4 * g + 1] * SCALE, dq[4 * g + 2] * SCALE, dq[4 * g + 3] * SCALE};
+            *reinterpret_cast<bf16x4*>(dst + 8 * g) = pack4(w);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ kernel B: dK, dV (keys on lanes)
+__global__ __launch_bounds__(512) void attn16_bwd_dkv_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
+                                                             const __bf16* __restrict__ v, const __bf16* __restrict__ do_rows,
+                                                             const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                             __bf16* __restrict__ dqkv) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * IMG + 2 * NTOK * 4];
+    char* Qs = smem;                                              // Q image
+    char* Os = smem + IMG;                                        // dO image (this head)
+    float* Ls = reinterpret_cast<float*>(smem + 2 * IMG);         // lse (log2 domain)
+    float* Ds = Ls + NTOK;                                        // D_i
+    const int bh = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, half = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int seq = bh / NH, head = bh % NH;
+    stage_img(Qs, q + (size_t)bh * NTOK * DH, DH, tid, 512);
+    stage_img(Os, do_rows + (size_t)seq * NTOK * D + head * DH, D, tid, 512);
+    for (int t = tid; t < NTOK; t += 512) {
+        Ls[t] = lse[(size_t)bh * NTOK + t];
+        Ds[t] = dsum[(size_t)bh * NTOK + t];
+    }
+    __syncthreads();
+    const __bf16* kg = k + (size_t)bh * NTOK * DH;
+    const __bf16* vg = v + (size_t)bh * NTOK * DH;
+    for (int kb = wave; kb < NKB; kb += 8) {
+        const int key = kb * 32 + j;
+        bf16x8 kf[2], vf[2];   // B operands: K^T and V^T of this lane's key
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            kf[s] = *reinterpret_cast<const bf16x8*>(kg + (size_t)key * DH + 16 * s + 8 * half);
+            vf[s] = *reinterpret_cast<const bf16x8*>(vg + (size_t)key * DH + 16 * s + 8 * half);
+        }
+        f32x16 dk, dv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk[r] = dv[r] = 0.f;
+        for (int qb = 0; qb < NKB; ++qb) {
+            f32x16 sc, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = dp[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                sc = mfma16(row_frag(Qs, qb * 32, lane, s), kf[s], sc);    // S[query][key], raw (registers = queries)
+                dp = mfma16(row_frag(Os, qb * 32, lane, s), vf[s], dp);    // dP[query][key] = dO V^T
+            }
+            // per-register query statistics: queries 8g + 4 half + 0..3 of this block
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qb * 32 + 8 * g + 4 * half);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ds + qb * 32 + 8 * g + 4 * half);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const float p = __builtin_amdgcn_exp2f(sc[r] * QS - l4[e]);
+                    dp[r] = p * (dp[r] - d4[e]);   // dS[query][key]
+                    sc[r] = p;                     // P[query][key]
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                dv = mfma16(col_frag(Os, qb * 32, lane, s), acc_frag(sc, s), dv);   // dV^T += dO^T P
+                dk = mfma16(col_frag(Qs, qb * 32, lane, s), acc_frag(dp, s), dk);   // dK^T += Q^T dS
+            }
+        }
+        __bf16* dst = dqkv + ((size_t)seq * NTOK + key) * (3 * D) + head * DH + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 wk = {dk[4 * g] * SCALE, dk[4 * g + 1] * SCALE, dk[4 * g + 2] * SCALE, dk[4 * g + 3] * SCALE};
+            const f32x4 wv = {dv[4 * g], dv[4 * g + 1], dv[4 * g + 2], dv[4 * g + 3]};
+            *reinterpret_cast<bf16x4*>(dst + D + 8 * g) = pack4(wk);
+            *reinterpret_cast<bf16x4*>(dst + 2 * D + 8 * g) = pack4(wv);
+        }
+    }
+}
+
+int attn16_train_fwd(const __bf16* q, const __bf16* k, const __bf16* v, __bf16* o_rows, float* lse, int BH, hipStream_t st) {
+    attn16_fwd_kernel<<<BH, 512, 0, st>>>(q, k, v, o_rows, lse);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+int attn16_bwd(const __bf16* q, const __bf16* k, const __bf16* v, const __bf16* o_rows, const __bf16* do_rows,
+               const float* lse, float* dsum, __bf16* dqkv_rows, int BH, hipStream_t st) {
+    const int M = (BH / NH) * NTOK;
+    attn16_dsum_kernel<<<(M * NH + 255) / 256, 256, 0, st>>>(o_rows, do_rows, dsum, M);
+    T2S_LAUNCH_CHECK();
+    attn16_bwd_dq_kernel<<<BH, 512, 0, st>>>(q, k, v, do_rows, lse, dsum, dqkv_rows);
+    T2S_LAUNCH_CHECK();
+    attn16_bwd_dkv_kernel<<<BH, 512, 0, st>>>(q, k, v, do_rows, lse, dsum, dqkv_rows);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+}  // namespace t2s

@@ -1,0 +1,298 @@
+// bf16-operand building blocks of the mixed-precision TRAINING path (BASELINE config 4:
+// "DiT training (train.py) bf16"): v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fp32 master
+// weights / residual stream / LayerNorm and softmax statistics / gradients, bf16 saved activations.
+//
+//   bgemm_kernel   out^T tile = W . A^T      tokens on the lanes (32 per wave), weights pre-packed
+//                                            as the A operand; prologues LN+modulate / GELU,
+//                                            epilogues bf16 rows / q,k,v heads / gelu-backward
+//   wgrad16_kernel dW = dY^T X, db = colsum  contraction over token rows; both operands read
+//                                            column-wise from row-major LDS tiles with
+//                                            ds_read_b64_tr_b16; bias gradient from a ones-MFMA
+//
+// With bf16 MFMA 16x faster than the fp32 form every kernel of the step is HBM-bound, so the
+// design rules here are bytes and coalescing, not MFMA occupancy: each activation is written once
+// as bf16 rows, read as 16-B lane fragments, and the waves of a workgroup are fully independent
+// (no LDS, no barrier) in bgemm.
+#pragma once
+#include "t2s_gemm.h"
+
+namespace t2s {
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// D(32x32) += A(32x16) * B(16x32); lane l (i = l&31, h = l>>5) supplies A[i][8h + j] and
+// B[8h + j][i], j = 0..7; the result layout equals the fp32 form's (t2s_common.h: acc_row).
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ bf16x4 pack4(f32x4 v) { return __builtin_convertvector(v, bf16x4); }
+__device__ __forceinline__ f32x4 unpack4(bf16x4 v) { return __builtin_convertvector(v, f32x4); }
+__device__ __forceinline__ bf16x8 pack8(f32x4 lo, f32x4 hi) {
+    const f32x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return __builtin_convertvector(v, bf16x8);
+}
+__device__ __forceinline__ f32x8 unpack8(bf16x8 v) { return __builtin_convertvector(v, f32x8); }
+
+// Registers 8s..8s+7 of a 32x32 accumulator as the operand of k-step s of a following MFMA that
+// sums over the accumulator's ROW index.  Element j of lane half h is row 16s + 8(j>>2) + 4h + (j&3)
+// ("permuted k order"): the other operand must use the same order (tr_frag below does).
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& c, int s) {
+    const f32x8 v = {c[8 * s + 0], c[8 * s + 1], c[8 * s + 2], c[8 * s + 3],
+                     c[8 * s + 4], c[8 * s + 5], c[8 * s + 6], c[8 * s + 7]};
+    return __builtin_convertvector(v, bf16x8);
+}
+
+// ds_read_b64_tr_b16: per group of 16 lanes a block of 4 rows x 16 columns of 16-bit elements is
+// read from LDS and delivered column-major: lane 4q+p of the group supplies the address of row q,
+// columns 4p..4p+3 (8 bytes, 8-byte aligned); lane i of the group receives column i, row q in
+// element q.  EXEC must be all ones.
+__device__ __forceinline__ s16x4 lds_tr16(const void* lds_addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_addr));
+}
+__device__ __forceinline__ bf16x8 join_tr(s16x4 lo, s16x4 hi) {
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// A-operand packing of a linear weight W (N,K) row-major (the GEMM is x @ W^T): n-tile nt (32
+// outputs), k-step s (16 inputs): lane l = 32h + (n & 31) owns the 8 bf16 W[n][16s + 8h + 0..7],
+// stored at packed[(nt * (K/16) + s) * 64 + l] -> one wave-level load = 1 KiB contiguous.
+__host__ __device__ inline size_t packed16_index(int n, int k, int K) {
+    const int nt = n >> 5, i = n & 31, s = k >> 4, h = (k >> 3) & 1, j = k & 7;
+    return ((((size_t)nt * (K >> 4) + s) * 64) + (h * 32 + i)) * 8 + j;
+}
+
+// W fp32 (N,K) -> packed16 of W (transpose = 0) or of W^T, a (K,N) weight (transpose = 1)
+static __global__ void pack16_kernel(const float* __restrict__ W, __bf16* __restrict__ P, int N, int K, int transpose) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * K) return;
+    const int n = idx / K, k = idx - n * K;
+    const size_t dst = transpose ? packed16_index(k, n, N) : packed16_index(n, k, K);
+    P[dst] = (__bf16)W[idx];
+}
+
+// ------------------------------------------------------------------------------------------ bgemm
+enum { BPRO_BF16 = 0, BPRO_LN = 1, BPRO_GELU = 2 };
+enum { BEPI_BF16 = 0, BEPI_QKV = 1, BEPI_GELUBWD = 2 };
+
+struct BGemmArgs {
+    const void* A;        // BPRO_LN: float (M,128) residual stream; otherwise bf16 (M,K)
+    const bf16x8* Wp;     // packed16 weights (N/32, K/16, 64)
+    const float* bias;    // (N) or NULL
+    __bf16* out;          // BEPI_BF16 / BEPI_GELUBWD: (M,N)
+    int M;                // rows, a multiple of 32
+    int N;                // outputs, a multiple of 32
+    const float* mod;     // BPRO_LN: (S, MODROW) adaLN table
+    int shift_off;
+    int scale_off;
+    __bf16* save_A;       // optional (M,K): the prologue-transformed rows (saved for the weight gradient)
+    const __bf16* aux;    // BEPI_GELUBWD: pre-activation u (M,N); out = acc * gelu'(u)
+    __bf16* q;            // BEPI_QKV destinations, each (S*4, 480, 32)
+    __bf16* k;
+    __bf16* v;
+};
+
+template <int K, int PRO, int EPI>
+__global__ __launch_bounds__(256) void bgemm_kernel(const BGemmArgs a) {
+    constexpr int KS = K / 16;
+    static_assert(PRO != BPRO_LN || K == 128, "LayerNorm prologue is over d_model = 128");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x * 4 + wave;        // 32-token tile of this wave (never straddles a sequence)
+    if (tile * 32 >= a.M) return;
+    const int h = lane >> 5, i = lane & 31;
+    const size_t row = (size_t)tile * 32 + i;
+
+    // ---- B operand: this lane's token, k = 16s + 8h + 0..7
+    bf16x8 xf[KS];
+    if constexpr (PRO == BPRO_LN) {
+        const float* xr = reinterpret_cast<const float*>(a.A) + row * K + 8 * h;
+        f32x4 v[KS][2];
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            v[t][0] = *reinterpret_cast<const f32x4*>(xr + 16 * t);
+            v[t][1] = *reinterpret_cast<const f32x4*>(xr + 16 * t + 4);
+            s += ((v[t][0].x + v[t][0].y) + (v[t][0].z + v[t][0].w)) + ((v[t][1].x + v[t][1].y) + (v[t][1].z + v[t][1].w));
+        }
+        s += xhalf(s);
+        const float mean = s * (1.0f / 128.0f);
+        float ss = 0.f;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            v[t][0] -= mean;
+            v[t][1] -= mean;
+            ss += ((v[t][0].x * v[t][0].x + v[t][0].y * v[t][0].y) + (v[t][0].z * v[t][0].z + v[t][0].w * v[t][0].w)) +
+                  ((v[t][1].x * v[t][1].x + v[t][1].y * v[t][1].y) + (v[t][1].z * v[t][1].z + v[t][1].w * v[t][1].w));
+        }
+        ss += xhalf(ss);
+        const float rstd = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+        const int seq = tile / (NTOK / 32);
+        const float* mrow = a.mod + (size_t)seq * MODROW + 8 * h;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            const f32x4 sc0 = *reinterpret_cast<const f32x4*>(mrow + a.scale_off + 16 * t);
+            const f32x4 sc1 = *reinterpret_cast<const f32x4*>(mrow + a.scale_off + 16 * t + 4);
+            const f32x4 sh0 = *reinterpret_cast<const f32x4*>(mrow + a.shift_off + 16 * t);
+            const f32x4 sh1 = *reinterpret_cast<const f32x4*>(mrow + a.shift_off + 16 * t + 4);
+            xf[t] = pack8((v[t][0] * rstd) * (1.0f + sc0) + sh0, (v[t][1] * rstd) * (1.0f + sc1) + sh1);
+            if (a.save_A != nullptr) *reinterpret_cast<bf16x8*>(a.save_A + row * K + 16 * t + 8 * h) = xf[t];
+        }
+    } else {
+        const __bf16* ar = reinterpret_cast<const __bf16*>(a.A) + row * K + 8 * h;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            xf[t] = *reinterpret_cast<const bf16x8*>(ar + 16 * t);
+            if constexpr (PRO == BPRO_GELU) {
+                f32x8 u = unpack8(xf[t]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) u[e] = gelu_tanh(u[e]);
+                xf[t] = __builtin_convertvector(u, bf16x8);
+                if (a.save_A != nullptr) *reinterpret_cast<bf16x8*>(a.save_A + row * K + 16 * t + 8 * h) = xf[t];
+            }
+        }
+    }
+
+    // ---- n-tiles: 32 outputs each, K/16 MFMAs; result register r = output 8(r>>2) + 4h + (r&3)
+    const bf16x8* wp = a.Wp + lane;
+    const int n_tiles = a.N >> 5;
+    const int seq = tile / (NTOK / 32);
+    const int tok = (tile - seq * (NTOK / 32)) * 32 + i;
+    for (int nt = 0; nt < n_tiles; ++nt) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) acc = mfma16(wp[((size_t)nt * KS + t) * 64], xf[t], acc);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = nt * 32 + 8 * g + 4 * h;
+            f32x4 y = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            if (a.bias != nullptr) y += *reinterpret_cast<const f32x4*>(a.bias + col);
+            if constexpr (EPI == BEPI_BF16) {
+                *reinterpret_cast<bf16x4*>(a.out + row * a.N + col) = pack4(y);
+            } else if constexpr (EPI == BEPI_GELUBWD) {
+                const f32x4 u = unpack4(*reinterpret_cast<const bf16x4*>(a.aux + row * a.N + col));
+                y.x *= gelu_tanh_grad(u.x); y.y *= gelu_tanh_grad(u.y);
+                y.z *= gelu_tanh_grad(u.z); y.w *= gelu_tanh_grad(u.w);
+                *reinterpret_cast<bf16x4*>(a.out + row * a.N + col) = pack4(y);
+            } else {   // BEPI_QKV: n-tile nt = (which, head)
+                __bf16* base = (nt >> 2) == 0 ? a.q : ((nt >> 2) == 1 ? a.k : a.v);
+                const int head = nt & 3;
+                *reinterpret_cast<bf16x4*>(base + (((size_t)seq * NH + head) * NTOK + tok) * DH + 8 * g + 4 * h) = pack4(y);
+            }
+        }
+    }
+}
+
+template <int K, int PRO, int EPI>
+inline int launch_bgemm(const BGemmArgs& a, hipStream_t st) {
+    if (a.M <= 0 || a.M % 32 != 0 || a.N % 32 != 0) {
+        set_error("bgemm: M=%d / N=%d must be positive multiples of 32", a.M, a.N);
+        return T2S_E_INVALID;
+    }
+    bgemm_kernel<K, PRO, EPI><<<(a.M / 32 + 3) / 4, 256, 0, st>>>(a);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+// ------------------------------------------------------------------------------------------ wgrad
+// dW[n][k] += sum_rows dY[row][n] X[row][k],  db[n] += sum_rows dY[row][n]   (fp32 atomics).
+// grid (row slabs, N/128); wave w of a workgroup owns outputs [128 y + 32 w, +32) x all K inputs.
+// MFMA: D[n][k] = sum_row A[n][row] B[row][k]: both operands are read column-wise out of row-major
+// LDS tiles (64 rows per pass, row strides 320 B / 2K+64 B: four consecutive rows land in disjoint
+// bank quarters, so the transposed reads are conflict-free).
+template <int K>
+__global__ __launch_bounds__(256) void wgrad16_kernel(const __bf16* __restrict__ dY, const __bf16* __restrict__ X,
+                                                      float* __restrict__ dW, float* __restrict__ db, int M, int N,
+                                                      int rows_per_wg) {
+    constexpr int KT = K / 32;
+    constexpr int SLAB = 64;
+    constexpr int YSTR = 320;
+    constexpr int XSTR = 2 * K + 64;
+    __shared__ __attribute__((aligned(16))) char ys[SLAB * YSTR];
+    __shared__ __attribute__((aligned(16))) char xs[SLAB * XSTR];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int ncol0 = blockIdx.y * 128;
+    const int r0 = blockIdx.x * rows_per_wg;
+    const int r1 = min(M, r0 + rows_per_wg);
+    // transposed-read addressing of this lane
+    const int grp = (lane >> 4) & 3, nhalf = grp & 1, q = (lane & 15) >> 2, p = lane & 3;
+    const int rbase = 8 * half + q;                      // row inside a 16-row k-step (second read: +4)
+    const char* ya = ys + rbase * YSTR + (wave * 32 + 16 * nhalf + 4 * p) * 2;
+    const char* xa = xs + rbase * XSTR + (16 * nhalf + 4 * p) * 2;
+
+    f32x16 acc[KT], accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const f32x8 onesf = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    const bf16x8 ones = __builtin_convertvector(onesf, bf16x8);
+    const bf16x8 zero8 = __builtin_convertvector(onesf * 0.f, bf16x8);
+
+    for (int rs = r0; rs < r1; rs += SLAB) {
+        __syncthreads();   // previous pass fully consumed
+        for (int idx = tid; idx < SLAB * 16; idx += 256) {
+            const int rr = idx >> 4, c = idx & 15, row = rs + rr;
+            bf16x8 v = zero8;
+            if (row < r1) v = *reinterpret_cast<const bf16x8*>(dY + (size_t)row * N + ncol0 + c * 8);
+            *reinterpret_cast<bf16x8*>(ys + rr * YSTR + c * 16) = v;
+        }
+        for (int idx = tid; idx < SLAB * (K / 8); idx += 256) {
+            const int rr = idx / (K / 8), c = idx - rr * (K / 8), row = rs + rr;
+            bf16x8 v = zero8;
+            if (row < r1) v = *reinterpret_cast<const bf16x8*>(X + (size_t)row * K + c * 8);
+            *reinterpret_cast<bf16x8*>(xs + rr * XSTR + c * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < SLAB / 16; ++s) {
+            const bf16x8 af = join_tr(lds_tr16(ya + (16 * s) * YSTR), lds_tr16(ya + (16 * s + 4) * YSTR));
+            accb = mfma16(af, ones, accb);
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                const bf16x8 bf = join_tr(lds_tr16(xa + (16 * s) * XSTR + t * 64), lds_tr16(xa + (16 * s + 4) * XSTR + t * 64));
+                acc[t] = mfma16(af, bf, acc[t]);
+            }
+        }
+    }
+    const int j = lane & 31;
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            atomicAdd(dW + (size_t)(ncol0 + wave * 32 + acc_row(r, half)) * K + t * 32 + j, acc[t][r]);
+    if (db != nullptr && j == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(db + ncol0 + wave * 32 + acc_row(r, half), accb[r]);
+    }
+}
+
+inline int launch_wgrad16(const __bf16* dY, const __bf16* X, float* dW, float* db, int M, int N, int K, hipStream_t st) {
+    if (N % 128 != 0 || (K != 128 && K != 256) || M <= 0) {
+        set_error("wgrad16: unsupported shape M=%d N=%d K=%d", M, N, K);
+        return T2S_E_INVALID;
+    }
+    const int rows_per_wg = 1024;
+    dim3 grid((M + rows_per_wg - 1) / rows_per_wg, N / 128);
+    if (K == 128)
+        wgrad16_kernel<128><<<grid, 256, 0, st>>>(dY, X, dW, db, M, N, rows_per_wg);
+    else
+        wgrad16_kernel<256><<<grid, 256, 0, st>>>(dY, X, dW, db, M, N, rows_per_wg);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+}  // namespace t2s

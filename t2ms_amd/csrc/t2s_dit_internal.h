@@ -18,6 +18,7 @@ struct t2s_dit {
     float *mod = nullptr, *c = nullptr;
     // optional in-situ kernel timing (HIP events on the launching stream; never under capture)
     t2s_train_ws* train = nullptr;
+    int train_dtype = 0;         // T2S_TRAIN_F32 / T2S_TRAIN_BF16 (t2s_dit_set_train_dtype)
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
     std::vector<int> ev_class;   // class of interval i = [ev_pool[2i], ev_pool[2i+1]]

@@ -16,7 +16,7 @@
 // reference-generated fixture tests/golden/train_step.npz.
 #include <vector>
 
-#include "t2s_gemm.h"
+#include "t2s_bf16.h"
 #include "t2s_dit_internal.h"
 
 using namespace t2s;
@@ -26,11 +26,16 @@ int attn_plain_train_fwd(const float* q, const float* k, const float* v, float* 
                          hipStream_t st);
 int attn_bwd(const float* q, const float* k, const float* v, const float* o_rows, const float* do_rows,
              const float* lse, float* dsum, float* dqkv_rows, int BH, hipStream_t st);
+void train_free(t2s_dit* h);
+int attn16_train_fwd(const __bf16* q, const __bf16* k, const __bf16* v, __bf16* o_rows, float* lse, int BH, hipStream_t st);
+int attn16_bwd(const __bf16* q, const __bf16* k, const __bf16* v, const __bf16* o_rows, const __bf16* do_rows,
+               const float* lse, float* dsum, __bf16* dqkv_rows, int BH, hipStream_t st);
 }
 
 // ------------------------------------------------------------------ workspace
 struct t2s_train_ws {
     int cap_seqs = 0;
+    int dtype = 0;        // T2S_TRAIN_F32 / T2S_TRAIN_BF16 this workspace was laid out for
     int S = 0;            // sequences of the last forward
     bool has_text = false;
     // packed weights for training (tile-major, both orientations), refreshed by pack_train_weights
@@ -48,6 +53,14 @@ struct t2s_train_ws {
     // backward temporaries
     float *dx = nullptr, *t1 = nullptr, *t2a = nullptr, *t2b = nullptr, *t3 = nullptr, *t4 = nullptr, *dsum = nullptr,
           *dmod = nullptr;
+    // ---- T2S_TRAIN_BF16: packed bf16 weights (forward W and dgrad W^T) and bf16 activations; the
+    // residual stream (x_in, x_mid, dx), lse, dsum, mod, dmod above stay fp32
+    __bf16* warena16 = nullptr;
+    bf16x8 *qkv_f16[NBLK], *proj_f16[NBLK], *fc1_f16[NBLK], *fc2_f16[NBLK];
+    bf16x8 *qkv_t16[NBLK], *proj_t16[NBLK], *fc1_t16[NBLK], *fc2_t16[NBLK];
+    __bf16* act16 = nullptr;
+    __bf16 *a1h[NBLK], *qh[NBLK], *kh[NBLK], *vh[NBLK], *oh[NBLK], *ph[NBLK], *a2h[NBLK], *uh[NBLK], *gh[NBLK], *fh[NBLK];
+    __bf16 *t1h = nullptr, *t2h = nullptr, *t3h = nullptr, *t4h = nullptr;   // (M,128) (M,256) (M,384) (M,128)
 };
 
 namespace {
@@ -72,8 +85,15 @@ int pack_any(const float* W, f32x4* P, int N, int K, int transpose, hipStream_t 
 }
 
 // ---------------------------------------------------------------- elementwise / per-sequence kernels
+// float4-granular access to a branch tensor stored as fp32 (T2S_TRAIN_F32) or bf16 (T2S_TRAIN_BF16)
+__device__ __forceinline__ f32x4 ld4(const float* p, size_t i4) { return reinterpret_cast<const f32x4*>(p)[i4]; }
+__device__ __forceinline__ f32x4 ld4(const __bf16* p, size_t i4) { return unpack4(reinterpret_cast<const bf16x4*>(p)[i4]); }
+__device__ __forceinline__ void st4(float* p, size_t i4, f32x4 v) { reinterpret_cast<f32x4*>(p)[i4] = v; }
+__device__ __forceinline__ void st4(__bf16* p, size_t i4, f32x4 v) { reinterpret_cast<bf16x4*>(p)[i4] = pack4(v); }
+
 // x_out = x_in + gate[seq] * f      (rows of 128)
-__global__ __launch_bounds__(256) void gate_res_kernel(const float* __restrict__ xin, const float* __restrict__ f,
+template <typename T>
+__global__ __launch_bounds__(256) void gate_res_kernel(const float* __restrict__ xin, const T* __restrict__ f,
                                                        const float* __restrict__ mod, int gate_off,
                                                        float* __restrict__ xout, int M) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // float4 index
@@ -82,14 +102,15 @@ __global__ __launch_bounds__(256) void gate_res_kernel(const float* __restrict__
     const int seq = row / NTOK;
     const f32x4 g = *reinterpret_cast<const f32x4*>(mod + (size_t)seq * MODROW + gate_off + c4 * 4);
     const f32x4 a = reinterpret_cast<const f32x4*>(xin)[idx];
-    const f32x4 b = reinterpret_cast<const f32x4*>(f)[idx];
+    const f32x4 b = ld4(f, idx);
     reinterpret_cast<f32x4*>(xout)[idx] = a + g * b;
 }
 
 // one workgroup per sequence: t = gate * dx ; dgate[seq] = sum_tok dx * f
-__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ f,
+template <typename T>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dx, const T* __restrict__ f,
                                                        const float* __restrict__ mod, int gate_off,
-                                                       float* __restrict__ t, float* __restrict__ dmod) {
+                                                       T* __restrict__ t, float* __restrict__ dmod) {
     __shared__ f32x4 red[8][32];
     const int seq = blockIdx.x;
     const int c4 = threadIdx.x & 31, rg = threadIdx.x >> 5;   // 8 row groups
@@ -98,8 +119,8 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
     for (int tok = rg; tok < NTOK; tok += 8) {
         const size_t idx = ((size_t)seq * NTOK + tok) * 32 + c4;
         const f32x4 d = reinterpret_cast<const f32x4*>(dx)[idx];
-        const f32x4 fv = reinterpret_cast<const f32x4*>(f)[idx];
-        reinterpret_cast<f32x4*>(t)[idx] = g * d;
+        const f32x4 fv = ld4(f, idx);
+        st4(t, idx, g * d);
         acc += d * fv;
     }
     red[rg][c4] = acc;
@@ -115,7 +136,8 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
 // one workgroup per sequence.  da = grad wrt modulate(LN(x)); computes
 //   dshift = sum_tok da, dscale = sum_tok da * n, dn = da * (1 + scale),
 //   dx += rstd * (dn - mean(dn) - n * mean(dn * n))          (LayerNorm backward, eps 1e-6, no affine)
-__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict__ da, const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const T* __restrict__ da, const float* __restrict__ x,
                                                          const float* __restrict__ mod, int shift_off, int scale_off,
                                                          float* __restrict__ dx, float* __restrict__ dmod) {
     __shared__ f32x4 red[2][8][32];
@@ -126,7 +148,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict
     for (int tok = rg; tok < NTOK; tok += 8) {
         const size_t idx = ((size_t)seq * NTOK + tok) * 32 + c4;
         const f32x4 xv = reinterpret_cast<const f32x4*>(x)[idx];
-        const f32x4 g = reinterpret_cast<const f32x4*>(da)[idx];
+        const f32x4 g = ld4(da, idx);
         float s = (xv.x + xv.y) + (xv.z + xv.w);
 #pragma unroll
         for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -533,70 +555,119 @@ __global__ __launch_bounds__(256) void final_rows_kernel(const float* __restrict
 
 // ---------------------------------------------------------------- workspace management
 int ensure_ws(t2s_dit* h, int S) {
-    if (h->train && h->train->cap_seqs >= S) return T2S_OK;
-    if (h->train) {
-        t2s_train_ws* w = h->train;
-        float* bufs[] = {w->warena, w->act};
-        for (float* b : bufs)
-            if (b) (void)hipFree(b);
-        delete w;
-        h->train = nullptr;
-    }
+    const int dtype = h->train_dtype;
+    if (h->train && h->train->cap_seqs >= S && h->train->dtype == dtype) return T2S_OK;
+    t2s::train_free(h);
     t2s_train_ws* w = new t2s_train_ws();
     w->cap_seqs = S;
-    // ---- packed weights
-    size_t woff = 0;
-    auto wtake = [&](size_t n) { size_t o = woff; woff += r64(n); return o; };
-    size_t o_qkv_f[NBLK], o_proj_f[NBLK], o_fc1_f[NBLK], o_fc2_f[NBLK], o_qkv_t[NBLK], o_proj_t[NBLK], o_fc1_t[NBLK],
-        o_fc2_t[NBLK];
-    for (int i = 0; i < NBLK; ++i) {
-        o_qkv_f[i] = wtake(3 * D * D); o_proj_f[i] = wtake(D * D); o_fc1_f[i] = wtake(2 * D * D); o_fc2_f[i] = wtake(2 * D * D);
-        o_qkv_t[i] = wtake(3 * D * D); o_proj_t[i] = wtake(D * D); o_fc1_t[i] = wtake(2 * D * D); o_fc2_t[i] = wtake(2 * D * D);
-    }
-    if (hipMalloc(&w->warena, woff * sizeof(float)) != hipSuccess) {
-        set_error("t2s train: hipMalloc(packed weights) failed");
+    w->dtype = dtype;
+    const bool bf = dtype == T2S_TRAIN_BF16;
+    auto fail = [&](const char* what, double mb) {
+        set_error("t2s train: hipMalloc(%s, %.1f MB) failed", what, mb);
+        if (w->warena) (void)hipFree(w->warena);
+        if (w->warena16) (void)hipFree(w->warena16);
+        if (w->act) (void)hipFree(w->act);
+        if (w->act16) (void)hipFree(w->act16);
         delete w;
         return T2S_E_HIP;
+    };
+    // ---- packed weights (fp32 packs: fc2 tile-major + all W^T; bf16 packs: W and W^T of every linear)
+    size_t woff = 0;
+    auto wtake = [&](size_t n) { size_t o = woff; woff += r64(n); return o; };
+    size_t o_f[4][NBLK], o_t[4][NBLK];
+    const size_t wsz[4] = {3 * D * D, D * D, 2 * D * D, 2 * D * D};   // qkv, proj, fc1, fc2
+    for (int i = 0; i < NBLK; ++i)
+        for (int j = 0; j < 4; ++j) { o_f[j][i] = wtake(wsz[j]); o_t[j][i] = wtake(wsz[j]); }
+    if (!bf) {
+        if (hipMalloc(&w->warena, woff * sizeof(float)) != hipSuccess) return fail("packed weights", woff * 4 / 1e6);
+        for (int i = 0; i < NBLK; ++i) {
+            w->qkv_f[i] = (f32x4*)(w->warena + o_f[0][i]); w->proj_f[i] = (f32x4*)(w->warena + o_f[1][i]);
+            w->fc1_f[i] = (f32x4*)(w->warena + o_f[2][i]); w->fc2_f[i] = (f32x4*)(w->warena + o_f[3][i]);
+            w->qkv_t[i] = (f32x4*)(w->warena + o_t[0][i]); w->proj_t[i] = (f32x4*)(w->warena + o_t[1][i]);
+            w->fc1_t[i] = (f32x4*)(w->warena + o_t[2][i]); w->fc2_t[i] = (f32x4*)(w->warena + o_t[3][i]);
+        }
+    } else {
+        if (hipMalloc(&w->warena16, woff * sizeof(__bf16)) != hipSuccess) return fail("packed bf16 weights", woff * 2 / 1e6);
+        for (int i = 0; i < NBLK; ++i) {
+            w->qkv_f16[i] = (bf16x8*)(w->warena16 + o_f[0][i]); w->proj_f16[i] = (bf16x8*)(w->warena16 + o_f[1][i]);
+            w->fc1_f16[i] = (bf16x8*)(w->warena16 + o_f[2][i]); w->fc2_f16[i] = (bf16x8*)(w->warena16 + o_f[3][i]);
+            w->qkv_t16[i] = (bf16x8*)(w->warena16 + o_t[0][i]); w->proj_t16[i] = (bf16x8*)(w->warena16 + o_t[1][i]);
+            w->fc1_t16[i] = (bf16x8*)(w->warena16 + o_t[2][i]); w->fc2_t16[i] = (bf16x8*)(w->warena16 + o_t[3][i]);
+        }
     }
-    for (int i = 0; i < NBLK; ++i) {
-        w->qkv_f[i] = (f32x4*)(w->warena + o_qkv_f[i]); w->proj_f[i] = (f32x4*)(w->warena + o_proj_f[i]);
-        w->fc1_f[i] = (f32x4*)(w->warena + o_fc1_f[i]); w->fc2_f[i] = (f32x4*)(w->warena + o_fc2_f[i]);
-        w->qkv_t[i] = (f32x4*)(w->warena + o_qkv_t[i]); w->proj_t[i] = (f32x4*)(w->warena + o_proj_t[i]);
-        w->fc1_t[i] = (f32x4*)(w->warena + o_fc1_t[i]); w->fc2_t[i] = (f32x4*)(w->warena + o_fc2_t[i]);
-    }
-    // ---- activations + temporaries
+    // ---- fp32 arena: residual stream and statistics always; branch activations only in fp32 mode
     const size_t M = (size_t)S * NTOK;
     size_t aoff = 0;
     auto atake = [&](size_t n) { size_t o = aoff; aoff += r64(n); return o; };
-    size_t o_xin[NBLK + 1], o_a1[NBLK], o_q[NBLK], o_k[NBLK], o_v[NBLK], o_o[NBLK], o_lse[NBLK], o_p[NBLK], o_xm[NBLK],
-        o_a2[NBLK], o_u[NBLK], o_f[NBLK];
+    size_t o_xin[NBLK + 1], o_xm[NBLK], o_lse[NBLK];
+    size_t o_a1[NBLK], o_q[NBLK], o_k[NBLK], o_v[NBLK], o_o[NBLK], o_p[NBLK], o_a2[NBLK], o_u[NBLK], o_f32[NBLK];
     for (int i = 0; i <= NBLK; ++i) o_xin[i] = atake(M * D);
     for (int i = 0; i < NBLK; ++i) {
-        o_a1[i] = atake(M * D); o_q[i] = atake(M * D); o_k[i] = atake(M * D); o_v[i] = atake(M * D); o_o[i] = atake(M * D);
-        o_lse[i] = atake(M * NH); o_p[i] = atake(M * D); o_xm[i] = atake(M * D); o_a2[i] = atake(M * D);
-        o_u[i] = atake(M * 2 * D); o_f[i] = atake(M * D);
+        o_xm[i] = atake(M * D);
+        o_lse[i] = atake(M * NH);
+        if (!bf) {
+            o_a1[i] = atake(M * D); o_q[i] = atake(M * D); o_k[i] = atake(M * D); o_v[i] = atake(M * D); o_o[i] = atake(M * D);
+            o_p[i] = atake(M * D); o_a2[i] = atake(M * D); o_u[i] = atake(M * 2 * D); o_f32[i] = atake(M * D);
+        }
     }
     const size_t o_silu = atake((size_t)S * D), o_mod = atake((size_t)S * MODROW), o_c = atake((size_t)S * D),
-                 o_lat = atake((size_t)S * LAT), o_dx = atake(M * D), o_t1 = atake(M * D), o_t2a = atake(M * 2 * D),
-                 o_t2b = atake(M * 2 * D), o_t3 = atake(M * 3 * D), o_t4 = atake(M * D), o_dsum = atake(M * NH),
+                 o_lat = atake((size_t)S * LAT), o_dx = atake(M * D), o_dsum = atake(M * NH),
                  o_dmod = atake((size_t)S * MODROW);
-    if (hipMalloc(&w->act, aoff * sizeof(float)) != hipSuccess) {
-        set_error("t2s train: hipMalloc(activations, %.1f MB) failed", aoff * 4 / 1e6);
-        (void)hipFree(w->warena);
-        delete w;
-        return T2S_E_HIP;
-    }
+    // t1 also serves the adaLN weight gradient as an (S,768) fp32 temporary in both modes
+    const size_t o_t1 = atake(bf ? (size_t)S * MODW : M * D);
+    size_t o_t2a = 0, o_t2b = 0, o_t3 = 0, o_t4 = 0;
+    if (!bf) { o_t2a = atake(M * 2 * D); o_t2b = atake(M * 2 * D); o_t3 = atake(M * 3 * D); o_t4 = atake(M * D); }
+    if (hipMalloc(&w->act, aoff * sizeof(float)) != hipSuccess) return fail("activations", aoff * 4 / 1e6);
     float* A = w->act;
     for (int i = 0; i <= NBLK; ++i) w->x_in[i] = A + o_xin[i];
     for (int i = 0; i < NBLK; ++i) {
-        w->a1[i] = A + o_a1[i]; w->q[i] = A + o_q[i]; w->k[i] = A + o_k[i]; w->v[i] = A + o_v[i]; w->o[i] = A + o_o[i];
-        w->lse[i] = A + o_lse[i]; w->p[i] = A + o_p[i]; w->x_mid[i] = A + o_xm[i]; w->a2[i] = A + o_a2[i];
-        w->u[i] = A + o_u[i]; w->f[i] = A + o_f[i];
+        w->x_mid[i] = A + o_xm[i];
+        w->lse[i] = A + o_lse[i];
+        if (!bf) {
+            w->a1[i] = A + o_a1[i]; w->q[i] = A + o_q[i]; w->k[i] = A + o_k[i]; w->v[i] = A + o_v[i]; w->o[i] = A + o_o[i];
+            w->p[i] = A + o_p[i]; w->a2[i] = A + o_a2[i]; w->u[i] = A + o_u[i]; w->f[i] = A + o_f32[i];
+        }
     }
-    w->silu_c = A + o_silu; w->mod = A + o_mod; w->c = A + o_c; w->lat = A + o_lat; w->dx = A + o_dx; w->t1 = A + o_t1;
-    w->t2a = A + o_t2a; w->t2b = A + o_t2b; w->t3 = A + o_t3; w->t4 = A + o_t4; w->dsum = A + o_dsum; w->dmod = A + o_dmod;
+    w->silu_c = A + o_silu; w->mod = A + o_mod; w->c = A + o_c; w->lat = A + o_lat; w->dx = A + o_dx;
+    w->dsum = A + o_dsum; w->dmod = A + o_dmod; w->t1 = A + o_t1;
+    if (!bf) { w->t2a = A + o_t2a; w->t2b = A + o_t2b; w->t3 = A + o_t3; w->t4 = A + o_t4; }
+    // ---- bf16 arena
+    if (bf) {
+        size_t hoff = 0;
+        auto htake = [&](size_t n) { size_t o = hoff; hoff += r64(n); return o; };
+        size_t h_a1[NBLK], h_q[NBLK], h_k[NBLK], h_v[NBLK], h_o[NBLK], h_p[NBLK], h_a2[NBLK], h_u[NBLK], h_g[NBLK], h_f[NBLK];
+        for (int i = 0; i < NBLK; ++i) {
+            h_a1[i] = htake(M * D); h_q[i] = htake(M * D); h_k[i] = htake(M * D); h_v[i] = htake(M * D); h_o[i] = htake(M * D);
+            h_p[i] = htake(M * D); h_a2[i] = htake(M * D); h_u[i] = htake(M * 2 * D); h_g[i] = htake(M * 2 * D);
+            h_f[i] = htake(M * D);
+        }
+        const size_t h_t1 = htake(M * D), h_t2 = htake(M * 2 * D), h_t3 = htake(M * 3 * D), h_t4 = htake(M * D);
+        if (hipMalloc(&w->act16, hoff * sizeof(__bf16)) != hipSuccess) return fail("bf16 activations", hoff * 2 / 1e6);
+        __bf16* H = w->act16;
+        for (int i = 0; i < NBLK; ++i) {
+            w->a1h[i] = H + h_a1[i]; w->qh[i] = H + h_q[i]; w->kh[i] = H + h_k[i]; w->vh[i] = H + h_v[i]; w->oh[i] = H + h_o[i];
+            w->ph[i] = H + h_p[i]; w->a2h[i] = H + h_a2[i]; w->uh[i] = H + h_u[i]; w->gh[i] = H + h_g[i]; w->fh[i] = H + h_f[i];
+        }
+        w->t1h = H + h_t1; w->t2h = H + h_t2; w->t3h = H + h_t3; w->t4h = H + h_t4;
+    }
     h->train = w;
     return T2S_OK;
+}
+
+int pack16(const float* W, bf16x8* P, int N, int K, int transpose, hipStream_t st) {
+    pack16_kernel<<<(N * K + 255) / 256, 256, 0, st>>>(W, reinterpret_cast<__bf16*>(P), N, K, transpose);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+template <int K, int PRO, int EPI>
+int bgemm(const void* A, const bf16x8* Wp, const float* bias, __bf16* out, int M, int N, hipStream_t st,
+          const float* mod = nullptr, int shift_off = 0, int scale_off = 0, __bf16* save_A = nullptr,
+          const __bf16* aux = nullptr, __bf16* q = nullptr, __bf16* k = nullptr, __bf16* v = nullptr) {
+    BGemmArgs a{};
+    a.A = A; a.Wp = Wp; a.bias = bias; a.out = out; a.M = M; a.N = N; a.mod = mod; a.shift_off = shift_off;
+    a.scale_off = scale_off; a.save_A = save_A; a.aux = aux; a.q = q; a.k = k; a.v = v;
+    return launch_bgemm<K, PRO, EPI>(a, st);
 }
 
 template <int K, int NT, int PRO, int EPI>
@@ -631,15 +702,25 @@ int colsum(const float* Y, float* out, int M, int N, hipStream_t st) {
 namespace t2s {
 void train_free(t2s_dit* h) {
     if (!h || !h->train) return;
-    if (h->train->warena) (void)hipFree(h->train->warena);
-    if (h->train->act) (void)hipFree(h->train->act);
-    delete h->train;
+    t2s_train_ws* w = h->train;
+    if (w->warena) (void)hipFree(w->warena);
+    if (w->warena16) (void)hipFree(w->warena16);
+    if (w->act) (void)hipFree(w->act);
+    if (w->act16) (void)hipFree(w->act16);
+    delete w;
     h->train = nullptr;
 }
 }  // namespace t2s
 
 // ------------------------------------------------------------------ C ABI
 extern "C" {
+
+int t2s_dit_set_train_dtype(t2s_dit* h, int dtype) {
+    T2S_REQUIRE(h, "t2s_dit_set_train_dtype: NULL handle");
+    T2S_REQUIRE(dtype == T2S_TRAIN_F32 || dtype == T2S_TRAIN_BF16, "t2s_dit_set_train_dtype: unknown dtype %d", dtype);
+    h->train_dtype = dtype;
+    return T2S_OK;
+}
 
 int t2s_dit_train_forward(t2s_dit* h, const t2s_dit_weights* w, const float* x, const float* temb, int temb_rows,
                           const float* text, float* out, int B, void* stream) {
@@ -654,13 +735,22 @@ int t2s_dit_train_forward(t2s_dit* h, const t2s_dit_weights* w, const float* x, 
     ws->S = S;
     ws->has_text = text != nullptr;
     // the handle's own parameter copies / forward packs must be current: the caller refreshes them
-    // with t2s_dit_update_weights; here only the training-specific packs (fc2 tile-major, all W^T)
+    // with t2s_dit_update_weights; here only the training-specific packs
+    const bool bf = ws->dtype == T2S_TRAIN_BF16;
     for (int i = 0; i < NBLK; ++i) {
         const t2s_dit_block_weights& b = w->blk[i];
-        if ((rc = pack_any(b.qkv_w, ws->qkv_t[i], 3 * D, D, 1, st)) || (rc = pack_any(b.proj_w, ws->proj_t[i], D, D, 1, st)) ||
-            (rc = pack_any(b.fc1_w, ws->fc1_t[i], 2 * D, D, 1, st)) || (rc = pack_any(b.fc2_w, ws->fc2_f[i], D, 2 * D, 0, st)) ||
-            (rc = pack_any(b.fc2_w, ws->fc2_t[i], D, 2 * D, 1, st)))
-            return rc;
+        if (!bf) {   // fc2 tile-major, all W^T
+            if ((rc = pack_any(b.qkv_w, ws->qkv_t[i], 3 * D, D, 1, st)) || (rc = pack_any(b.proj_w, ws->proj_t[i], D, D, 1, st)) ||
+                (rc = pack_any(b.fc1_w, ws->fc1_t[i], 2 * D, D, 1, st)) || (rc = pack_any(b.fc2_w, ws->fc2_f[i], D, 2 * D, 0, st)) ||
+                (rc = pack_any(b.fc2_w, ws->fc2_t[i], D, 2 * D, 1, st)))
+                return rc;
+        } else {     // bf16 copies of the fp32 master weights, both orientations
+            if ((rc = pack16(b.qkv_w, ws->qkv_f16[i], 3 * D, D, 0, st)) || (rc = pack16(b.qkv_w, ws->qkv_t16[i], 3 * D, D, 1, st)) ||
+                (rc = pack16(b.proj_w, ws->proj_f16[i], D, D, 0, st)) || (rc = pack16(b.proj_w, ws->proj_t16[i], D, D, 1, st)) ||
+                (rc = pack16(b.fc1_w, ws->fc1_f16[i], 2 * D, D, 0, st)) || (rc = pack16(b.fc1_w, ws->fc1_t16[i], 2 * D, D, 1, st)) ||
+                (rc = pack16(b.fc2_w, ws->fc2_f16[i], D, 2 * D, 0, st)) || (rc = pack16(b.fc2_w, ws->fc2_t16[i], D, 2 * D, 1, st)))
+                return rc;
+        }
     }
     T2S_HIP_CHECK(hipMemcpyAsync(ws->lat, x, (size_t)S * LAT * sizeof(float), hipMemcpyDeviceToDevice, st));
     cond_rows_kernel<<<(S * D + 255) / 256, 256, 0, st>>>(ws->c, temb, temb_rows, text, S);
@@ -671,7 +761,27 @@ int t2s_dit_train_forward(t2s_dit* h, const t2s_dit_weights* w, const float* x, 
     patchify_rows_kernel<<<(S * NTOK * 32 + 255) / 256, 256, 0, st>>>(x, ws->x_in[0], S, h->conv_w, h->conv_b, h->patch_w,
                                                                       h->patch_b, h->pos);
     T2S_LAUNCH_CHECK();
-    for (int i = 0; i < NBLK; ++i) {
+    for (int i = 0; i < NBLK && bf; ++i) {
+        const int base = i * MODW;
+        // a1 = mod(LN1(x_in)) -> bf16; q,k,v = a1 Wqkv^T + b -> bf16 heads
+        if ((rc = bgemm<128, BPRO_LN, BEPI_QKV>(ws->x_in[i], ws->qkv_f16[i], h->qkv_b[i], nullptr, M, 3 * D, st, ws->mod,
+                                                 base + 0 * D, base + 1 * D, ws->a1h[i], nullptr, ws->qh[i], ws->kh[i], ws->vh[i])))
+            return rc;
+        if ((rc = attn16_train_fwd(ws->qh[i], ws->kh[i], ws->vh[i], ws->oh[i], ws->lse[i], S * NH, st))) return rc;
+        if ((rc = bgemm<128, BPRO_BF16, BEPI_BF16>(ws->oh[i], ws->proj_f16[i], h->proj_b[i], ws->ph[i], M, D, st))) return rc;
+        gate_res_kernel<<<(M * 32 + 255) / 256, 256, 0, st>>>(ws->x_in[i], ws->ph[i], ws->mod, base + 2 * D, ws->x_mid[i], M);
+        T2S_LAUNCH_CHECK();
+        // a2 = mod(LN2(x_mid)); u = a2 W1^T + b1; g = gelu(u) (saved for the fc2 weight gradient); f = g W2^T + b2
+        if ((rc = bgemm<128, BPRO_LN, BEPI_BF16>(ws->x_mid[i], ws->fc1_f16[i], h->fc1_b[i], ws->uh[i], M, 2 * D, st, ws->mod,
+                                                  base + 3 * D, base + 4 * D, ws->a2h[i])))
+            return rc;
+        if ((rc = bgemm<256, BPRO_GELU, BEPI_BF16>(ws->uh[i], ws->fc2_f16[i], h->fc2_b[i], ws->fh[i], M, D, st, nullptr, 0, 0,
+                                                    ws->gh[i])))
+            return rc;
+        gate_res_kernel<<<(M * 32 + 255) / 256, 256, 0, st>>>(ws->x_mid[i], ws->fh[i], ws->mod, base + 5 * D, ws->x_in[i + 1], M);
+        T2S_LAUNCH_CHECK();
+    }
+    for (int i = 0; i < NBLK && !bf; ++i) {
         const int base = i * MODW;
         // a1 = mod(LN1(x_in)); q,k,v = a1 Wqkv^T + b
         if ((rc = gemm<128, 3, PRO_LNMOD, EPI_QKV>(ws->x_in[i], h->qkv_p[i], h->qkv_b[i], nullptr, M, 3 * D, st, ws->mod,
@@ -697,6 +807,7 @@ int t2s_dit_train_forward(t2s_dit* h, const t2s_dit_weights* w, const float* x, 
 int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g, int B, void* stream) {
     T2S_REQUIRE(h && dout && g, "t2s_dit_train_backward: NULL argument");
     T2S_REQUIRE(h->train && h->train->S == B, "t2s_dit_train_backward: no matching t2s_dit_train_forward (B=%d)", B);
+    T2S_REQUIRE(h->train->dtype == h->train_dtype, "t2s_dit_train_backward: training dtype changed since the forward");
     hipStream_t st = (hipStream_t)stream;
     t2s_train_ws* ws = h->train;
     const int S = B, M = S * NTOK;
@@ -718,7 +829,37 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
     final_bwd_kernel<<<(M + 63) / 64, 256, 0, st>>>(ws->x_in[NBLK], dout, h->ln_w, h->ln_b, h->out_w, ws->dx, g->ln_w,
                                                     g->ln_b, g->out_w, g->out_b, M);
     T2S_LAUNCH_CHECK();
-    for (int i = NBLK - 1; i >= 0; --i) {
+    const bool bf = ws->dtype == T2S_TRAIN_BF16;
+    for (int i = NBLK - 1; i >= 0 && bf; --i) {
+        const int base = i * MODW;
+        const t2s_dit_block_grads& b = g->blk[i];
+        // ---- MLP branch: x_out = x_mid + g2 * f
+        gate_bwd_kernel<<<S, 256, 0, st>>>(ws->dx, ws->fh[i], ws->mod, base + 5 * D, ws->t1h, ws->dmod);     // t1 = df
+        T2S_LAUNCH_CHECK();
+        if ((rc = launch_wgrad16(ws->t1h, ws->gh[i], b.fc2_w, b.fc2_b, M, D, 2 * D, st))) return rc;
+        // du = (df W2) * gelu'(u)
+        if ((rc = bgemm<128, BPRO_BF16, BEPI_GELUBWD>(ws->t1h, ws->fc2_t16[i], nullptr, ws->t2h, M, 2 * D, st, nullptr, 0, 0,
+                                                       nullptr, ws->uh[i])))
+            return rc;
+        if ((rc = launch_wgrad16(ws->t2h, ws->a2h[i], b.fc1_w, b.fc1_b, M, 2 * D, D, st))) return rc;
+        // da2 = du W1
+        if ((rc = bgemm<256, BPRO_BF16, BEPI_BF16>(ws->t2h, ws->fc1_t16[i], nullptr, ws->t1h, M, D, st))) return rc;
+        ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t1h, ws->x_mid[i], ws->mod, base + 3 * D, base + 4 * D, ws->dx, ws->dmod);
+        T2S_LAUNCH_CHECK();
+        // ---- attention branch: x_mid = x_in + g1 * p
+        gate_bwd_kernel<<<S, 256, 0, st>>>(ws->dx, ws->ph[i], ws->mod, base + 2 * D, ws->t1h, ws->dmod);     // t1 = dp
+        T2S_LAUNCH_CHECK();
+        if ((rc = launch_wgrad16(ws->t1h, ws->oh[i], b.proj_w, b.proj_b, M, D, D, st))) return rc;
+        if ((rc = bgemm<128, BPRO_BF16, BEPI_BF16>(ws->t1h, ws->proj_t16[i], nullptr, ws->t4h, M, D, st))) return rc;   // do
+        if ((rc = attn16_bwd(ws->qh[i], ws->kh[i], ws->vh[i], ws->oh[i], ws->t4h, ws->lse[i], ws->dsum, ws->t3h, S * NH, st)))
+            return rc;
+        if ((rc = launch_wgrad16(ws->t3h, ws->a1h[i], b.qkv_w, b.qkv_b, M, 3 * D, D, st))) return rc;
+        // da1 = dqkv Wqkv
+        if ((rc = bgemm<384, BPRO_BF16, BEPI_BF16>(ws->t3h, ws->qkv_t16[i], nullptr, ws->t1h, M, D, st))) return rc;
+        ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t1h, ws->x_in[i], ws->mod, base + 0 * D, base + 1 * D, ws->dx, ws->dmod);
+        T2S_LAUNCH_CHECK();
+    }
+    for (int i = NBLK - 1; i >= 0 && !bf; --i) {
         const int base = i * MODW;
         const t2s_dit_block_grads& b = g->blk[i];
         // ---- MLP branch: x_out = x_mid + g2 * f

@@ -248,6 +248,15 @@ class Transformer(nn.Module):
             self.__dict__["_t2s_stamp"] = stamp
         return h.ptr
 
+    def set_train_dtype(self, dtype: str):
+        """Arithmetic of forward-under-autograd / backward: "f32" (default; gradients equal the fp32
+        reference's) or "bf16" (BASELINE config 4: bf16 MFMA operands and saved activations, fp32
+        accumulation, master weights, residual stream, statistics and gradients)."""
+        if dtype not in ("f32", "bf16"):
+            raise ValueError(f"train dtype must be 'f32' or 'bf16', got {dtype!r}")
+        self.__dict__["_t2s_train_dtype"] = dtype
+        return self
+
     def __getstate__(self):
         state = self.__dict__.copy()
         for k in ("_t2s_h", "_t2s_dev", "_t2s_stamp"):

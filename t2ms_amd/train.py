@@ -71,6 +71,8 @@ class _DitTrainFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             h = model.t2s_handle(dev, B)                    # refreshes the packed weights if they changed
             w, keep, _ = model._weights_struct(dev)
+            dt = L.TRAIN_BF16 if model.__dict__.get("_t2s_train_dtype", "f32") == "bf16" else L.TRAIN_F32
+            L.check(L.lib().t2s_dit_set_train_dtype(h, dt), "t2s_dit_set_train_dtype")
             out = torch.empty(B, L.LAT_C, L.LAT_W, device=dev, dtype=torch.float32)
             L.check(L.lib().t2s_dit_train_forward(h, C.byref(w), L.dev_ptr(x, "input"), L.dev_ptr(temb), B,
                                                   L.dev_ptr(text, "text_input"), L.dev_ptr(out), B,

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--length", type=int, default=96)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
     a = ap.parse_args()
     rank, local_rank, world = tdist.env_world()
     torch.cuda.set_device(local_rank)
@@ -26,7 +27,7 @@ def main():
     from model.denoiser.transformer import Transformer
     from model.pretrained.vqvae import vqvae
     from model.backbone.DDPM import DDPM
-    m = Transformer(); m.load_state_dict(synth.make_dit_state_dict(2025), strict=True); m = m.to(dev).train()
+    m = Transformer(); m.load_state_dict(synth.make_dit_state_dict(2025), strict=True); m = m.to(dev).train().set_train_dtype(a.dtype)
     v = vqvae(types.SimpleNamespace(block_hidden_size=128, num_residual_layers=2, res_hidden_size=256, embedding_dim=64))
     v.load_state_dict(synth.make_vae_state_dict(2025), strict=True); v = v.to(dev).eval()
     m.encoder = v.encoder
@@ -65,9 +66,9 @@ def main():
     el = tdist.max_over_ranks(dist, time.perf_counter() - t0, dev)
     if rank == 0:
         flops = 3 * 0.977e9 * B * world * a.steps
-        print(json.dumps({"metric": "DiT training samples/sec (config 4 shape, fp32)", "value": B * world * a.steps / el,
+        print(json.dumps({"metric": f"DiT training samples/sec (config 4 shape, {a.dtype})", "value": B * world * a.steps / el,
                           "unit": "samples/s", "n_gpus": world, "ms_per_step": el / a.steps * 1e3, "per_gpu_batch": B,
-                          "dtype": "f32", "tflops": flops / el / 1e12, "allreduce_share": t_ar / el,
+                          "dtype": a.dtype, "tflops": flops / el / 1e12, "allreduce_share": t_ar / el,
                           "loss": float(loss.item())}))
     tdist.barrier(dist, dev)
 
