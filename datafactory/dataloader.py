@@ -45,15 +45,19 @@ class AlternatingDataset(Dataset):
 
 
 def custom_collate_fn(batch):
-    """Group a mixed batch by source dataset -> list of (texts, xs, embeddings) (dataloader.py:115-133)."""
+    """Group a mixed batch by source dataset -> list of (texts, xs, embeddings) (dataloader.py:115-133);
+    with a latent cache attached each group carries its dataset row indices as a 4th element."""
     out = []
     for which in (0, 1, 2):
         rows = [item for item, w in batch if w == which]
         if not rows:
             continue
-        texts, xs, embs = zip(*rows)
-        out.append((list(texts), torch.stack([torch.as_tensor(x) for x in xs]),
-                    torch.stack([torch.as_tensor(e) for e in embs])))
+        cols = list(zip(*rows))
+        group = (list(cols[0]), torch.stack([torch.as_tensor(x) for x in cols[1]]),
+                 torch.stack([torch.as_tensor(e) for e in cols[2]]))
+        if len(cols) == 4:
+            group += (torch.as_tensor(cols[3], dtype=torch.long),)
+        out.append(group)
     return out
 
 

@@ -8,7 +8,9 @@ Contract kept from the reference:
     rows are "train", the rest "test"; the global numpy RNG state is restored (dataset.py:43-69);
   * item = (text, x (L,), embedding (128,)) (dataset.py:98-102).
 A parsed-once binary cache (`<name>.t2scache.npz` next to the CSV) replaces the per-row
-ast.literal_eval on later runs.
+ast.literal_eval on later runs.  `attach_latents` turns a dataset into a source of pre-encoded
+LA-VAE latents (the encoder is frozen, train.py:31-33, yet re-run on every step,
+train.py:106): items then carry their row index as a 4th element.
 """
 from __future__ import annotations
 
@@ -40,6 +42,21 @@ def minmax_scale_columns(a: np.ndarray) -> np.ndarray:
     return (a - lo) / span
 
 
+class _LatentCacheMixin:
+    """Row-index plumbing for the training latent cache (t2ms_amd/latent_cache.py)."""
+    latents = None          # device tensor (N,64,w) once attached
+
+    def attach_latents(self, latents):
+        if latents.shape[0] != len(self):
+            raise ValueError(f"latent cache has {latents.shape[0]} rows, dataset has {len(self)}")
+        self.latents = latents
+        return self
+
+    def _item(self, i):
+        base = (self.text[i], self.samples[i], self.embedding[i])
+        return base if self.latents is None else base + (i,)
+
+
 def _parse_embedding(cell, literal: bool) -> np.ndarray:
     if literal:
         return np.asarray(ast.literal_eval(cell), dtype=np.float64)
@@ -67,7 +84,7 @@ def load_table(name: str, data_root: str):
     return series, texts, emb
 
 
-class T2SDataset(Dataset):
+class T2SDataset(_LatentCacheMixin, Dataset):
     def __init__(self, name="Agriculture", data_root="./Data/MMD", window=24, proportion=0.99, seed=123,
                  period="train", max_length=32):
         assert period in ("train", "test"), "period must be train or test."
@@ -84,13 +101,13 @@ class T2SDataset(Dataset):
         self.sample_num = self.samples.shape[0]
 
     def __getitem__(self, i):
-        return self.text[i], self.samples[i], self.embedding[i]
+        return self._item(i)
 
     def __len__(self):
         return self.sample_num
 
 
-class SyntheticT2SDataset(Dataset):
+class SyntheticT2SDataset(_LatentCacheMixin, Dataset):
     """Offline stand-in with the same item contract: U[0,1] series, unit-norm 128-d embeddings."""
 
     def __init__(self, n: int, length: int, seed: int = 2025):
@@ -102,7 +119,7 @@ class SyntheticT2SDataset(Dataset):
         self.len, self.var_num, self.sample_num = length, 1, n
 
     def __getitem__(self, i):
-        return self.text[i], self.samples[i], self.embedding[i]
+        return self._item(i)
 
     def __len__(self):
         return self.sample_num

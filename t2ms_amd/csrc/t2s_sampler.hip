@@ -164,23 +164,54 @@ __global__ __launch_bounds__(256) void p_sample_rows_kernel(const float* __restr
     reinterpret_cast<f32x4*>(out)[idx] = c0 * (x - c1 * e) + c2 * z;
 }
 
-// F.mse_loss (mean over all elements): ONE workgroup, fixed summation order -> deterministic
-__global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                   float* __restrict__ out, size_t n) {
-    __shared__ float part[16];
+// F.mse_loss (mean over all elements), deterministic: every workgroup sums a fixed contiguous
+// chunk in a fixed order into mse_part[], the last one to finish adds the partials in index order.
+// The scratch is per device and shared by all calls: t2s_mse calls on ONE device must not overlap
+// (they never do on a single stream).
+constexpr int MSE_MAX_WGS = 1024;
+__device__ float mse_part[MSE_MAX_WGS];
+__device__ unsigned int mse_done = 0;
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, size_t n) {
+    __shared__ float part[4];
+    __shared__ bool last;
+    const size_t n4 = n >> 2;
+    const size_t per = (n4 + gridDim.x - 1) / gridDim.x;          // float4 per workgroup
+    const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < n4 ? lo + per : n4;
     float acc = 0.f;
-    for (size_t i = threadIdx.x; i < n; i += 1024) {
-        const float d = a[i] - b[i];
-        acc += d * d;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const f32x4 d = reinterpret_cast<const f32x4*>(a)[i] - reinterpret_cast<const f32x4*>(b)[i];
+        acc += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
     }
+    if (blockIdx.x == gridDim.x - 1)                                // ragged tail (n % 4 elements)
+        for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
+            const float d = a[i] - b[i];
+            acc += d * d;
+        }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        float s = 0.f;
-        for (int i = 0; i < 16; ++i) s += part[i];
-        *out = s / (float)n;
+        __hip_atomic_store(&mse_part[blockIdx.x], (part[0] + part[1]) + (part[2] + part[3]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = atomicAdd(&mse_done, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    float s = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)        // fixed assignment, fixed order below
+        s += __hip_atomic_load(&mse_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *out = ((part[0] + part[1]) + (part[2] + part[3])) / (float)n;
+        mse_done = 0;
     }
 }
 
@@ -247,7 +278,9 @@ extern "C" int t2s_ddpm_p_sample(const float* xt, const float* eps_hat, const in
 
 extern "C" int t2s_mse(const float* a, const float* b, float* out, uint64_t n, void* stream) {
     T2S_REQUIRE(a && b && out && n > 0, "t2s_mse: bad argument");
-    mse_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(a, b, out, (size_t)n);
+    const size_t n4 = n / 4;
+    const int wgs = (int)(n4 / 1024 < 1 ? 1 : (n4 / 1024 > MSE_MAX_WGS ? MSE_MAX_WGS : n4 / 1024));   // >= 4 float4 per thread
+    mse_kernel<<<wgs, 256, 0, (hipStream_t)stream>>>(a, b, out, (size_t)n);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }

@@ -275,6 +275,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dY
     }
 }
 
+// Rows per workgroup of the two "tail" backward kernels below: their small gradients are reduced
+// in the workgroup and flushed with one set of atomics, so fewer, longer workgroups mean
+// proportionally less same-address atomic traffic (64 rows per workgroup cost 1.1-1.7 ms at
+// B=1152, almost all of it atomics).
+constexpr int TAIL_ROWS = 512;
+
 // final layer backward (transformer.py:182-191): dout (S,64,30) -> dx (M,128) and grads of
 // ln.weight, ln.bias, linear_emb_to_patch.{weight,bias}.  32 lanes per token row.
 __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout,
@@ -292,8 +298,8 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
     for (int p = 0; p < 4; ++p) w[p] = *reinterpret_cast<const f32x4*>(ow + p * D + c4 * 4);
     f32x4 a_g = {0, 0, 0, 0}, a_b = {0, 0, 0, 0}, a_w[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     float a_ob[4] = {0.f, 0.f, 0.f, 0.f};
-    const int row0 = blockIdx.x * 64;
-    for (int rr = rg; rr < 64; rr += 8) {
+    const int row0 = blockIdx.x * TAIL_ROWS;
+    for (int rr = rg; rr < TAIL_ROWS; rr += 8) {
         const int row = row0 + rr;
         if (row >= M) break;   // uniform per 32-lane group; shuffles below stay inside the group
         const size_t idx = (size_t)row * 32 + c4;
@@ -378,8 +384,8 @@ __global__ __launch_bounds__(256) void patchify_bwd_kernel(const float* __restri
     for (int i = 0; i < 16; ++i) a_cw[i] = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) a_cb[i] = 0.f;
-    const int row0 = blockIdx.x * 64;
-    for (int rr = rg; rr < 64; rr += 8) {
+    const int row0 = blockIdx.x * TAIL_ROWS;
+    for (int rr = rg; rr < TAIL_ROWS; rr += 8) {
         const int row = row0 + rr;
         if (row >= M) break;
         const f32x4 g = reinterpret_cast<const f32x4*>(dtok)[(size_t)row * 32 + c4];
@@ -682,7 +688,9 @@ int gemm(const float* A, const f32x4* Wp, const float* bias, float* out, int M, 
 
 // weight (and, if db != NULL, bias) gradient of a linear layer
 int wgrad(const float* dY, const float* X, float* dW, float* db, int M, int N, int K, hipStream_t st) {
-    const int rows_per_wg = 1024;
+    // enough row slabs to fill the chip even for the adaLN linear (M = sequences, not tokens)
+    int rows_per_wg = ((M / 256 + WG_ROWS - 1) / WG_ROWS) * WG_ROWS;   // about one slab per CU ...
+    rows_per_wg = rows_per_wg < WG_ROWS ? WG_ROWS : (rows_per_wg > 1024 ? 1024 : rows_per_wg);   // ... within [64, 1024]
     const int ngroups = (N / 32 + 3) / 4;
     dim3 grid((M + rows_per_wg - 1) / rows_per_wg, ngroups * (K / 128));
     wgrad_kernel<<<grid, 256, 0, st>>>(dY, X, dW, db, M, N, K, rows_per_wg);
@@ -826,7 +834,7 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
         T2S_HIP_CHECK(hipMemsetAsync(z.p, 0, z.n * sizeof(float), st));
     }
     // ---- final layer
-    final_bwd_kernel<<<(M + 63) / 64, 256, 0, st>>>(ws->x_in[NBLK], dout, h->ln_w, h->ln_b, h->out_w, ws->dx, g->ln_w,
+    final_bwd_kernel<<<(M + TAIL_ROWS - 1) / TAIL_ROWS, 256, 0, st>>>(ws->x_in[NBLK], dout, h->ln_w, h->ln_b, h->out_w, ws->dx, g->ln_w,
                                                     g->ln_b, g->out_w, g->out_b, M);
     T2S_LAUNCH_CHECK();
     const bool bf = ws->dtype == T2S_TRAIN_BF16;
@@ -890,7 +898,7 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
         T2S_LAUNCH_CHECK();
     }
     // ---- patchify
-    patchify_bwd_kernel<<<(M + 63) / 64, 256, 0, st>>>(ws->dx, ws->lat, S, h->conv_w, h->conv_b, h->patch_w, g->patch_w,
+    patchify_bwd_kernel<<<(M + TAIL_ROWS - 1) / TAIL_ROWS, 256, 0, st>>>(ws->dx, ws->lat, S, h->conv_w, h->conv_b, h->patch_w, g->patch_w,
                                                        g->patch_b, g->conv_w, g->conv_b, M);
     T2S_LAUNCH_CHECK();
     // ---- adaLN linear: mod = silu(c) W_ada^T + b_ada  (per block rows [768 i, 768 i + 768) of the (3072,128) stack)

@@ -4,6 +4,7 @@ pre-interpolation `before` (B,64,6) of an L=24 encode)."""
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import t2s_oracle as O
@@ -49,3 +50,28 @@ def test_config1_plumbing_chain_matches_oracle():
             x_ref = O.ddpm_p_sample(tab, x_ref, u + cfg * (c - u), t, noises[j])
     scale = max(1.0, float(x_ref.abs().max()))
     assert float((x - x_ref).abs().max()) < 1e-4 * scale and bool(torch.isfinite(x).all())
+
+
+def test_latent_cache_plumbing_cpu():
+    """datasets with attached latents hand out row indices; the mixed collate keeps them
+    per length group; encode_all chunks through the encoder (a stand-in here: no GPU on this tier)."""
+    import numpy as np
+    from datafactory.dataset import SyntheticT2SDataset
+    from datafactory.dataloader import AlternatingDataset, custom_collate_fn
+    from t2ms_amd import latent_cache
+    parts = [SyntheticT2SDataset(10, L, seed=L) for L in (24, 48, 96)]
+    ds = AlternatingDataset(*parts)
+    assert len(ds[0][0]) == 3                                   # (text, x, emb) without a cache
+    enc = lambda x: (x.mean(dim=1, keepdim=True).repeat(1, 4), None)    # noqa: E731
+    by_len = latent_cache.attach(ds, enc, torch.device("cpu"))
+    assert sorted(by_len) == [24, 48, 96] and by_len[48].shape == (10, 4)
+    batch = [ds[i] for i in (0, 3, 12, 25, 29)]
+    groups = custom_collate_fn(batch)
+    assert [g[1].shape[1] for g in groups] == [24, 48, 96]
+    for texts, xs, embs, idx in groups:
+        assert idx.dtype == torch.long and len(texts) == xs.shape[0] == embs.shape[0] == idx.shape[0]
+        z = by_len[int(xs.shape[1])][idx]
+        np.testing.assert_allclose(z[:, 0].numpy(), xs.float().mean(dim=1).numpy(), rtol=1e-6)
+    assert groups[1][3].tolist() == [2] and groups[2][3].tolist() == [5, 9]
+    with pytest.raises(ValueError):
+        parts[0].attach_latents(torch.zeros(3, 4))

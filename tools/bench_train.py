@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--length", type=int, default=96)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--cache_latents", action="store_true", help="encode once (t2ms_amd/latent_cache.py) instead of per step")
     a = ap.parse_args()
     rank, local_rank, world = tdist.env_world()
     torch.cuda.set_device(local_rank)
@@ -39,11 +40,19 @@ def main():
     x = synth.make_series(1, B, a.length).to(dev)
     text = synth.make_text_embeddings(1, B).to(dev)
     t_ar = 0.0
+    z_all = None
+    if a.cache_latents:
+        from t2ms_amd import latent_cache
+        z_all = latent_cache.encode_all(m.encoder, x, dev)
+        rows = torch.arange(B, device=dev)
 
     def step():
         nonlocal t_ar
-        with torch.no_grad():
-            z, _ = m.encoder(x)
+        if z_all is not None:
+            z = z_all[rows]                       # the gather a cached training step does
+        else:
+            with torch.no_grad():
+                z, _ = m.encoder(x)
         t = torch.floor(torch.rand(B, device=dev) * 100).long()
         eps = torch.randn_like(z)
         xt, _ = ddpm.q_sample(z, t, eps)
@@ -68,7 +77,7 @@ def main():
         flops = 3 * 0.977e9 * B * world * a.steps
         print(json.dumps({"metric": f"DiT training samples/sec (config 4 shape, {a.dtype})", "value": B * world * a.steps / el,
                           "unit": "samples/s", "n_gpus": world, "ms_per_step": el / a.steps * 1e3, "per_gpu_batch": B,
-                          "dtype": a.dtype, "tflops": flops / el / 1e12, "allreduce_share": t_ar / el,
+                          "dtype": a.dtype, "latents": "cached" if a.cache_latents else "encoded per step", "tflops": flops / el / 1e12, "allreduce_share": t_ar / el,
                           "loss": float(loss.item())}))
     tdist.barrier(dist, dev)
 

@@ -11,8 +11,10 @@ len(loader) * epochs) stepped per outer batch (mix) / per epoch (split) (train.p
 frozen LA-VAE encoder grafted as `model.encoder` (train.py:30-33); the 30 % per-batch
 classifier-free text drop drawn from the CPU generator (train.py:120-122); checkpoint
 dict(model, optimizer, epoch, loss_list) every 1000 epochs and at the end (train.py:132-136).
-Additions: `--synthetic N`, `--random_init`, `--seed`; under torchrun each rank trains on its
-slice of every batch and gradients are averaged.
+Additions: `--synthetic N`, `--random_init`, `--seed`, `--bf16` (BASELINE config 4 arithmetic),
+`--no_cache_latents` (by default the frozen encoder runs once per dataset row instead of once per
+step: t2ms_amd/latent_cache.py); under torchrun each rank trains on its slice of every batch and
+gradients are averaged.
 """
 import argparse
 import os
@@ -47,14 +49,17 @@ def _load_vae(args, device):
     return vae.float().to(device).eval()
 
 
-def train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world):
+def train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world, latents=None, idx=None):
     """One optimisation step on this rank's slice of the batch (train.py:103-127 / 60-87)."""
     lo, hi = tdist.shard_rows(x_1.shape[0], rank, world)
     if hi == lo:
         return None
     emb = emb[lo:hi].float().to(device)
-    with torch.no_grad():
-        z, _ = model.encoder(x_1[lo:hi].float().to(device).contiguous())      # frozen LA-VAE (train.py:31-33,106)
+    if latents is not None and idx is not None:
+        z = latents[idx[lo:hi].to(device)]                                         # pre-encoded rows (latent cache)
+    else:
+        with torch.no_grad():
+            z, _ = model.encoder(x_1[lo:hi].float().to(device).contiguous())      # frozen LA-VAE (train.py:31-33,106)
     n = z.shape[0]
     if args.backbone == "flowmatching":
         t = torch.round(torch.rand(n, device=device) * args.total_step) / args.total_step
@@ -101,6 +106,8 @@ def train(args):
     if backbone is None:
         raise ValueError("No backbone found")
     model.encoder = vae.encoder
+    if args.bf16:
+        model.set_train_dtype("bf16")
     for name, p in model.named_parameters():
         if "encoder" in name:
             p.requires_grad = not args.usepretrainedvae
@@ -116,13 +123,22 @@ def train(args):
         model.load_state_dict(ck["model"])
         opt.load_state_dict(ck["optimizer"])
         start_epoch, loss_list = ck["epoch"] + 1, ck["loss_list"]
+    cache = None
+    if args.cache_latents:
+        from t2ms_amd import latent_cache
+        cache = latent_cache.attach(dataset, model.encoder, device)
+        if rank == 0:
+            print("latent cache: " + ", ".join(f"L={L}: {tuple(z.shape)}" for L, z in sorted(cache.items())))
     model.train()
     t0, seen = time.time(), 0
     for epoch in range(start_epoch, args.epochs):
         for batch, data in enumerate(dataloader):
             groups = data if args.mix_train else [data]
-            for (_, x_1, emb) in groups:
-                loss = train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world)
+            for group in groups:
+                x_1, emb = group[1], group[2]
+                idx = group[3] if len(group) > 3 else None
+                loss = train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world,
+                                  cache.get(int(x_1.shape[1])) if cache else None, idx)
                 if loss is None:
                     continue
                 seen += x_1.shape[0]
@@ -159,6 +175,9 @@ def get_args(argv=None):
     p.add_argument("--synthetic", type=int, default=0, help="serve N synthetic rows per length instead of the CSVs")
     p.add_argument("--random_init", action="store_true", help="seeded synthetic LA-VAE / DiT weights")
     p.add_argument("--split_train", action="store_true", help="mix_train=False (argparse type=bool cannot be switched off)")
+    p.add_argument("--bf16", action="store_true", help="bf16 MFMA operands / saved activations (fp32 accumulate and master weights)")
+    p.add_argument("--no_cache_latents", dest="cache_latents", action="store_false",
+                   help="re-run the frozen LA-VAE encoder on every step, as the reference does")
     args = p.parse_args(argv)
     if args.split_train:
         args.mix_train = False
