@@ -98,138 +98,179 @@ struct BGemmArgs {
     __bf16* v;
 };
 
-template <int K, int PRO, int EPI>
-__global__ __launch_bounds__(256) void bgemm_kernel(const BGemmArgs a) {
-    constexpr int KS = K / 16;
+// Weights-stationary streaming GEMM: one persistent workgroup of 12 waves per CU keeps the whole
+// packed weight (<= 96 KB bf16) and the bias in LDS; every wave then streams 32-token tiles:
+// rows from HBM -> registers (prologue) -> N/32 x K/16 MFMAs with the A operand read from LDS
+// (lane-linear 16-byte fragments: conflict-free ds_read_b128) -> epilogue stores.  No barrier after
+// the weight load; HBM latency is hidden by the three waves per SIMD.
+constexpr int BG_THREADS = 768;
+
+template <int K, int N, int PRO, int EPI>
+__global__ __launch_bounds__(BG_THREADS) void bgemm_kernel(const BGemmArgs a) {
+    constexpr int KS = K / 16, NT = N / 32;
     static_assert(PRO != BPRO_LN || K == 128, "LayerNorm prologue is over d_model = 128");
+    extern __shared__ __attribute__((aligned(16))) char wl[];
+    bf16x8* wlds = reinterpret_cast<bf16x8*>(wl);
+    float* blds = reinterpret_cast<float*>(wl + (size_t)N * K * 2);
+    for (int c = threadIdx.x; c < N * K / 8; c += BG_THREADS) wlds[c] = a.Wp[c];
+    for (int c = threadIdx.x; c < N; c += BG_THREADS) blds[c] = a.bias != nullptr ? a.bias[c] : 0.f;
+    __syncthreads();
+
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = blockIdx.x * 4 + wave;        // 32-token tile of this wave (never straddles a sequence)
-    if (tile * 32 >= a.M) return;
     const int h = lane >> 5, i = lane & 31;
-    const size_t row = (size_t)tile * 32 + i;
-
-    // ---- B operand: this lane's token, k = 16s + 8h + 0..7
-    bf16x8 xf[KS];
-    if constexpr (PRO == BPRO_LN) {
-        const float* xr = reinterpret_cast<const float*>(a.A) + row * K + 8 * h;
-        f32x4 v[KS][2];
-        float s = 0.f;
-#pragma unroll
-        for (int t = 0; t < KS; ++t) {
-            v[t][0] = *reinterpret_cast<const f32x4*>(xr + 16 * t);
-            v[t][1] = *reinterpret_cast<const f32x4*>(xr + 16 * t + 4);
-            s += ((v[t][0].x + v[t][0].y) + (v[t][0].z + v[t][0].w)) + ((v[t][1].x + v[t][1].y) + (v[t][1].z + v[t][1].w));
-        }
-        s += xhalf(s);
-        const float mean = s * (1.0f / 128.0f);
-        float ss = 0.f;
-#pragma unroll
-        for (int t = 0; t < KS; ++t) {
-            v[t][0] -= mean;
-            v[t][1] -= mean;
-            ss += ((v[t][0].x * v[t][0].x + v[t][0].y * v[t][0].y) + (v[t][0].z * v[t][0].z + v[t][0].w * v[t][0].w)) +
-                  ((v[t][1].x * v[t][1].x + v[t][1].y * v[t][1].y) + (v[t][1].z * v[t][1].z + v[t][1].w * v[t][1].w));
-        }
-        ss += xhalf(ss);
-        const float rstd = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+    const int n_tiles = a.M >> 5;
+    for (int tile = blockIdx.x * (BG_THREADS / 64) + wave; tile < n_tiles; tile += gridDim.x * (BG_THREADS / 64)) {
+        const size_t row = (size_t)tile * 32 + i;   // a 32-token tile never straddles a sequence (480 = 15 x 32)
         const int seq = tile / (NTOK / 32);
-        const float* mrow = a.mod + (size_t)seq * MODROW + 8 * h;
+        const int tok = (tile - seq * (NTOK / 32)) * 32 + i;
+
+        // ---- B operand: this lane's token, k = 16s + 8h + 0..7
+        bf16x8 xf[KS];
+        if constexpr (PRO == BPRO_LN) {
+            const float* xr = reinterpret_cast<const float*>(a.A) + row * K + 8 * h;
+            f32x4 v[KS][2];
+            float s = 0.f;
 #pragma unroll
-        for (int t = 0; t < KS; ++t) {
-            const f32x4 sc0 = *reinterpret_cast<const f32x4*>(mrow + a.scale_off + 16 * t);
-            const f32x4 sc1 = *reinterpret_cast<const f32x4*>(mrow + a.scale_off + 16 * t + 4);
-            const f32x4 sh0 = *reinterpret_cast<const f32x4*>(mrow + a.shift_off + 16 * t);
-            const f32x4 sh1 = *reinterpret_cast<const f32x4*>(mrow + a.shift_off + 16 * t + 4);
-            xf[t] = pack8((v[t][0] * rstd) * (1.0f + sc0) + sh0, (v[t][1] * rstd) * (1.0f + sc1) + sh1);
-            if (a.save_A != nullptr) *reinterpret_cast<bf16x8*>(a.save_A + row * K + 16 * t + 8 * h) = xf[t];
-        }
-    } else {
-        const __bf16* ar = reinterpret_cast<const __bf16*>(a.A) + row * K + 8 * h;
+            for (int t = 0; t < KS; ++t) {
+                v[t][0] = *reinterpret_cast<const f32x4*>(xr + 16 * t);
+                v[t][1] = *reinterpret_cast<const f32x4*>(xr + 16 * t + 4);
+                s += ((v[t][0].x + v[t][0].y) + (v[t][0].z + v[t][0].w)) + ((v[t][1].x + v[t][1].y) + (v[t][1].z + v[t][1].w));
+            }
+            s += xhalf(s);
+            const float mean = s * (1.0f / 128.0f);
+            float ss = 0.f;
 #pragma unroll
-        for (int t = 0; t < KS; ++t) {
-            xf[t] = *reinterpret_cast<const bf16x8*>(ar + 16 * t);
-            if constexpr (PRO == BPRO_GELU) {
-                f32x8 u = unpack8(xf[t]);
+            for (int t = 0; t < KS; ++t) {
+                v[t][0] -= mean;
+                v[t][1] -= mean;
+                ss += ((v[t][0].x * v[t][0].x + v[t][0].y * v[t][0].y) + (v[t][0].z * v[t][0].z + v[t][0].w * v[t][0].w)) +
+                      ((v[t][1].x * v[t][1].x + v[t][1].y * v[t][1].y) + (v[t][1].z * v[t][1].z + v[t][1].w * v[t][1].w));
+            }
+            ss += xhalf(ss);
+            const float rstd = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+            const float* mrow = a.mod + (size_t)seq * MODROW + 8 * h;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) u[e] = gelu_tanh(u[e]);
-                xf[t] = __builtin_convertvector(u, bf16x8);
+            for (int t = 0; t < KS; ++t) {
+                const f32x4 sc0 = *reinterpret_cast<const f32x4*>(mrow + a.scale_off + 16 * t);
+                const f32x4 sc1 = *reinterpret_cast<const f32x4*>(mrow + a.scale_off + 16 * t + 4);
+                const f32x4 sh0 = *reinterpret_cast<const f32x4*>(mrow + a.shift_off + 16 * t);
+                const f32x4 sh1 = *reinterpret_cast<const f32x4*>(mrow + a.shift_off + 16 * t + 4);
+                xf[t] = pack8((v[t][0] * rstd) * (1.0f + sc0) + sh0, (v[t][1] * rstd) * (1.0f + sc1) + sh1);
                 if (a.save_A != nullptr) *reinterpret_cast<bf16x8*>(a.save_A + row * K + 16 * t + 8 * h) = xf[t];
             }
+        } else {
+            const __bf16* ar = reinterpret_cast<const __bf16*>(a.A) + row * K + 8 * h;
+#pragma unroll
+            for (int t = 0; t < KS; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(ar + 16 * t);
+            if constexpr (PRO == BPRO_GELU) {
+#pragma unroll
+                for (int t = 0; t < KS; ++t) {
+                    f32x8 u = unpack8(xf[t]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) u[e] = gelu_tanh(u[e]);
+                    xf[t] = __builtin_convertvector(u, bf16x8);
+                    if (a.save_A != nullptr) *reinterpret_cast<bf16x8*>(a.save_A + row * K + 16 * t + 8 * h) = xf[t];
+                }
+            }
         }
-    }
 
-    // ---- n-tiles: 32 outputs each, K/16 MFMAs; result register r = output 8(r>>2) + 4h + (r&3)
-    const bf16x8* wp = a.Wp + lane;
-    const int n_tiles = a.N >> 5;
-    const int seq = tile / (NTOK / 32);
-    const int tok = (tile - seq * (NTOK / 32)) * 32 + i;
-    for (int nt = 0; nt < n_tiles; ++nt) {
-        f32x16 acc;
+        // ---- n-tiles: 32 outputs each, K/16 MFMAs; result register r = output 8(r>>2) + 4h + (r&3).
+        // The LDS offset is made opaque per token tile: the weights are loop-invariant, and hipcc would
+        // otherwise hoist ALL their LDS reads out of the persistent loop into (spilled) registers.
+        int wo = lane;
+        asm volatile("" : "+v"(wo));
+#pragma unroll 2
+        for (int nt = 0; nt < NT; ++nt) {
+            bf16x4 aux4[4];
+            if constexpr (EPI == BEPI_GELUBWD) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                for (int g = 0; g < 4; ++g)
+                    aux4[g] = *reinterpret_cast<const bf16x4*>(a.aux + row * N + nt * 32 + 8 * g + 4 * h);
+            }
+            f32x16 acc;
 #pragma unroll
-        for (int t = 0; t < KS; ++t) acc = mfma16(wp[((size_t)nt * KS + t) * 64], xf[t], acc);
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int col = nt * 32 + 8 * g + 4 * h;
-            f32x4 y = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-            if (a.bias != nullptr) y += *reinterpret_cast<const f32x4*>(a.bias + col);
-            if constexpr (EPI == BEPI_BF16) {
-                *reinterpret_cast<bf16x4*>(a.out + row * a.N + col) = pack4(y);
-            } else if constexpr (EPI == BEPI_GELUBWD) {
-                const f32x4 u = unpack4(*reinterpret_cast<const bf16x4*>(a.aux + row * a.N + col));
-                y.x *= gelu_tanh_grad(u.x); y.y *= gelu_tanh_grad(u.y);
-                y.z *= gelu_tanh_grad(u.z); y.w *= gelu_tanh_grad(u.w);
-                *reinterpret_cast<bf16x4*>(a.out + row * a.N + col) = pack4(y);
-            } else {   // BEPI_QKV: n-tile nt = (which, head)
-                __bf16* base = (nt >> 2) == 0 ? a.q : ((nt >> 2) == 1 ? a.k : a.v);
-                const int head = nt & 3;
-                *reinterpret_cast<bf16x4*>(base + (((size_t)seq * NH + head) * NTOK + tok) * DH + 8 * g + 4 * h) = pack4(y);
+            for (int t = 0; t < KS; ++t) acc = mfma16(wlds[(nt * KS + t) * 64 + wo], xf[t], acc);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = nt * 32 + 8 * g + 4 * h;
+                f32x4 y = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                y += *reinterpret_cast<const f32x4*>(blds + col);
+                if constexpr (EPI == BEPI_BF16) {
+                    *reinterpret_cast<bf16x4*>(a.out + row * N + col) = pack4(y);
+                } else if constexpr (EPI == BEPI_GELUBWD) {
+                    const f32x4 u = unpack4(aux4[g]);
+                    y.x *= gelu_tanh_grad(u.x); y.y *= gelu_tanh_grad(u.y);
+                    y.z *= gelu_tanh_grad(u.z); y.w *= gelu_tanh_grad(u.w);
+                    *reinterpret_cast<bf16x4*>(a.out + row * N + col) = pack4(y);
+                } else {   // BEPI_QKV: n-tile nt = (which, head)
+                    __bf16* base = (nt >> 2) == 0 ? a.q : ((nt >> 2) == 1 ? a.k : a.v);
+                    const int head = nt & 3;
+                    *reinterpret_cast<bf16x4*>(base + (((size_t)seq * NH + head) * NTOK + tok) * DH + 8 * g + 4 * h) = pack4(y);
+                }
             }
         }
     }
 }
 
-template <int K, int PRO, int EPI>
+template <int K, int N, int PRO, int EPI>
 inline int launch_bgemm(const BGemmArgs& a, hipStream_t st) {
-    if (a.M <= 0 || a.M % 32 != 0 || a.N % 32 != 0) {
-        set_error("bgemm: M=%d / N=%d must be positive multiples of 32", a.M, a.N);
+    if (a.M <= 0 || a.M % 32 != 0 || a.N != N) {
+        set_error("bgemm: M=%d must be a positive multiple of 32 and N=%d must equal %d", a.M, a.N, N);
         return T2S_E_INVALID;
     }
-    bgemm_kernel<K, PRO, EPI><<<(a.M / 32 + 3) / 4, 256, 0, st>>>(a);
+    constexpr int lds = N * K * 2 + N * 4;
+    static int n_cu = 0;
+    static bool attr = false;   // first call is never under stream capture (training is not captured)
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        T2S_HIP_CHECK(hipGetDevice(&dev));
+        T2S_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount;
+    }
+    if (!attr) {
+        T2S_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bgemm_kernel<K, N, PRO, EPI>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    const int tiles = a.M / 32, per_wg = BG_THREADS / 64;
+    int grid = (tiles + per_wg - 1) / per_wg < n_cu ? (tiles + per_wg - 1) / per_wg : n_cu;
+    if (const char* e = getenv("T2S_BG_GRID")) grid = (tiles + per_wg - 1) / per_wg < atoi(e) ? (tiles + per_wg - 1) / per_wg : atoi(e);
+    bgemm_kernel<K, N, PRO, EPI><<<grid, BG_THREADS, lds, st>>>(a);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }
 
 // ------------------------------------------------------------------------------------------ wgrad
 // dW[n][k] += sum_rows dY[row][n] X[row][k],  db[n] += sum_rows dY[row][n]   (fp32 atomics).
-// grid (row slabs, N/128); wave w of a workgroup owns outputs [128 y + 32 w, +32) x all K inputs.
-// MFMA: D[n][k] = sum_row A[n][row] B[row][k]: both operands are read column-wise out of row-major
-// LDS tiles (64 rows per pass, row strides 320 B / 2K+64 B: four consecutive rows land in disjoint
-// bank quarters, so the transposed reads are conflict-free).
-template <int K>
-__global__ __launch_bounds__(256) void wgrad16_kernel(const __bf16* __restrict__ dY, const __bf16* __restrict__ X,
+// grid (row slabs, N/128, K/128); wave w of a workgroup owns outputs [128 y + 32 w, +32) x inputs
+// [128 z, +128).  MFMA: D[n][k] = sum_row A[n][row] B[row][k]: both operands are read column-wise
+// out of row-major LDS tiles (64 rows per pass, row stride 320 B: four consecutive rows land in
+// disjoint bank quarters, so the transposed reads are conflict-free).
+static __global__ __launch_bounds__(256) void wgrad16_kernel(const __bf16* __restrict__ dY, const __bf16* __restrict__ X,
                                                       float* __restrict__ dW, float* __restrict__ db, int M, int N,
-                                                      int rows_per_wg) {
-    constexpr int KT = K / 32;
+                                                      int K, int rows_per_wg) {
+    constexpr int KT = 4;          // 32-wide k-tiles per workgroup
     constexpr int SLAB = 64;
-    constexpr int YSTR = 320;
-    constexpr int XSTR = 2 * K + 64;
-    __shared__ __attribute__((aligned(16))) char ys[SLAB * YSTR];
-    __shared__ __attribute__((aligned(16))) char xs[SLAB * XSTR];
+    constexpr int STR = 320;
+    __shared__ __attribute__((aligned(16))) char ys[SLAB * STR];
+    __shared__ __attribute__((aligned(16))) char xs[SLAB * STR];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
     const int ncol0 = blockIdx.y * 128;
+    const int kcol0 = blockIdx.z * 128;
     const int r0 = blockIdx.x * rows_per_wg;
     const int r1 = min(M, r0 + rows_per_wg);
     // transposed-read addressing of this lane
     const int grp = (lane >> 4) & 3, nhalf = grp & 1, q = (lane & 15) >> 2, p = lane & 3;
     const int rbase = 8 * half + q;                      // row inside a 16-row k-step (second read: +4)
-    const char* ya = ys + rbase * YSTR + (wave * 32 + 16 * nhalf + 4 * p) * 2;
-    const char* xa = xs + rbase * XSTR + (16 * nhalf + 4 * p) * 2;
+    const char* ya = ys + rbase * STR + (wave * 32 + 16 * nhalf + 4 * p) * 2;
+    const char* xa = xs + rbase * STR + (16 * nhalf + 4 * p) * 2;
 
     f32x16 acc[KT], accb;
 #pragma unroll
@@ -242,28 +283,39 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const __bf16* __restrict__
     const bf16x8 ones = __builtin_convertvector(onesf, bf16x8);
     const bf16x8 zero8 = __builtin_convertvector(onesf * 0.f, bf16x8);
 
+    // Register-staged, software-pipelined row slabs: the NEXT slab's 16-byte chunks are in flight
+    // while the current one is multiplied (one chunk at a time behind vmcnt(0) cost 8 HBM round
+    // trips per slab).  Rows past the end are clamped for the load and zeroed afterwards.
+    constexpr int CH = SLAB * 16 / 256;             // 16-byte chunks of each operand per thread and slab
+    bf16x8 py[CH], px[CH];
+    auto fetch = [&](int rs) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int idx = tid + 256 * u, rr = idx >> 4, c = idx & 15;
+            const int row = min(rs + rr, r1 - 1);
+            py[u] = *reinterpret_cast<const bf16x8*>(dY + (size_t)row * N + ncol0 + c * 8);
+            px[u] = *reinterpret_cast<const bf16x8*>(X + (size_t)row * K + kcol0 + c * 8);
+        }
+    };
+    fetch(r0);
     for (int rs = r0; rs < r1; rs += SLAB) {
         __syncthreads();   // previous pass fully consumed
-        for (int idx = tid; idx < SLAB * 16; idx += 256) {
-            const int rr = idx >> 4, c = idx & 15, row = rs + rr;
-            bf16x8 v = zero8;
-            if (row < r1) v = *reinterpret_cast<const bf16x8*>(dY + (size_t)row * N + ncol0 + c * 8);
-            *reinterpret_cast<bf16x8*>(ys + rr * YSTR + c * 16) = v;
-        }
-        for (int idx = tid; idx < SLAB * (K / 8); idx += 256) {
-            const int rr = idx / (K / 8), c = idx - rr * (K / 8), row = rs + rr;
-            bf16x8 v = zero8;
-            if (row < r1) v = *reinterpret_cast<const bf16x8*>(X + (size_t)row * K + c * 8);
-            *reinterpret_cast<bf16x8*>(xs + rr * XSTR + c * 16) = v;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int idx = tid + 256 * u, rr = idx >> 4, c = idx & 15;
+            const bool in = rs + rr < r1;
+            *reinterpret_cast<bf16x8*>(ys + rr * STR + c * 16) = in ? py[u] : zero8;
+            *reinterpret_cast<bf16x8*>(xs + rr * STR + c * 16) = in ? px[u] : zero8;
         }
         __syncthreads();
+        if (rs + SLAB < r1) fetch(rs + SLAB);
 #pragma unroll
         for (int s = 0; s < SLAB / 16; ++s) {
-            const bf16x8 af = join_tr(lds_tr16(ya + (16 * s) * YSTR), lds_tr16(ya + (16 * s + 4) * YSTR));
-            accb = mfma16(af, ones, accb);
+            const bf16x8 af = join_tr(lds_tr16(ya + (16 * s) * STR), lds_tr16(ya + (16 * s + 4) * STR));
+            if (blockIdx.z == 0) accb = mfma16(af, ones, accb);
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
-                const bf16x8 bf = join_tr(lds_tr16(xa + (16 * s) * XSTR + t * 64), lds_tr16(xa + (16 * s + 4) * XSTR + t * 64));
+                const bf16x8 bf = join_tr(lds_tr16(xa + (16 * s) * STR + t * 64), lds_tr16(xa + (16 * s + 4) * STR + t * 64));
                 acc[t] = mfma16(af, bf, acc[t]);
             }
         }
@@ -273,24 +325,21 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const __bf16* __restrict__
     for (int t = 0; t < KT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            atomicAdd(dW + (size_t)(ncol0 + wave * 32 + acc_row(r, half)) * K + t * 32 + j, acc[t][r]);
-    if (db != nullptr && j == 0) {
+            atomicAdd(dW + (size_t)(ncol0 + wave * 32 + acc_row(r, half)) * K + kcol0 + t * 32 + j, acc[t][r]);
+    if (db != nullptr && j == 0 && blockIdx.z == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) atomicAdd(db + ncol0 + wave * 32 + acc_row(r, half), accb[r]);
     }
 }
 
 inline int launch_wgrad16(const __bf16* dY, const __bf16* X, float* dW, float* db, int M, int N, int K, hipStream_t st) {
-    if (N % 128 != 0 || (K != 128 && K != 256) || M <= 0) {
+    if (N % 128 != 0 || K % 128 != 0 || M <= 0) {
         set_error("wgrad16: unsupported shape M=%d N=%d K=%d", M, N, K);
         return T2S_E_INVALID;
     }
     const int rows_per_wg = 1024;
-    dim3 grid((M + rows_per_wg - 1) / rows_per_wg, N / 128);
-    if (K == 128)
-        wgrad16_kernel<128><<<grid, 256, 0, st>>>(dY, X, dW, db, M, N, rows_per_wg);
-    else
-        wgrad16_kernel<256><<<grid, 256, 0, st>>>(dY, X, dW, db, M, N, rows_per_wg);
+    dim3 grid((M + rows_per_wg - 1) / rows_per_wg, N / 128, K / 128);
+    wgrad16_kernel<<<grid, 256, 0, st>>>(dY, X, dW, db, M, N, K, rows_per_wg);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }

@@ -666,14 +666,14 @@ int pack16(const float* W, bf16x8* P, int N, int K, int transpose, hipStream_t s
     return T2S_OK;
 }
 
-template <int K, int PRO, int EPI>
-int bgemm(const void* A, const bf16x8* Wp, const float* bias, __bf16* out, int M, int N, hipStream_t st,
+template <int K, int N, int PRO, int EPI>
+int bgemm(const void* A, const bf16x8* Wp, const float* bias, __bf16* out, int M, int n_out, hipStream_t st,
           const float* mod = nullptr, int shift_off = 0, int scale_off = 0, __bf16* save_A = nullptr,
           const __bf16* aux = nullptr, __bf16* q = nullptr, __bf16* k = nullptr, __bf16* v = nullptr) {
     BGemmArgs a{};
-    a.A = A; a.Wp = Wp; a.bias = bias; a.out = out; a.M = M; a.N = N; a.mod = mod; a.shift_off = shift_off;
+    a.A = A; a.Wp = Wp; a.bias = bias; a.out = out; a.M = M; a.N = n_out; a.mod = mod; a.shift_off = shift_off;
     a.scale_off = scale_off; a.save_A = save_A; a.aux = aux; a.q = q; a.k = k; a.v = v;
-    return launch_bgemm<K, PRO, EPI>(a, st);
+    return launch_bgemm<K, N, PRO, EPI>(a, st);
 }
 
 template <int K, int NT, int PRO, int EPI>
@@ -772,18 +772,18 @@ int t2s_dit_train_forward(t2s_dit* h, const t2s_dit_weights* w, const float* x, 
     for (int i = 0; i < NBLK && bf; ++i) {
         const int base = i * MODW;
         // a1 = mod(LN1(x_in)) -> bf16; q,k,v = a1 Wqkv^T + b -> bf16 heads
-        if ((rc = bgemm<128, BPRO_LN, BEPI_QKV>(ws->x_in[i], ws->qkv_f16[i], h->qkv_b[i], nullptr, M, 3 * D, st, ws->mod,
+        if ((rc = bgemm<128, 384, BPRO_LN, BEPI_QKV>(ws->x_in[i], ws->qkv_f16[i], h->qkv_b[i], nullptr, M, 3 * D, st, ws->mod,
                                                  base + 0 * D, base + 1 * D, ws->a1h[i], nullptr, ws->qh[i], ws->kh[i], ws->vh[i])))
             return rc;
         if ((rc = attn16_train_fwd(ws->qh[i], ws->kh[i], ws->vh[i], ws->oh[i], ws->lse[i], S * NH, st))) return rc;
-        if ((rc = bgemm<128, BPRO_BF16, BEPI_BF16>(ws->oh[i], ws->proj_f16[i], h->proj_b[i], ws->ph[i], M, D, st))) return rc;
+        if ((rc = bgemm<128, 128, BPRO_BF16, BEPI_BF16>(ws->oh[i], ws->proj_f16[i], h->proj_b[i], ws->ph[i], M, D, st))) return rc;
         gate_res_kernel<<<(M * 32 + 255) / 256, 256, 0, st>>>(ws->x_in[i], ws->ph[i], ws->mod, base + 2 * D, ws->x_mid[i], M);
         T2S_LAUNCH_CHECK();
         // a2 = mod(LN2(x_mid)); u = a2 W1^T + b1; g = gelu(u) (saved for the fc2 weight gradient); f = g W2^T + b2
-        if ((rc = bgemm<128, BPRO_LN, BEPI_BF16>(ws->x_mid[i], ws->fc1_f16[i], h->fc1_b[i], ws->uh[i], M, 2 * D, st, ws->mod,
+        if ((rc = bgemm<128, 256, BPRO_LN, BEPI_BF16>(ws->x_mid[i], ws->fc1_f16[i], h->fc1_b[i], ws->uh[i], M, 2 * D, st, ws->mod,
                                                   base + 3 * D, base + 4 * D, ws->a2h[i])))
             return rc;
-        if ((rc = bgemm<256, BPRO_GELU, BEPI_BF16>(ws->uh[i], ws->fc2_f16[i], h->fc2_b[i], ws->fh[i], M, D, st, nullptr, 0, 0,
+        if ((rc = bgemm<256, 128, BPRO_GELU, BEPI_BF16>(ws->uh[i], ws->fc2_f16[i], h->fc2_b[i], ws->fh[i], M, D, st, nullptr, 0, 0,
                                                     ws->gh[i])))
             return rc;
         gate_res_kernel<<<(M * 32 + 255) / 256, 256, 0, st>>>(ws->x_mid[i], ws->fh[i], ws->mod, base + 5 * D, ws->x_in[i + 1], M);
@@ -846,24 +846,24 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
         T2S_LAUNCH_CHECK();
         if ((rc = launch_wgrad16(ws->t1h, ws->gh[i], b.fc2_w, b.fc2_b, M, D, 2 * D, st))) return rc;
         // du = (df W2) * gelu'(u)
-        if ((rc = bgemm<128, BPRO_BF16, BEPI_GELUBWD>(ws->t1h, ws->fc2_t16[i], nullptr, ws->t2h, M, 2 * D, st, nullptr, 0, 0,
+        if ((rc = bgemm<128, 256, BPRO_BF16, BEPI_GELUBWD>(ws->t1h, ws->fc2_t16[i], nullptr, ws->t2h, M, 2 * D, st, nullptr, 0, 0,
                                                        nullptr, ws->uh[i])))
             return rc;
         if ((rc = launch_wgrad16(ws->t2h, ws->a2h[i], b.fc1_w, b.fc1_b, M, 2 * D, D, st))) return rc;
         // da2 = du W1
-        if ((rc = bgemm<256, BPRO_BF16, BEPI_BF16>(ws->t2h, ws->fc1_t16[i], nullptr, ws->t1h, M, D, st))) return rc;
+        if ((rc = bgemm<256, 128, BPRO_BF16, BEPI_BF16>(ws->t2h, ws->fc1_t16[i], nullptr, ws->t1h, M, D, st))) return rc;
         ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t1h, ws->x_mid[i], ws->mod, base + 3 * D, base + 4 * D, ws->dx, ws->dmod);
         T2S_LAUNCH_CHECK();
         // ---- attention branch: x_mid = x_in + g1 * p
         gate_bwd_kernel<<<S, 256, 0, st>>>(ws->dx, ws->ph[i], ws->mod, base + 2 * D, ws->t1h, ws->dmod);     // t1 = dp
         T2S_LAUNCH_CHECK();
         if ((rc = launch_wgrad16(ws->t1h, ws->oh[i], b.proj_w, b.proj_b, M, D, D, st))) return rc;
-        if ((rc = bgemm<128, BPRO_BF16, BEPI_BF16>(ws->t1h, ws->proj_t16[i], nullptr, ws->t4h, M, D, st))) return rc;   // do
+        if ((rc = bgemm<128, 128, BPRO_BF16, BEPI_BF16>(ws->t1h, ws->proj_t16[i], nullptr, ws->t4h, M, D, st))) return rc;   // do
         if ((rc = attn16_bwd(ws->qh[i], ws->kh[i], ws->vh[i], ws->oh[i], ws->t4h, ws->lse[i], ws->dsum, ws->t3h, S * NH, st)))
             return rc;
         if ((rc = launch_wgrad16(ws->t3h, ws->a1h[i], b.qkv_w, b.qkv_b, M, 3 * D, D, st))) return rc;
         // da1 = dqkv Wqkv
-        if ((rc = bgemm<384, BPRO_BF16, BEPI_BF16>(ws->t3h, ws->qkv_t16[i], nullptr, ws->t1h, M, D, st))) return rc;
+        if ((rc = bgemm<384, 128, BPRO_BF16, BEPI_BF16>(ws->t3h, ws->qkv_t16[i], nullptr, ws->t1h, M, D, st))) return rc;
         ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t1h, ws->x_in[i], ws->mod, base + 0 * D, base + 1 * D, ws->dx, ws->dmod);
         T2S_LAUNCH_CHECK();
     }
