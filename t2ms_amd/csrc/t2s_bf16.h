@@ -245,13 +245,17 @@ inline int launch_bgemm(const BGemmArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------ wgrad
-// dW[n][k] += sum_rows dY[row][n] X[row][k],  db[n] += sum_rows dY[row][n]   (fp32 atomics).
+// dW[n][k] = sum_rows dY[row][n] X[row][k],  db[n] = sum_rows dY[row][n], in two deterministic
+// stages: wgrad16_kernel writes one fp32 partial tile (128 x 128, + 128 bias sums) per workgroup
+// with plain coalesced stores, wgrad16_reduce_kernel adds the partials of all row slabs in slab
+// order.  (fp32 atomics into the 64 KB gradient tile from ~500 workgroups ran at 0.3 TB/s and
+// cost 100 us per call -- more than streaming the operands.)
 // grid (row slabs, N/128, K/128); wave w of a workgroup owns outputs [128 y + 32 w, +32) x inputs
 // [128 z, +128).  MFMA: D[n][k] = sum_row A[n][row] B[row][k]: both operands are read column-wise
 // out of row-major LDS tiles (64 rows per pass, row stride 320 B: four consecutive rows land in
 // disjoint bank quarters, so the transposed reads are conflict-free).
 static __global__ __launch_bounds__(256) void wgrad16_kernel(const __bf16* __restrict__ dY, const __bf16* __restrict__ X,
-                                                      float* __restrict__ dW, float* __restrict__ db, int M, int N,
+                                                      float* __restrict__ part, float* __restrict__ bpart, int M, int N,
                                                       int K, int rows_per_wg) {
     constexpr int KT = 4;          // 32-wide k-tiles per workgroup
     constexpr int SLAB = 64;
@@ -320,26 +324,93 @@ static __global__ __launch_bounds__(256) void wgrad16_kernel(const __bf16* __res
             }
         }
     }
+    // partial tile of this workgroup: [(x * gy + y) * gz + z][128 n][128 k], bias sums [(x * gy + y)][128]
     const int j = lane & 31;
+    float* pt = part + ((size_t)(blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * (128 * 128);
 #pragma unroll
     for (int t = 0; t < KT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            atomicAdd(dW + (size_t)(ncol0 + wave * 32 + acc_row(r, half)) * K + kcol0 + t * 32 + j, acc[t][r]);
-    if (db != nullptr && j == 0 && blockIdx.z == 0) {
+        for (int r = 0; r < 16; ++r) pt[(wave * 32 + acc_row(r, half)) * 128 + t * 32 + j] = acc[t][r];
+    if (j == 0 && blockIdx.z == 0) {
+        float* bp = bpart + (size_t)(blockIdx.x * gridDim.y + blockIdx.y) * 128;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) atomicAdd(db + ncol0 + wave * 32 + acc_row(r, half), accb[r]);
+        for (int r = 0; r < 16; ++r) bp[wave * 32 + acc_row(r, half)] = accb[r];
     }
 }
 
-inline int launch_wgrad16(const __bf16* dY, const __bf16* X, float* dW, float* db, int M, int N, int K, hipStream_t st) {
+// Stage 2: dW[128 y + n][128 z + k] = sum_x part[x][y][z][n][k]; db[128 y + n] = sum_x bpart[x][y][n].
+// grid (65, gy * gz): blockIdx.x < 64 = a 1 KiB run of the tile, 64 = the bias; the four 64-lane
+// groups of a workgroup take every 4th slab, then their sums are added in a fixed order.
+static __global__ __launch_bounds__(256) void wgrad16_reduce_kernel(const float* __restrict__ part,
+                                                                    const float* __restrict__ bpart, float* __restrict__ dW,
+                                                                    float* __restrict__ db, int gx, int gy, int gz, int K) {
+    __shared__ f32x4 red[4][64];
+    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int tile = blockIdx.y, y = tile / gz, z = tile - y * gz;
+    const bool bias = blockIdx.x == 64;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (!bias) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(part) + (size_t)tile * 4096 + blockIdx.x * 64 + c;
+#pragma unroll 8
+        for (int x = sl; x < gx; x += 4) acc += p[(size_t)x * gy * gz * 4096];
+    } else if (z == 0 && c < 32) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(bpart) + (size_t)y * 32 + c;
+#pragma unroll 8
+        for (int x = sl; x < gx; x += 4) acc += p[(size_t)x * gy * 32];
+    }
+    red[sl][c] = acc;
+    __syncthreads();
+    if (sl != 0) return;
+    const f32x4 s = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (!bias) {
+        const int e = blockIdx.x * 256 + c * 4, n = e >> 7, k = e & 127;
+        *reinterpret_cast<f32x4*>(dW + (size_t)(y * 128 + n) * K + z * 128 + k) = s;
+    } else if (z == 0 && c < 32 && db != nullptr) {
+        *reinterpret_cast<f32x4*>(db + y * 128 + c * 4) = s;
+    }
+}
+
+// workgroups of stage 1 for a given shape (about three per CU in total) and the scratch they need
+inline void wgrad16_plan(int M, int N, int K, int n_cu, int* rows_per_wg, int* gx) {
+    const int tiles = (N / 128) * (K / 128);
+    int per = 3 * n_cu / tiles;                               // row slabs
+    per = per < 1 ? 1 : per;
+    int rows = ((M + per - 1) / per + 63) / 64 * 64;
+    rows = rows < 256 ? 256 : rows;
+    *rows_per_wg = rows;
+    *gx = (M + rows - 1) / rows;
+}
+inline size_t wgrad16_scratch_floats(int M, int n_cu) {      // worst case over the DiT's four linears
+    size_t worst = 0;
+    const int shapes[4][2] = {{128, 128}, {256, 128}, {384, 128}, {128, 256}};
+    for (auto& sh : shapes) {
+        int rows, gx;
+        wgrad16_plan(M, sh[0], sh[1], n_cu, &rows, &gx);
+        const size_t need = (size_t)gx * (sh[0] / 128) * (sh[1] / 128) * (128 * 128) + (size_t)gx * (sh[0] / 128) * 128;
+        worst = need > worst ? need : worst;
+    }
+    return worst;
+}
+
+inline int launch_wgrad16(const __bf16* dY, const __bf16* X, float* dW, float* db, int M, int N, int K, float* scratch,
+                          size_t scratch_floats, int n_cu, hipStream_t st) {
     if (N % 128 != 0 || K % 128 != 0 || M <= 0) {
         set_error("wgrad16: unsupported shape M=%d N=%d K=%d", M, N, K);
         return T2S_E_INVALID;
     }
-    const int rows_per_wg = 1024;
-    dim3 grid((M + rows_per_wg - 1) / rows_per_wg, N / 128, K / 128);
-    wgrad16_kernel<<<grid, 256, 0, st>>>(dY, X, dW, db, M, N, K, rows_per_wg);
+    int rows_per_wg, gx;
+    wgrad16_plan(M, N, K, n_cu, &rows_per_wg, &gx);
+    const int gy = N / 128, gz = K / 128;
+    const size_t part_floats = (size_t)gx * gy * gz * (128 * 128);
+    if (part_floats + (size_t)gx * gy * 128 > scratch_floats) {
+        set_error("wgrad16: scratch of %zu floats is too small for M=%d N=%d K=%d", scratch_floats, M, N, K);
+        return T2S_E_INVALID;
+    }
+    float* part = scratch;
+    float* bpart = scratch + part_floats;
+    wgrad16_kernel<<<dim3(gx, gy, gz), 256, 0, st>>>(dY, X, part, bpart, M, N, K, rows_per_wg);
+    T2S_LAUNCH_CHECK();
+    wgrad16_reduce_kernel<<<dim3(65, gy * gz), 256, 0, st>>>(part, bpart, dW, db, gx, gy, gz, K);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }

@@ -61,6 +61,9 @@ struct t2s_train_ws {
     __bf16* act16 = nullptr;
     __bf16 *a1h[NBLK], *qh[NBLK], *kh[NBLK], *vh[NBLK], *oh[NBLK], *ph[NBLK], *a2h[NBLK], *uh[NBLK], *gh[NBLK], *fh[NBLK];
     __bf16 *t1h = nullptr, *t2h = nullptr, *t3h = nullptr, *t4h = nullptr;   // (M,128) (M,256) (M,384) (M,128)
+    float* wg_scratch = nullptr;   // partial weight-gradient tiles (wgrad16 stage 1 -> stage 2)
+    size_t wg_scratch_floats = 0;
+    int n_cu = 0;
 };
 
 namespace {
@@ -621,6 +624,15 @@ int ensure_ws(t2s_dit* h, int S) {
                  o_dmod = atake((size_t)S * MODROW);
     // t1 also serves the adaLN weight gradient as an (S,768) fp32 temporary in both modes
     const size_t o_t1 = atake(bf ? (size_t)S * MODW : M * D);
+    size_t o_wgs = 0;
+    if (bf) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail("device query", 0.0);
+        w->n_cu = prop.multiProcessorCount;
+        w->wg_scratch_floats = wgrad16_scratch_floats((int)M, w->n_cu);
+        o_wgs = atake(w->wg_scratch_floats);
+    }
     size_t o_t2a = 0, o_t2b = 0, o_t3 = 0, o_t4 = 0;
     if (!bf) { o_t2a = atake(M * 2 * D); o_t2b = atake(M * 2 * D); o_t3 = atake(M * 3 * D); o_t4 = atake(M * D); }
     if (hipMalloc(&w->act, aoff * sizeof(float)) != hipSuccess) return fail("activations", aoff * 4 / 1e6);
@@ -637,6 +649,7 @@ int ensure_ws(t2s_dit* h, int S) {
     w->silu_c = A + o_silu; w->mod = A + o_mod; w->c = A + o_c; w->lat = A + o_lat; w->dx = A + o_dx;
     w->dsum = A + o_dsum; w->dmod = A + o_dmod; w->t1 = A + o_t1;
     if (!bf) { w->t2a = A + o_t2a; w->t2b = A + o_t2b; w->t3 = A + o_t3; w->t4 = A + o_t4; }
+    if (bf) w->wg_scratch = A + o_wgs;
     // ---- bf16 arena
     if (bf) {
         size_t hoff = 0;
@@ -844,12 +857,12 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
         // ---- MLP branch: x_out = x_mid + g2 * f
         gate_bwd_kernel<<<S, 256, 0, st>>>(ws->dx, ws->fh[i], ws->mod, base + 5 * D, ws->t1h, ws->dmod);     // t1 = df
         T2S_LAUNCH_CHECK();
-        if ((rc = launch_wgrad16(ws->t1h, ws->gh[i], b.fc2_w, b.fc2_b, M, D, 2 * D, st))) return rc;
+        if ((rc = launch_wgrad16(ws->t1h, ws->gh[i], b.fc2_w, b.fc2_b, M, D, 2 * D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
         // du = (df W2) * gelu'(u)
         if ((rc = bgemm<128, 256, BPRO_BF16, BEPI_GELUBWD>(ws->t1h, ws->fc2_t16[i], nullptr, ws->t2h, M, 2 * D, st, nullptr, 0, 0,
                                                        nullptr, ws->uh[i])))
             return rc;
-        if ((rc = launch_wgrad16(ws->t2h, ws->a2h[i], b.fc1_w, b.fc1_b, M, 2 * D, D, st))) return rc;
+        if ((rc = launch_wgrad16(ws->t2h, ws->a2h[i], b.fc1_w, b.fc1_b, M, 2 * D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
         // da2 = du W1
         if ((rc = bgemm<256, 128, BPRO_BF16, BEPI_BF16>(ws->t2h, ws->fc1_t16[i], nullptr, ws->t1h, M, D, st))) return rc;
         ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t1h, ws->x_mid[i], ws->mod, base + 3 * D, base + 4 * D, ws->dx, ws->dmod);
@@ -857,11 +870,11 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
         // ---- attention branch: x_mid = x_in + g1 * p
         gate_bwd_kernel<<<S, 256, 0, st>>>(ws->dx, ws->ph[i], ws->mod, base + 2 * D, ws->t1h, ws->dmod);     // t1 = dp
         T2S_LAUNCH_CHECK();
-        if ((rc = launch_wgrad16(ws->t1h, ws->oh[i], b.proj_w, b.proj_b, M, D, D, st))) return rc;
+        if ((rc = launch_wgrad16(ws->t1h, ws->oh[i], b.proj_w, b.proj_b, M, D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
         if ((rc = bgemm<128, 128, BPRO_BF16, BEPI_BF16>(ws->t1h, ws->proj_t16[i], nullptr, ws->t4h, M, D, st))) return rc;   // do
         if ((rc = attn16_bwd(ws->qh[i], ws->kh[i], ws->vh[i], ws->oh[i], ws->t4h, ws->lse[i], ws->dsum, ws->t3h, S * NH, st)))
             return rc;
-        if ((rc = launch_wgrad16(ws->t3h, ws->a1h[i], b.qkv_w, b.qkv_b, M, 3 * D, D, st))) return rc;
+        if ((rc = launch_wgrad16(ws->t3h, ws->a1h[i], b.qkv_w, b.qkv_b, M, 3 * D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
         // da1 = dqkv Wqkv
         if ((rc = bgemm<384, 128, BPRO_BF16, BEPI_BF16>(ws->t3h, ws->qkv_t16[i], nullptr, ws->t1h, M, D, st))) return rc;
         ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t1h, ws->x_in[i], ws->mod, base + 0 * D, base + 1 * D, ws->dx, ws->dmod);

@@ -66,5 +66,21 @@ int main(int argc, char** argv) {
     run<128, 256, BPRO_BF16, BEPI_GELUBWD>("128->256 gelubwd", M, A, Wp, bias, out, mod, nullptr, aux, 5 * u);
     run<256, 128, BPRO_BF16, BEPI_BF16>("256->128 plain", M, A, Wp, bias, out, mod, nullptr, aux, 3 * u);
     run<384, 128, BPRO_BF16, BEPI_BF16>("384->128 plain", M, A, Wp, bias, out, mod, nullptr, aux, 4 * u);
+    // weight-gradient kernel: dW (N,K) += dY^T X
+    float* dW; hipMalloc(&dW, 384 * 256 * 4); hipMemset(dW, 0, 384 * 256 * 4);
+    const size_t scr = wgrad16_scratch_floats(M, 256); float* scratch; hipMalloc(&scratch, scr * 4);
+    const int shapes[4][2] = {{128, 128}, {256, 128}, {384, 128}, {128, 256}};
+    for (auto& sh : shapes) {
+        const int N = sh[0], K = sh[1];
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int w = 0; w < 2; ++w) launch_wgrad16((const __bf16*)out, (const __bf16*)A, dW, bias, M, N, K, scratch, scr, 256, 0);
+        hipEventRecord(e0, 0);
+        for (int r = 0; r < 5; ++r) launch_wgrad16((const __bf16*)out, (const __bf16*)A, dW, bias, M, N, K, scratch, scr, 256, 0);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+        const double bytes = (double)M * (N + K) * 2;
+        printf("wgrad16 N=%d K=%d  %8.1f us  %7.0f GB/s (single-read bytes) (%s)\n", N, K, ms / 5 * 1e3,
+               bytes / (ms / 5 * 1e-3) / 1e9, hipGetErrorString(hipGetLastError()));
+    }
     return 0;
 }
