@@ -225,16 +225,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ Y
 // 128-B rows per wave instruction).  The bias gradient falls out of the A operand for free.
 constexpr int WG_ROWS = 64;   // rows staged per LDS pass
 __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dY, const float* __restrict__ X,
-                                                    float* __restrict__ dW, float* __restrict__ db, int M, int N,
+                                                    float* __restrict__ part, float* __restrict__ bpart, int M, int N,
                                                     int K, int rows_per_wg) {
     __shared__ __attribute__((aligned(16))) float xs[WG_ROWS * 132];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5, j = lane & 31;
-    const int n_tiles = N >> 5;
-    const int ngroups = (n_tiles + 3) >> 2;           // groups of 4 n-tiles (one per wave)
-    const int kc = blockIdx.y / ngroups;              // 128-wide k-chunk
-    const int nt = (blockIdx.y % ngroups) * 4 + wave; // this wave's n-tile (may be past the end)
-    const bool live = nt < n_tiles;
+    const int kc = blockIdx.z;                        // 128-wide k-chunk
+    const int nt = blockIdx.y * 4 + wave;             // this wave's n-tile (N % 128 == 0)
     const int r0 = blockIdx.x * rows_per_wg;
     const int r1 = min(M, r0 + rows_per_wg);
     f32x16 acc[4];
@@ -243,7 +240,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dY
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float bsum = 0.f;
-    const float* ya = dY + (live ? nt * 32 + j : 0);
+    const float* ya = dY + nt * 32 + j;
     for (int rs = r0; rs < r1; rs += WG_ROWS) {
         __syncthreads();   // previous sub-slab fully consumed
         for (int idx = threadIdx.x; idx < WG_ROWS * 32; idx += 256) {
@@ -254,27 +251,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dY
             *reinterpret_cast<f32x4*>(xs + rr * 132 + c4 * 4) = v;
         }
         __syncthreads();
-        if (live) {
 #pragma unroll 4
-            for (int rr = 0; rr < WG_ROWS; rr += 2) {
-                const int row = rs + rr + half;
-                const float a = row < r1 ? ya[(size_t)row * N] : 0.f;
-                bsum += a;
-                const float* xb = xs + (rr + half) * 132 + j;
+        for (int rr = 0; rr < WG_ROWS; rr += 2) {
+            const int row = rs + rr + half;
+            const float a = row < r1 ? ya[(size_t)row * N] : 0.f;
+            bsum += a;
+            const float* xb = xs + (rr + half) * 132 + j;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = mfma32(a, xb[t * 32], acc[t]);
-            }
+            for (int t = 0; t < 4; ++t) acc[t] = mfma32(a, xb[t * 32], acc[t]);
         }
     }
-    if (!live) return;
+    // partial tile of this workgroup (summed over the row slabs by wgrad16_reduce_kernel, t2s_bf16.h)
+    float* pt = part + ((size_t)(blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * (128 * 128);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            atomicAdd(dW + (size_t)(nt * 32 + acc_row(r, half)) * K + kc * 128 + t * 32 + j, acc[t][r]);
-    if (db != nullptr && kc == 0) {
+        for (int r = 0; r < 16; ++r) pt[(wave * 32 + acc_row(r, half)) * 128 + t * 32 + j] = acc[t][r];
+    if (kc == 0) {
         bsum += xhalf(bsum);
-        if (half == 0) atomicAdd(db + nt * 32 + j, bsum);
+        if (half == 0) bpart[(size_t)(blockIdx.x * gridDim.y + blockIdx.y) * 128 + wave * 32 + j] = bsum;
     }
 }
 
@@ -625,12 +620,16 @@ int ensure_ws(t2s_dit* h, int S) {
     // t1 also serves the adaLN weight gradient as an (S,768) fp32 temporary in both modes
     const size_t o_t1 = atake(bf ? (size_t)S * MODW : M * D);
     size_t o_wgs = 0;
-    if (bf) {
+    {
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail("device query", 0.0);
         w->n_cu = prop.multiProcessorCount;
         w->wg_scratch_floats = wgrad16_scratch_floats((int)M, w->n_cu);
+        int rows, gx;                                            // the adaLN linear: M = S rows, (768,128)
+        wgrad16_plan(S, MODW, D, w->n_cu, &rows, &gx);
+        const size_t ada = (size_t)gx * (MODW / 128) * (128 * 128 + 128);
+        if (ada > w->wg_scratch_floats) w->wg_scratch_floats = ada;
         o_wgs = atake(w->wg_scratch_floats);
     }
     size_t o_t2a = 0, o_t2b = 0, o_t3 = 0, o_t4 = 0;
@@ -649,7 +648,7 @@ int ensure_ws(t2s_dit* h, int S) {
     w->silu_c = A + o_silu; w->mod = A + o_mod; w->c = A + o_c; w->lat = A + o_lat; w->dx = A + o_dx;
     w->dsum = A + o_dsum; w->dmod = A + o_dmod; w->t1 = A + o_t1;
     if (!bf) { w->t2a = A + o_t2a; w->t2b = A + o_t2b; w->t3 = A + o_t3; w->t4 = A + o_t4; }
-    if (bf) w->wg_scratch = A + o_wgs;
+    w->wg_scratch = A + o_wgs;
     // ---- bf16 arena
     if (bf) {
         size_t hoff = 0;
@@ -700,13 +699,18 @@ int gemm(const float* A, const f32x4* Wp, const float* bias, float* out, int M, 
 }
 
 // weight (and, if db != NULL, bias) gradient of a linear layer
-int wgrad(const float* dY, const float* X, float* dW, float* db, int M, int N, int K, hipStream_t st) {
-    // enough row slabs to fill the chip even for the adaLN linear (M = sequences, not tokens)
-    int rows_per_wg = ((M / 256 + WG_ROWS - 1) / WG_ROWS) * WG_ROWS;   // about one slab per CU ...
-    rows_per_wg = rows_per_wg < WG_ROWS ? WG_ROWS : (rows_per_wg > 1024 ? 1024 : rows_per_wg);   // ... within [64, 1024]
-    const int ngroups = (N / 32 + 3) / 4;
-    dim3 grid((M + rows_per_wg - 1) / rows_per_wg, ngroups * (K / 128));
-    wgrad_kernel<<<grid, 256, 0, st>>>(dY, X, dW, db, M, N, K, rows_per_wg);
+int wgrad(t2s_train_ws* ws, const float* dY, const float* X, float* dW, float* db, int M, int N, int K, hipStream_t st) {
+    T2S_REQUIRE(N % 128 == 0 && K % 128 == 0 && M > 0, "wgrad: unsupported shape M=%d N=%d K=%d", M, N, K);
+    int rows_per_wg, gx;
+    wgrad16_plan(M, N, K, ws->n_cu, &rows_per_wg, &gx);
+    const int gy = N / 128, gz = K / 128;
+    const size_t part_floats = (size_t)gx * gy * gz * (128 * 128);
+    T2S_REQUIRE(part_floats + (size_t)gx * gy * 128 <= ws->wg_scratch_floats, "wgrad: scratch too small for M=%d N=%d K=%d", M, N, K);
+    float* part = ws->wg_scratch;
+    float* bpart = ws->wg_scratch + part_floats;
+    wgrad_kernel<<<dim3(gx, gy, gz), 256, 0, st>>>(dY, X, part, bpart, M, N, K, rows_per_wg);
+    T2S_LAUNCH_CHECK();
+    wgrad16_reduce_kernel<<<dim3(65, gy * gz), 256, 0, st>>>(part, bpart, dW, db, gx, gy, gz, K);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }
@@ -888,12 +892,12 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
         T2S_LAUNCH_CHECK();
         gelu_kernel<<<((size_t)M * 64 + 255) / 256, 256, 0, st>>>(ws->u[i], ws->t2a, (size_t)M * 64);        // t2a = gelu(u)
         T2S_LAUNCH_CHECK();
-        if ((rc = wgrad(ws->t1, ws->t2a, b.fc2_w, b.fc2_b, M, D, 2 * D, st))) return rc;
+        if ((rc = wgrad(ws, ws->t1, ws->t2a, b.fc2_w, b.fc2_b, M, D, 2 * D, st))) return rc;
         // du = (df W2) * gelu'(u)      (dgrad = row GEMM on W2^T: out 256 <- in 128)
         if ((rc = gemm<128, 2, PRO_PLAIN, EPI_GELUBWD>(ws->t1, ws->fc2_t[i], nullptr, ws->t2b, M, 2 * D, st, nullptr, 0, 0,
                                                         nullptr, ws->u[i])))
             return rc;
-        if ((rc = wgrad(ws->t2b, ws->a2[i], b.fc1_w, b.fc1_b, M, 2 * D, D, st))) return rc;
+        if ((rc = wgrad(ws, ws->t2b, ws->a2[i], b.fc1_w, b.fc1_b, M, 2 * D, D, st))) return rc;
         // da2 = du W1 (out 128 <- in 256)
         if ((rc = gemm<256, 1, PRO_PLAIN, EPI_BIAS>(ws->t2b, ws->fc1_t[i], nullptr, ws->t1, M, D, st))) return rc;
         ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t1, ws->x_mid[i], ws->mod, base + 3 * D, base + 4 * D, ws->dx, ws->dmod);
@@ -901,10 +905,10 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
         // ---- attention branch: x_mid = x_in + g1 * p
         gate_bwd_kernel<<<S, 256, 0, st>>>(ws->dx, ws->p[i], ws->mod, base + 2 * D, ws->t1, ws->dmod);       // t1 = dp
         T2S_LAUNCH_CHECK();
-        if ((rc = wgrad(ws->t1, ws->o[i], b.proj_w, b.proj_b, M, D, D, st))) return rc;
+        if ((rc = wgrad(ws, ws->t1, ws->o[i], b.proj_w, b.proj_b, M, D, D, st))) return rc;
         if ((rc = gemm<128, 1, PRO_PLAIN, EPI_BIAS>(ws->t1, ws->proj_t[i], nullptr, ws->t4, M, D, st))) return rc;   // do
         if ((rc = attn_bwd(ws->q[i], ws->k[i], ws->v[i], ws->o[i], ws->t4, ws->lse[i], ws->dsum, ws->t3, S * NH, st))) return rc;
-        if ((rc = wgrad(ws->t3, ws->a1[i], b.qkv_w, b.qkv_b, M, 3 * D, D, st))) return rc;
+        if ((rc = wgrad(ws, ws->t3, ws->a1[i], b.qkv_w, b.qkv_b, M, 3 * D, D, st))) return rc;
         // da1 = dqkv Wqkv (out 128 <- in 384)
         if ((rc = gemm<384, 1, PRO_PLAIN, EPI_BIAS>(ws->t3, ws->qkv_t[i], nullptr, ws->t1, M, D, st))) return rc;
         ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t1, ws->x_in[i], ws->mod, base + 0 * D, base + 1 * D, ws->dx, ws->dmod);
@@ -919,7 +923,7 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
         // dmod block slice is strided (row stride MODROW): copy to a dense (S,768) temp first
         T2S_HIP_CHECK(hipMemcpy2DAsync(ws->t1, MODW * sizeof(float), ws->dmod + i * MODW, MODROW * sizeof(float),
                                        MODW * sizeof(float), S, hipMemcpyDeviceToDevice, st));
-        if ((rc = wgrad(ws->t1, ws->silu_c, g->blk[i].ada_w, g->blk[i].ada_b, S, MODW, D, st))) return rc;
+        if ((rc = wgrad(ws, ws->t1, ws->silu_c, g->blk[i].ada_w, g->blk[i].ada_b, S, MODW, D, st))) return rc;
     }
     return T2S_OK;
 }
