@@ -164,8 +164,9 @@ int t2s_dit_set_train_dtype(t2s_dit* h, int dtype);
 int t2s_dit_train_forward(t2s_dit* h, const t2s_dit_weights* w, const float* x, const float* temb,
                           int temb_rows, const float* text, float* out, int B, void* stream);
 /* Backward of the last t2s_dit_train_forward: dout (B,64,30) = dLoss/dout; writes (overwrites)
- * every gradient tensor of `g`.  Weight gradients are accumulated with fp32 atomics (order, hence
- * the last bits, may vary from run to run). */
+ * every gradient tensor of `g`.  The block weight / bias gradients are reduced in a fixed order
+ * (bit-reproducible); the small final-layer and patchify gradients (ln, linear_emb_to_patch,
+ * patch_emb, conv) are flushed with fp32 atomics, so their last bits may vary from run to run. */
 int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g, int B, void* stream);
 /* One fused AdamW update (torch.optim.AdamW semantics; train.py:37 uses lr 1e-4, weight_decay 0):
  * p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
