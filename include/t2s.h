@@ -163,6 +163,12 @@ int t2s_dit_set_train_dtype(t2s_dit* h, int dtype);
  * workspace on first use (not capturable). */
 int t2s_dit_train_forward(t2s_dit* h, const t2s_dit_weights* w, const float* x, const float* temb,
                           int temb_rows, const float* text, float* out, int B, void* stream);
+/* The attention forward of the T2S_TRAIN_BF16 path on fp32 buffers (converted to bf16 on the way
+ * in, back on the way out; synchronises the stream): q, k, v (n_seq*4, 480, 32) heads ->
+ * o_rows (n_seq*480, 128) token rows, lse (n_seq*4, 480) = log2-domain log-sum-exp of the scaled
+ * scores.  For tests / benchmarking of that kernel (incl. its stale-reference branch). */
+int t2s_attn_fwd_bf16(const float* q, const float* k, const float* v, float* o_rows, float* lse,
+                      int n_seq, void* stream);
 /* Backward of the last t2s_dit_train_forward: dout (B,64,30) = dLoss/dout; writes (overwrites)
  * every gradient tensor of `g`.  The block weight / bias gradients are reduced in a fixed order
  * (bit-reproducible); the small final-layer and patchify gradients (ln, linear_emb_to_patch,

@@ -82,6 +82,10 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(const __bf16* __restric
         f32x16 ot;
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[r] = 0.f;
+        // Sticky-reference softmax: the reference m_ref is the row max of the FIRST key block; later blocks
+        // are exponentiated against it without a max or an output rescale (the kernel is VALU-bound:
+        // that is a third of its vector work).  A block whose row sum shows the reference is stale by
+        // more than 2^40 re-references the running state (classic online-softmax step), wave-uniformly.
         float m_run = -INFINITY, l_lane = 0.f;
         for (int jb = 0; jb < NKB; ++jb) {
             f32x16 st;
@@ -89,24 +93,40 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(const __bf16* __restric
             for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
             for (int s = 0; s < 2; ++s) st = mfma16(row_frag(Ks, jb * 32, lane, s), qf[s], st);   // S^T[key][query], raw
-            float mloc = st[0];
+            if (jb == 0) {
+                float mloc = st[0];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[r]);
-            mloc = pair_max_f(mloc);
-            const float m_new = fmaxf(m_run, mloc);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * QS);
-            m_run = m_new;
-            const float mq = m_new * QS;
+                for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[r]);
+                m_run = pair_max_f(mloc);
+            }
+            float mq = m_run * QS;
+            f32x16 pt;
             float ps = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                st[r] = __builtin_amdgcn_exp2f(st[r] * QS - mq);
-                ps += st[r];
-                ot[r] *= alpha;
+                pt[r] = __builtin_amdgcn_exp2f(st[r] * QS - mq);
+                ps += pt[r];
             }
-            l_lane = l_lane * alpha + ps;
+            if (__any(!(ps < 1.0995116e12f))) {      // 2^40; also catches inf / NaN
+                float mloc = st[0];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) ot = mfma16(col_frag(Vs, jb * 32, lane, s), acc_frag(st, s), ot);   // O^T += V^T P^T
+                for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[r]);
+                const float m_new = fmaxf(m_run, pair_max_f(mloc));
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * QS);
+                m_run = m_new;
+                mq = m_new * QS;
+                ps = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pt[r] = __builtin_amdgcn_exp2f(st[r] * QS - mq);
+                    ps += pt[r];
+                    ot[r] *= alpha;
+                }
+                l_lane *= alpha;
+            }
+            l_lane += ps;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) ot = mfma16(col_frag(Vs, jb * 32, lane, s), acc_frag(pt, s), ot);   // O^T += V^T P^T
         }
         const float l_tot = pair_sum_f(l_lane);
         const float inv = 1.0f / l_tot;
@@ -287,3 +307,38 @@ int attn16_bwd(const __bf16* q, const __bf16* k, const __bf16* v, const __bf16* 
 }
 
 }  // namespace t2s
+
+// ------------------------------------------------------------------ C ABI: stand-alone bf16 attention forward
+namespace {
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) reinterpret_cast<t2s::bf16x4*>(dst)[i] = t2s::pack4(reinterpret_cast<const t2s::f32x4*>(src)[i]);
+}
+__global__ void bf16_to_f32_kernel(const __bf16* __restrict__ src, float* __restrict__ dst, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) reinterpret_cast<t2s::f32x4*>(dst)[i] = t2s::unpack4(reinterpret_cast<const t2s::bf16x4*>(src)[i]);
+}
+}  // namespace
+
+extern "C" int t2s_attn_fwd_bf16(const float* q, const float* k, const float* v, float* o_rows, float* lse, int n_seq,
+                                 void* stream) {
+    using namespace t2s;
+    T2S_REQUIRE(q && k && v && o_rows && lse && n_seq > 0, "t2s_attn_fwd_bf16: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)n_seq * NH * NTOK * DH;      // elements of each of q, k, v, o
+    __bf16* buf = nullptr;
+    T2S_HIP_CHECK(hipMalloc(&buf, 4 * n * sizeof(__bf16)));
+    const unsigned blocks = (unsigned)((n / 4 + 255) / 256);
+    f32_to_bf16_kernel<<<blocks, 256, 0, st>>>(q, buf, n / 4);
+    f32_to_bf16_kernel<<<blocks, 256, 0, st>>>(k, buf + n, n / 4);
+    f32_to_bf16_kernel<<<blocks, 256, 0, st>>>(v, buf + 2 * n, n / 4);
+    int rc = attn16_train_fwd(buf, buf + n, buf + 2 * n, buf + 3 * n, lse, n_seq * NH, st);
+    if (rc == T2S_OK) {
+        bf16_to_f32_kernel<<<blocks, 256, 0, st>>>(buf + 3 * n, o_rows, n / 4);
+        if (hipGetLastError() != hipSuccess) rc = T2S_E_HIP;
+    }
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(buf);
+    return rc;
+}
+

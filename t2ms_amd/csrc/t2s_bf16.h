@@ -376,7 +376,7 @@ inline void wgrad16_plan(int M, int N, int K, int n_cu, int* rows_per_wg, int* g
     int per = 3 * n_cu / tiles;                               // row slabs
     per = per < 1 ? 1 : per;
     int rows = ((M + per - 1) / per + 63) / 64 * 64;
-    rows = rows < 256 ? 256 : rows;
+    rows = rows < 64 ? 64 : rows;
     *rows_per_wg = rows;
     *gx = (M + rows - 1) / rows;
 }

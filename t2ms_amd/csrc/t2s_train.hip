@@ -139,15 +139,22 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
 // one workgroup per sequence.  da = grad wrt modulate(LN(x)); computes
 //   dshift = sum_tok da, dscale = sum_tok da * n, dn = da * (1 + scale),
 //   dx += rstd * (dn - mean(dn) - n * mean(dn * n))          (LayerNorm backward, eps 1e-6, no affine)
+// and, when f_next != NULL, the gate backward of the branch that is differentiated next
+// (gate_bwd_kernel) on the dx it has just produced: t_next = gate_next * dx, dgate_next = sum_tok dx * f_next
+// -- that saves one read of the fp32 gradient stream per branch.
 template <typename T>
 __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const T* __restrict__ da, const float* __restrict__ x,
                                                          const float* __restrict__ mod, int shift_off, int scale_off,
-                                                         float* __restrict__ dx, float* __restrict__ dmod) {
-    __shared__ f32x4 red[2][8][32];
+                                                         float* __restrict__ dx, float* __restrict__ dmod,
+                                                         const T* __restrict__ f_next, int gate_next_off,
+                                                         T* __restrict__ t_next) {
+    __shared__ f32x4 red[3][8][32];
     const int seq = blockIdx.x;
     const int c4 = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const f32x4 sc = *reinterpret_cast<const f32x4*>(mod + (size_t)seq * MODROW + scale_off + c4 * 4);
-    f32x4 a_sh = {0.f, 0.f, 0.f, 0.f}, a_sc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 gn = {0.f, 0.f, 0.f, 0.f};
+    if (f_next != nullptr) gn = *reinterpret_cast<const f32x4*>(mod + (size_t)seq * MODROW + gate_next_off + c4 * 4);
+    f32x4 a_sh = {0.f, 0.f, 0.f, 0.f}, a_sc = {0.f, 0.f, 0.f, 0.f}, a_gt = {0.f, 0.f, 0.f, 0.f};
     for (int tok = rg; tok < NTOK; tok += 8) {
         const size_t idx = ((size_t)seq * NTOK + tok) * 32 + c4;
         const f32x4 xv = reinterpret_cast<const f32x4*>(x)[idx];
@@ -174,17 +181,23 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const T* __restrict__ d
         }
         m1 *= (1.0f / 128.0f);
         m2 *= (1.0f / 128.0f);
-        const f32x4 r = (dn - m1 - n * m2) * rstd;
-        reinterpret_cast<f32x4*>(dx)[idx] = reinterpret_cast<const f32x4*>(dx)[idx] + r;
+        const f32x4 r = reinterpret_cast<const f32x4*>(dx)[idx] + (dn - m1 - n * m2) * rstd;
+        reinterpret_cast<f32x4*>(dx)[idx] = r;
+        if (f_next != nullptr) {
+            st4(t_next, idx, gn * r);
+            a_gt += r * ld4(f_next, idx);
+        }
     }
     red[0][rg][c4] = a_sh;
     red[1][rg][c4] = a_sc;
+    red[2][rg][c4] = a_gt;
     __syncthreads();
-    if (rg < 2) {
+    if (rg < 3) {
+        if (rg == 2 && f_next == nullptr) return;
         f32x4 s = red[rg][0][c4];
 #pragma unroll
         for (int i = 1; i < 8; ++i) s += red[rg][i][c4];
-        const int off = rg == 0 ? shift_off : scale_off;
+        const int off = rg == 0 ? shift_off : (rg == 1 ? scale_off : gate_next_off);
         *reinterpret_cast<f32x4*>(dmod + (size_t)seq * MODROW + off + c4 * 4) = s;
     }
 }
@@ -793,6 +806,8 @@ int t2s_dit_train_forward(t2s_dit* h, const t2s_dit_weights* w, const float* x, 
                                                  base + 0 * D, base + 1 * D, ws->a1h[i], nullptr, ws->qh[i], ws->kh[i], ws->vh[i])))
             return rc;
         if ((rc = attn16_train_fwd(ws->qh[i], ws->kh[i], ws->vh[i], ws->oh[i], ws->lse[i], S * NH, st))) return rc;
+        // p = o Wp^T + b; x_mid = x_in + g1 * p.  (Fusing the gate/residual into the GEMM epilogue was measured
+        // slower: the lane-per-token epilogue touches the fp32 stream in 32-byte pieces, 346 vs 82 + 123 us.)
         if ((rc = bgemm<128, 128, BPRO_BF16, BEPI_BF16>(ws->oh[i], ws->proj_f16[i], h->proj_b[i], ws->ph[i], M, D, st))) return rc;
         gate_res_kernel<<<(M * 32 + 255) / 256, 256, 0, st>>>(ws->x_in[i], ws->ph[i], ws->mod, base + 2 * D, ws->x_mid[i], M);
         T2S_LAUNCH_CHECK();
@@ -801,7 +816,7 @@ int t2s_dit_train_forward(t2s_dit* h, const t2s_dit_weights* w, const float* x, 
                                                   base + 3 * D, base + 4 * D, ws->a2h[i])))
             return rc;
         if ((rc = bgemm<256, 128, BPRO_GELU, BEPI_BF16>(ws->uh[i], ws->fc2_f16[i], h->fc2_b[i], ws->fh[i], M, D, st, nullptr, 0, 0,
-                                                    ws->gh[i])))
+                                                         ws->gh[i])))
             return rc;
         gate_res_kernel<<<(M * 32 + 255) / 256, 256, 0, st>>>(ws->x_mid[i], ws->fh[i], ws->mod, base + 5 * D, ws->x_in[i + 1], M);
         T2S_LAUNCH_CHECK();
@@ -858,30 +873,35 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
     for (int i = NBLK - 1; i >= 0 && bf; --i) {
         const int base = i * MODW;
         const t2s_dit_block_grads& b = g->blk[i];
-        // ---- MLP branch: x_out = x_mid + g2 * f
-        gate_bwd_kernel<<<S, 256, 0, st>>>(ws->dx, ws->fh[i], ws->mod, base + 5 * D, ws->t1h, ws->dmod);     // t1 = df
-        T2S_LAUNCH_CHECK();
+        // ---- MLP branch: x_out = x_mid + g2 * f.  t1 = df = g2 * dx and dgate2 come from the previous block's
+        // LN1 backward (merged gate backward) except for the last block
+        if (i == NBLK - 1) {
+            gate_bwd_kernel<<<S, 256, 0, st>>>(ws->dx, ws->fh[i], ws->mod, base + 5 * D, ws->t1h, ws->dmod);
+            T2S_LAUNCH_CHECK();
+        }
         if ((rc = launch_wgrad16(ws->t1h, ws->gh[i], b.fc2_w, b.fc2_b, M, D, 2 * D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
         // du = (df W2) * gelu'(u)
         if ((rc = bgemm<128, 256, BPRO_BF16, BEPI_GELUBWD>(ws->t1h, ws->fc2_t16[i], nullptr, ws->t2h, M, 2 * D, st, nullptr, 0, 0,
-                                                       nullptr, ws->uh[i])))
+                                                            nullptr, ws->uh[i])))
             return rc;
         if ((rc = launch_wgrad16(ws->t2h, ws->a2h[i], b.fc1_w, b.fc1_b, M, 2 * D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
-        // da2 = du W1
-        if ((rc = bgemm<256, 128, BPRO_BF16, BEPI_BF16>(ws->t2h, ws->fc1_t16[i], nullptr, ws->t1h, M, D, st))) return rc;
-        ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t1h, ws->x_mid[i], ws->mod, base + 3 * D, base + 4 * D, ws->dx, ws->dmod);
+        // da2 = du W1 -> t4
+        if ((rc = bgemm<256, 128, BPRO_BF16, BEPI_BF16>(ws->t2h, ws->fc1_t16[i], nullptr, ws->t4h, M, D, st))) return rc;
+        // LN2 backward into dx, merged with the attention branch's gate backward: t1 = dp = g1 * dx, dgate1
+        ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t4h, ws->x_mid[i], ws->mod, base + 3 * D, base + 4 * D, ws->dx, ws->dmod,
+                                             ws->ph[i], base + 2 * D, ws->t1h);
         T2S_LAUNCH_CHECK();
         // ---- attention branch: x_mid = x_in + g1 * p
-        gate_bwd_kernel<<<S, 256, 0, st>>>(ws->dx, ws->ph[i], ws->mod, base + 2 * D, ws->t1h, ws->dmod);     // t1 = dp
-        T2S_LAUNCH_CHECK();
         if ((rc = launch_wgrad16(ws->t1h, ws->oh[i], b.proj_w, b.proj_b, M, D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
         if ((rc = bgemm<128, 128, BPRO_BF16, BEPI_BF16>(ws->t1h, ws->proj_t16[i], nullptr, ws->t4h, M, D, st))) return rc;   // do
         if ((rc = attn16_bwd(ws->qh[i], ws->kh[i], ws->vh[i], ws->oh[i], ws->t4h, ws->lse[i], ws->dsum, ws->t3h, S * NH, st)))
             return rc;
         if ((rc = launch_wgrad16(ws->t3h, ws->a1h[i], b.qkv_w, b.qkv_b, M, 3 * D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
-        // da1 = dqkv Wqkv
-        if ((rc = bgemm<384, 128, BPRO_BF16, BEPI_BF16>(ws->t3h, ws->qkv_t16[i], nullptr, ws->t1h, M, D, st))) return rc;
-        ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t1h, ws->x_in[i], ws->mod, base + 0 * D, base + 1 * D, ws->dx, ws->dmod);
+        // da1 = dqkv Wqkv -> t4
+        if ((rc = bgemm<384, 128, BPRO_BF16, BEPI_BF16>(ws->t3h, ws->qkv_t16[i], nullptr, ws->t4h, M, D, st))) return rc;
+        // LN1 backward into dx, merged with the gate backward of block i-1's MLP branch
+        ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t4h, ws->x_in[i], ws->mod, base + 0 * D, base + 1 * D, ws->dx, ws->dmod,
+                                             i > 0 ? ws->fh[i - 1] : (const __bf16*)nullptr, (i - 1) * MODW + 5 * D, ws->t1h);
         T2S_LAUNCH_CHECK();
     }
     for (int i = NBLK - 1; i >= 0 && !bf; --i) {
@@ -900,7 +920,8 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
         if ((rc = wgrad(ws, ws->t2b, ws->a2[i], b.fc1_w, b.fc1_b, M, 2 * D, D, st))) return rc;
         // da2 = du W1 (out 128 <- in 256)
         if ((rc = gemm<256, 1, PRO_PLAIN, EPI_BIAS>(ws->t2b, ws->fc1_t[i], nullptr, ws->t1, M, D, st))) return rc;
-        ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t1, ws->x_mid[i], ws->mod, base + 3 * D, base + 4 * D, ws->dx, ws->dmod);
+        ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t1, ws->x_mid[i], ws->mod, base + 3 * D, base + 4 * D, ws->dx, ws->dmod,
+                                             (const float*)nullptr, 0, (float*)nullptr);
         T2S_LAUNCH_CHECK();
         // ---- attention branch: x_mid = x_in + g1 * p
         gate_bwd_kernel<<<S, 256, 0, st>>>(ws->dx, ws->p[i], ws->mod, base + 2 * D, ws->t1, ws->dmod);       // t1 = dp
@@ -911,7 +932,8 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
         if ((rc = wgrad(ws, ws->t3, ws->a1[i], b.qkv_w, b.qkv_b, M, 3 * D, D, st))) return rc;
         // da1 = dqkv Wqkv (out 128 <- in 384)
         if ((rc = gemm<384, 1, PRO_PLAIN, EPI_BIAS>(ws->t3, ws->qkv_t[i], nullptr, ws->t1, M, D, st))) return rc;
-        ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t1, ws->x_in[i], ws->mod, base + 0 * D, base + 1 * D, ws->dx, ws->dmod);
+        ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t1, ws->x_in[i], ws->mod, base + 0 * D, base + 1 * D, ws->dx, ws->dmod,
+                                             (const float*)nullptr, 0, (float*)nullptr);
         T2S_LAUNCH_CHECK();
     }
     // ---- patchify

@@ -227,3 +227,32 @@ def test_bf16_training_reduces_loss(dev):
         opt.step()
         losses.append(loss.item())
     assert np.isfinite(losses).all() and np.mean(losses[-3:]) < np.mean(losses[:3])
+
+
+def test_bf16_attention_forward_and_stale_reference_branch(dev):
+    """attn16_fwd_kernel through t2s_attn_fwd_bf16: output and log2-domain LSE against an fp64 softmax of
+    the bf16-rounded operands, with spikes that make the sticky reference (row max of the FIRST key
+    block) stale by far more than 2^40 at early and late key blocks."""
+    from t2ms_amd import _lib as L
+    rs = np.random.RandomState(33)
+    n_seq = 2
+    BH = n_seq * 4
+    q, k, v = (torch.from_numpy(rs.randn(BH, 480, 32).astype(np.float32)) for _ in range(3))
+    k[:, 333] = q[:, 100] * 5.0
+    k[:, 410] = q[:, 200] * 12.0                       # log2-domain jump of ~100 at key block 12
+    k[:, 0:32] = -q[:, 7:8] * 3.0 + 0.01 * k[:, 0:32]  # first block hugely negative for query 7 ...
+    k[:, 448] = q[:, 7] * 10.0                         # ... and its real maximum in block 14
+    qb, kb, vb = (t.to(torch.bfloat16).double() for t in (q, k, v))
+    s = (qb @ kb.transpose(-1, -2)) * 32 ** -0.5
+    ref = torch.softmax(s, dim=-1) @ vb
+    lse_ref = torch.logsumexp(s, dim=-1) / np.log(2.0)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    od = torch.empty(n_seq * 480, 128, device=dev)
+    lsed = torch.empty(BH, 480, device=dev)
+    L.check(L.lib().t2s_attn_fwd_bf16(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), lsed.data_ptr(),
+                                      n_seq, L.stream_ptr(dev)), "t2s_attn_fwd_bf16")
+    o = od.cpu().reshape(n_seq, 480, 4, 32).permute(0, 2, 1, 3).reshape(BH, 480, 32).double()
+    assert torch.isfinite(o).all()
+    # P is rounded to bf16 before P.V and O is stored as bf16: ~2^-8 relative
+    assert float((o - ref).abs().max()) < 3e-2 and _rel(o, ref) < 6e-3
+    assert float((lsed.cpu().double() - lse_ref).abs().max()) < 2e-3
