@@ -136,6 +136,30 @@ def cpu_baseline(batch, diff_steps, cfg, length, n_cfg_steps=4):
                       f"extrapolated x{diff_steps}/{n_cfg_steps}; {t_step:.3f} s/step; CPU: {cpu_model}"}
 
 
+def alt_math_run(model, vae, args, dev, text):
+    """One extra batch of the same workload with the attention products in bf16x3 arithmetic (include/t2s.h
+    T2S_MATH_BF16X3: fp32-accurate, six bf16 MFMAs per product).  Reported NEXT TO the headline, never as it."""
+    from t2ms_amd.sampler import Sampler
+    model.set_math("bf16x3")
+    try:
+        s2 = Sampler(model, vae.decoder, args.backbone, args.diffusion_steps, args.cfg_scale, args.batch, args.length,
+                     dev, use_graph=not args.no_graph, seed=2025, row0=0)
+        s2.run(text, decode=True)                 # captures its own graph with the x3 kernels
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        s2.run_inplace(decode=True)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        kt = time_kernels_in_situ(model, dev, torch.randn(args.batch, 64, 30, device=dev), text)
+    finally:
+        model.set_math("f32")
+    return {"math": "bf16x3 attention (fp32-accurate split-bf16 products; row chain on f32 MFMA)",
+            "value": args.batch / el, "unit": "series/s", "ms_per_step": el * 1e3,
+            "attention_us": kt["attn_us"], "row_chain_us": kt["rows_us"],
+            "attention_bf16_tflops_executed": 6 * FLOP_ATTN_PER_SEQ_BLOCK * 2 * args.batch / (kt["attn_us"] * 1e-6) / 1e12,
+            "bf16_dense_peak_tflops": 2500.0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,6 +172,9 @@ def main():
     ap.add_argument("--backbone", default="ddpm", choices=["ddpm", "flowmatching"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-math", action="store_true", help="skip the extra bf16x3 measurement reported as alt_math")
+    ap.add_argument("--math", default="f32", choices=["f32", "bf16x3"],
+                    help="attention arithmetic: f32 MFMA (headline) or fp32-accurate split-bf16 products (include/t2s.h)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -168,6 +195,7 @@ def main():
 
     B = args.batch
     model, vae = build_models(dev)
+    model.set_math(args.math)
     sampler = Sampler(model, vae.decoder, args.backbone, args.diffusion_steps, args.cfg_scale, B, args.length,
                       dev, use_graph=not args.no_graph, seed=2025, row0=rank * B)
     text = synth.make_text_embeddings(2025, B, row0=rank * B).to(dev)
@@ -220,6 +248,8 @@ def main():
         step_flops = FLOP_FORWARD_PER_SEQ * 2 * B * args.diffusion_steps * args.steps
         out["whole_path_tflops"] = step_flops / elapsed / 1e12
         out["whole_path_frac_of_fp32_mfma_peak"] = out["whole_path_tflops"] / PEAK_FP32_MFMA_TFLOPS
+        if world == 1 and args.math == "f32" and not args.no_alt_math:
+            out["alt_math"] = alt_math_run(model, vae, args, dev, text)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, args.diffusion_steps, args.cfg_scale, args.length)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -90,6 +90,17 @@ int t2s_dit_create(const t2s_dit_weights* w, int max_seqs, t2s_dit** out);
 int t2s_dit_update_weights(t2s_dit* h, const t2s_dit_weights* w, void* stream);
 void t2s_dit_destroy(t2s_dit* h);
 int t2s_dit_max_seqs(const t2s_dit* h);
+/* Arithmetic of the attention products in t2s_dit_forward[_cfg] / the sampler.
+ *   T2S_MATH_F32 (default)  v_mfma_f32_32x32x2_f32: exact fp32 multiply-add chains.
+ *   T2S_MATH_BF16X3         every fp32 operand split into three bf16 terms, each product evaluated as
+ *                           the six bf16 MFMAs of weight >= 2^-16 with fp32 accumulation: the same
+ *                           accuracy as an fp32 product (dropped terms <= 3 * 2^-24 relative; measured
+ *                           against fp64 the kernel is as close as the f32 one) at 2.67x fewer matrix
+ *                           cycles.  Allocates 2 x max_seqs x 368,640 B on first use.
+ * Not capturable; a hipGraph captured under one mode keeps replaying that mode's kernels. */
+#define T2S_MATH_F32 0
+#define T2S_MATH_BF16X3 1
+int t2s_dit_set_math(t2s_dit* h, int math);
 
 /* TimeEmbedding.forward, transformer.py:30-40.  t: (B) fp32 (int64 timesteps are
  * converted to fp32 by the host mirror exactly as `t * 100.0` promotes them);
@@ -136,6 +147,12 @@ int t2s_attn_fwd(const float* q, const float* k, const float* v, float* o, int B
  *     o[(((row/32)*16 + G)*64 + 32*h + row%32)*4 + e] = O[row][8*G + 4*h + e]  (G = col/8). */
 int t2s_attn_fwd_packed(const float* q, const float* k, const float* vT, float* o, int n_seq,
                         void* stream);
+
+/* The "bf16x3" attention kernel (T2S_MATH_BF16X3, see t2s_dit_set_math) on plain tensors: same
+ * contract as t2s_attn_fwd (q, k, v, o: (BH, 480, 32) fp32, BH a multiple of 4), fp32-accurate
+ * products evaluated as six bf16 MFMAs each.  Packs / unpacks its operands internally and
+ * synchronises the stream (tests, benchmarking). */
+int t2s_attn_fwd_x3(const float* q, const float* k, const float* v, float* o, int BH, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * Training step of the DiT: train.py:101-127 (pred = model(x_t, t, emb); loss.backward();

@@ -18,6 +18,7 @@ N_BLOCKS = 4
 LAT_C, LAT_W, LAT = 64, 30, 1920
 D_MODEL, N_TOK = 128, 480
 TRAIN_F32, TRAIN_BF16 = 0, 1   # t2s.h: T2S_TRAIN_F32 / T2S_TRAIN_BF16
+MATH_F32, MATH_BF16X3 = 0, 1    # t2s.h: T2S_MATH_F32 / T2S_MATH_BF16X3
 
 c_float_p = C.c_void_p  # device pointers travel as opaque addresses
 
@@ -81,6 +82,8 @@ SYMBOLS = {
     "t2s_dit_timing_begin": (_I, [_VP]),
     "t2s_dit_timing_end": (_I, [_VP, C.POINTER(C.c_double)]),
     "t2s_dit_set_train_dtype": (_I, [_VP, _I]),
+    "t2s_dit_set_math": (_I, [_VP, _I]),
+    "t2s_attn_fwd_x3": (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_attn_fwd_bf16": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_dit_train_forward": (_I, [_VP, C.POINTER(DitWeights), _VP, _VP, _I, _VP, _VP, _I, _VP]),
     "t2s_dit_train_backward": (_I, [_VP, _VP, C.POINTER(DitGrads), _I, _VP]),

@@ -24,6 +24,8 @@ void set_error(const char* fmt, ...) {
 
 int launch_attn_packed(const float* q, const float* k, const float* vT, float* o, int BH, hipStream_t st);
 int attn_init();
+int launch_attn_x3(const float* q, const __bf16* k3, const __bf16* vT3, float* o, int BH, hipStream_t st);
+int attn_x3_init();
 void train_free(t2s_dit* h);
 
 // ------------------------------------------------------------------ small kernels
@@ -296,21 +298,27 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
             a.bp = h->proj_b[blk]; a.b1 = h->fc1_b[blk]; a.b2 = h->fc2_b[blk];
         }
         if (qkv_blk >= 0) { a.Wq = h->qkv_p[qkv_blk]; a.bq = h->qkv_b[qkv_blk]; }
-        a.q = h->q; a.k = h->k; a.v = h->v;
+        a.q = h->q; a.k = h->k; a.v = h->v; a.k3 = h->k3; a.v3 = h->v3;
         return a;
     };
+    // T2S_MATH_BF16X3: the qkv epilogues write k / V^T as split bf16 planes and the attention runs its
+    // products as six bf16 MFMAs each (fp32-accurate, t2s_x3.h); the row chain itself stays on f32 MFMA
+    const bool x3 = h->math == T2S_MATH_BF16X3;
     {
         TimeScope ts(h, TC_ROWS, st);
-        if ((rc = launch_dit_rows<false, true>(rows_args(-1, 0), st)) != T2S_OK) return rc;
+        rc = x3 ? launch_dit_rows<false, true, true>(rows_args(-1, 0), st) : launch_dit_rows<false, true>(rows_args(-1, 0), st);
+        if (rc != T2S_OK) return rc;
     }
     for (int i = 0; i < NBLK; ++i) {
         {
             TimeScope ts(h, TC_ATTN, st);
-            if ((rc = launch_attn_packed(h->q, h->k, h->v, h->ao, S * NH, st)) != T2S_OK) return rc;
+            rc = x3 ? launch_attn_x3(h->q, h->k3, h->v3, h->ao, S * NH, st)
+                    : launch_attn_packed(h->q, h->k, h->v, h->ao, S * NH, st);
+            if (rc != T2S_OK) return rc;
         }
         TimeScope ts(h, TC_ROWS, st);
         if (i + 1 < NBLK)
-            rc = launch_dit_rows<true, true>(rows_args(i, i + 1), st);
+            rc = x3 ? launch_dit_rows<true, true, true>(rows_args(i, i + 1), st) : launch_dit_rows<true, true>(rows_args(i, i + 1), st);
         else
             rc = launch_dit_rows<true, false>(rows_args(i, -1), st);
         if (rc != T2S_OK) return rc;
@@ -409,9 +417,28 @@ int t2s_dit_update_weights(t2s_dit* h, const t2s_dit_weights* w, void* stream) {
     return upload_weights(h, w, (hipStream_t)stream);
 }
 
+int t2s_dit_set_math(t2s_dit* h, int math) {
+    T2S_REQUIRE(h, "t2s_dit_set_math: NULL handle");
+    T2S_REQUIRE(math == T2S_MATH_F32 || math == T2S_MATH_BF16X3, "t2s_dit_set_math: unknown mode %d", math);
+    if (math == T2S_MATH_BF16X3 && h->k3 == nullptr) {
+        if (int rc = attn_x3_init()) return rc;
+        const size_t bytes = (size_t)h->max_seqs * NTOK * D * 3 * sizeof(__bf16);   // three bf16 planes
+        if (hipMalloc(&h->k3, bytes) != hipSuccess || hipMalloc(&h->v3, bytes) != hipSuccess) {
+            if (h->k3) (void)hipFree(h->k3);
+            h->k3 = h->v3 = nullptr;
+            set_error("t2s_dit_set_math: hipMalloc(2 x %zu B) failed", bytes);
+            return T2S_E_HIP;
+        }
+    }
+    h->math = math;
+    return T2S_OK;
+}
+
 void t2s_dit_destroy(t2s_dit* h) {
     if (!h) return;
     t2s::train_free(h);
+    if (h->k3) (void)hipFree(h->k3);
+    if (h->v3) (void)hipFree(h->v3);
     float* bufs[] = {h->arena, h->h, h->q, h->k, h->v, h->ao, h->mod, h->c};
     for (float* b : bufs)
         if (b) (void)hipFree(b);

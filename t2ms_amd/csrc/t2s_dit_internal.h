@@ -16,6 +16,9 @@ struct t2s_dit {
     // workspace (device), activations fragment-major
     float *h = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *ao = nullptr;
     float *mod = nullptr, *c = nullptr;
+    // T2S_MATH_BF16X3: k and V^T of the running block as split bf16 planes (t2s_x3.h), allocated on first use
+    int math = 0;
+    __bf16 *k3 = nullptr, *v3 = nullptr;
     // optional in-situ kernel timing (HIP events on the launching stream; never under capture)
     t2s_train_ws* train = nullptr;
     int train_dtype = 0;         // T2S_TRAIN_F32 / T2S_TRAIN_BF16 (t2s_dit_set_train_dtype)

@@ -241,12 +241,28 @@ class Transformer(nn.Module):
             with torch.cuda.device(device):
                 h = _DitHandle(w, keep, cap)
             self.__dict__["_t2s_h"], self.__dict__["_t2s_dev"], self.__dict__["_t2s_stamp"] = h, device, stamp
+            self.__dict__.pop("_t2s_math_applied", None)
         elif self.__dict__.get("_t2s_stamp") != stamp:
             L.check(L.lib().t2s_dit_update_weights(h.ptr, C.byref(w), L.stream_ptr(device)),
                     "t2s_dit_update_weights")
             h.keep = keep
             self.__dict__["_t2s_stamp"] = stamp
+        math = self.__dict__.get("_t2s_math", "f32")
+        if self.__dict__.get("_t2s_math_applied") != math:
+            with torch.cuda.device(device):
+                L.check(L.lib().t2s_dit_set_math(h.ptr, L.MATH_BF16X3 if math == "bf16x3" else L.MATH_F32),
+                        "t2s_dit_set_math")
+            self.__dict__["_t2s_math_applied"] = math
         return h.ptr
+
+    def set_math(self, math: str):
+        """Arithmetic of the attention products in the (no-grad) forward / the sampler: "f32" (default, f32
+        MFMA) or "bf16x3" (fp32-accurate split-bf16 products on the bf16 matrix cores, include/t2s.h
+        T2S_MATH_BF16X3).  Set it before building a Sampler: a captured hipGraph keeps its kernels."""
+        if math not in ("f32", "bf16x3"):
+            raise ValueError(f"math must be 'f32' or 'bf16x3', got {math!r}")
+        self.__dict__["_t2s_math"] = math
+        return self
 
     def set_train_dtype(self, dtype: str):
         """Arithmetic of forward-under-autograd / backward: "f32" (default; gradients equal the fp32
@@ -259,7 +275,7 @@ class Transformer(nn.Module):
 
     def __getstate__(self):
         state = self.__dict__.copy()
-        for k in ("_t2s_h", "_t2s_dev", "_t2s_stamp"):
+        for k in ("_t2s_h", "_t2s_dev", "_t2s_stamp", "_t2s_math_applied"):
             state.pop(k, None)
         return state
 

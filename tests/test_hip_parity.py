@@ -487,3 +487,47 @@ def test_config5_variable_length_encode_sample_decode(dev, vae):
         assert _maxdiff(lat, ref) < TOL * scale and _maxdiff(ser, ref_ser) < TOL * scale
         assert ser.shape == (B, L_)
         row += B
+
+
+# ---------------------------------------------------------------------------- bf16x3 arithmetic (opt-in)
+def test_attention_x3_kernel_vs_fp64(dev):
+    """T2S_MATH_BF16X3 attention (six bf16 MFMAs per fp32 product): same tolerance as the f32 kernel against
+    an fp64 softmax, with the spikes that force the stale-reference branch at early and late key blocks."""
+    rs = np.random.RandomState(21)
+    BH = 12
+    q, k, v = (torch.from_numpy(rs.randn(BH, 480, 32).astype(np.float32)) for _ in range(3))
+    k[:, 333] = q[:, 100] * 5.0
+    k[:, 410] = q[:, 200] * 12.0
+    k[:, 0:32] = -q[:, 7:8] * 3.0 + 0.01 * k[:, 0:32]
+    k[:, 448] = q[:, 7] * 10.0
+    ref = (torch.softmax((q.double() * 32 ** -0.5) @ k.double().transpose(-1, -2), dim=-1) @ v.double())
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    od = torch.empty_like(qd)
+    L.check(L.lib().t2s_attn_fwd_x3(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), od.data_ptr(), BH,
+                                    L.stream_ptr(dev)), "t2s_attn_fwd_x3")
+    err = (od.cpu().double() - ref).abs()
+    assert float(err.max()) < 2e-5 and float(err.pow(2).mean().sqrt()) < 1e-6
+
+
+@pytest.mark.parametrize("B", [3, 256])
+def test_dit_forward_bf16x3_matches_f32_path(dev, B):
+    """The whole forward under T2S_MATH_BF16X3 against the f32-MFMA path (itself within 1e-4 of the oracle):
+    both are fp32-accurate, so they agree to a few ulp of the activations -- 2e-5 absolute."""
+    from model.denoiser.transformer import Transformer
+    m = Transformer()
+    m.load_state_dict(synth.make_dit_state_dict(2025), strict=True)
+    m = m.to(dev).eval()
+    x = synth.make_latents(5, B).to(dev)
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(1)).to(dev)
+    text = synth.make_text_embeddings(5, B).to(dev)
+    with torch.no_grad():
+        y32 = m(input=x, t=t, text_input=text)
+        y3 = m.set_math("bf16x3")(input=x, t=t, text_input=text)
+        y32b = m.set_math("f32")(input=x, t=t, text_input=text)
+    assert torch.equal(y32, y32b)                      # switching back restores the f32 kernels bit for bit
+    assert torch.isfinite(y3).all()
+    assert _maxdiff(y3, y32) < 2e-5
+    if B == 3:
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        ref = O.dit_forward(sd, x.cpu(), t.cpu(), text.cpu())
+        assert _maxdiff(y3, ref) < 1e-4
