@@ -9,7 +9,7 @@
 #include <vector>
 
 #include "t2s_gemm.h"
-#include "t2s_rows.h"
+#include "t2s_rows_x3.h"
 
 namespace t2s {
 
@@ -213,6 +213,19 @@ int pack(const float* W, f32x4* P, int N, int K, int n_offset, int mode, hipStre
     return T2S_OK;
 }
 
+// split planes of the row-chain weights from the handle's packed fp32 copies (T2S_MATH_BF16X3)
+int pack_x3_weights(t2s_dit* h, hipStream_t st) {
+    int rc;
+    for (int i = 0; i < NBLK; ++i) {
+        if ((rc = pack_rows_x3(reinterpret_cast<const float*>(h->qkv_p[i]), reinterpret_cast<bf16x8*>(h->qkv3[i]), 3 * D, D, 0, st)) ||
+            (rc = pack_rows_x3(reinterpret_cast<const float*>(h->proj_p[i]), reinterpret_cast<bf16x8*>(h->proj3[i]), D, D, 0, st)) ||
+            (rc = pack_rows_x3(reinterpret_cast<const float*>(h->fc1_p[i]), reinterpret_cast<bf16x8*>(h->fc13[i]), 2 * D, D, 0, st)) ||
+            (rc = pack_rows_x3(reinterpret_cast<const float*>(h->fc2_c[i]), reinterpret_cast<bf16x8*>(h->fc2c3[i]), D, 2 * D, 1, st)))
+            return rc;
+    }
+    return T2S_OK;
+}
+
 int upload_weights(t2s_dit* h, const t2s_dit_weights* w, hipStream_t st) {
     T2S_REQUIRE(w->conv_w && w->conv_b && w->patch_w && w->patch_b && w->pos_embed && w->ln_w &&
                     w->ln_b && w->out_w && w->out_b && w->time_freqs,
@@ -247,6 +260,7 @@ int upload_weights(t2s_dit* h, const t2s_dit_weights* w, hipStream_t st) {
         if ((rc = pack(b.ada_w, h->ada_p, MODW, D, i * MODW, 0, st)) != T2S_OK) return rc;
     }
 #undef CP
+    if (h->w3 != nullptr) return pack_x3_weights(h, st);
     return T2S_OK;
 }
 
@@ -301,12 +315,24 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
         a.q = h->q; a.k = h->k; a.v = h->v; a.k3 = h->k3; a.v3 = h->v3;
         return a;
     };
-    // T2S_MATH_BF16X3: the qkv epilogues write k / V^T as split bf16 planes and the attention runs its
-    // products as six bf16 MFMAs each (fp32-accurate, t2s_x3.h); the row chain itself stays on f32 MFMA
+    // T2S_MATH_BF16X3: every product of the row chain and of the attention is evaluated as six bf16 MFMAs
+    // (fp32-accurate, t2s_x3.h); k / V^T travel as split bf16 planes
     const bool x3 = h->math == T2S_MATH_BF16X3;
+    auto rows_args_x3 = [&](int blk, int qkv_blk) {
+        RowArgsX3 a{};
+        a.x = h->h; a.ao = h->ao; a.mod = h->mod; a.M = M; a.blk = blk; a.qkv_blk = qkv_blk;
+        if (blk >= 0) {
+            a.Wp = reinterpret_cast<const bf16x8*>(h->proj3[blk]); a.W1 = reinterpret_cast<const bf16x8*>(h->fc13[blk]);
+            a.W2c = reinterpret_cast<const bf16x8*>(h->fc2c3[blk]);
+            a.bp = h->proj_b[blk]; a.b1 = h->fc1_b[blk]; a.b2 = h->fc2_b[blk];
+        }
+        if (qkv_blk >= 0) { a.Wq = reinterpret_cast<const bf16x8*>(h->qkv3[qkv_blk]); a.bq = h->qkv_b[qkv_blk]; }
+        a.q = h->q; a.k3 = h->k3; a.v3 = h->v3;
+        return a;
+    };
     {
         TimeScope ts(h, TC_ROWS, st);
-        rc = x3 ? launch_dit_rows<false, true, true>(rows_args(-1, 0), st) : launch_dit_rows<false, true>(rows_args(-1, 0), st);
+        rc = x3 ? launch_dit_rows_x3<false, true>(rows_args_x3(-1, 0), st) : launch_dit_rows<false, true>(rows_args(-1, 0), st);
         if (rc != T2S_OK) return rc;
     }
     for (int i = 0; i < NBLK; ++i) {
@@ -318,9 +344,9 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
         }
         TimeScope ts(h, TC_ROWS, st);
         if (i + 1 < NBLK)
-            rc = x3 ? launch_dit_rows<true, true, true>(rows_args(i, i + 1), st) : launch_dit_rows<true, true>(rows_args(i, i + 1), st);
+            rc = x3 ? launch_dit_rows_x3<true, true>(rows_args_x3(i, i + 1), st) : launch_dit_rows<true, true>(rows_args(i, i + 1), st);
         else
-            rc = launch_dit_rows<true, false>(rows_args(i, -1), st);
+            rc = x3 ? launch_dit_rows_x3<true, false>(rows_args_x3(i, -1), st) : launch_dit_rows<true, false>(rows_args(i, -1), st);
         if (rc != T2S_OK) return rc;
     }
     {
@@ -421,14 +447,29 @@ int t2s_dit_set_math(t2s_dit* h, int math) {
     T2S_REQUIRE(h, "t2s_dit_set_math: NULL handle");
     T2S_REQUIRE(math == T2S_MATH_F32 || math == T2S_MATH_BF16X3, "t2s_dit_set_math: unknown mode %d", math);
     if (math == T2S_MATH_BF16X3 && h->k3 == nullptr) {
-        if (int rc = attn_x3_init()) return rc;
+        int rc;
+        if ((rc = attn_x3_init()) || (rc = dit_rows_x3_init<false, true>()) || (rc = dit_rows_x3_init<true, true>()) ||
+            (rc = dit_rows_x3_init<true, false>()))
+            return rc;
         const size_t bytes = (size_t)h->max_seqs * NTOK * D * 3 * sizeof(__bf16);   // three bf16 planes
-        if (hipMalloc(&h->k3, bytes) != hipSuccess || hipMalloc(&h->v3, bytes) != hipSuccess) {
+        const size_t wvals = (size_t)NBLK * (3 + 1 + 2 + 2) * D * D * 3;              // qkv, proj, fc1, fc2: 3 planes
+        if (hipMalloc(&h->k3, bytes) != hipSuccess || hipMalloc(&h->v3, bytes) != hipSuccess ||
+            hipMalloc(&h->w3, wvals * sizeof(__bf16)) != hipSuccess) {
             if (h->k3) (void)hipFree(h->k3);
-            h->k3 = h->v3 = nullptr;
-            set_error("t2s_dit_set_math: hipMalloc(2 x %zu B) failed", bytes);
+            if (h->v3) (void)hipFree(h->v3);
+            h->k3 = h->v3 = h->w3 = nullptr;
+            set_error("t2s_dit_set_math: hipMalloc(2 x %zu B + weights) failed", bytes);
             return T2S_E_HIP;
         }
+        __bf16* p = h->w3;
+        for (int i = 0; i < NBLK; ++i) {
+            h->qkv3[i] = p; p += (size_t)3 * D * D * 3;
+            h->proj3[i] = p; p += (size_t)D * D * 3;
+            h->fc13[i] = p; p += (size_t)2 * D * D * 3;
+            h->fc2c3[i] = p; p += (size_t)2 * D * D * 3;
+        }
+        if ((rc = pack_x3_weights(h, nullptr))) return rc;
+        T2S_HIP_CHECK(hipStreamSynchronize(nullptr));
     }
     h->math = math;
     return T2S_OK;
@@ -439,6 +480,7 @@ void t2s_dit_destroy(t2s_dit* h) {
     t2s::train_free(h);
     if (h->k3) (void)hipFree(h->k3);
     if (h->v3) (void)hipFree(h->v3);
+    if (h->w3) (void)hipFree(h->w3);
     float* bufs[] = {h->arena, h->h, h->q, h->k, h->v, h->ao, h->mod, h->c};
     for (float* b : bufs)
         if (b) (void)hipFree(b);

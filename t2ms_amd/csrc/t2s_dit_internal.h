@@ -19,6 +19,8 @@ struct t2s_dit {
     // T2S_MATH_BF16X3: k and V^T of the running block as split bf16 planes (t2s_x3.h), allocated on first use
     int math = 0;
     __bf16 *k3 = nullptr, *v3 = nullptr;
+    __bf16* w3 = nullptr;        // split (3 x bf16) weights of the row chain in chunk order (t2s_rows_x3.h)
+    __bf16 *qkv3[t2s::NBLK], *proj3[t2s::NBLK], *fc13[t2s::NBLK], *fc2c3[t2s::NBLK];
     // optional in-situ kernel timing (HIP events on the launching stream; never under capture)
     t2s_train_ws* train = nullptr;
     int train_dtype = 0;         // T2S_TRAIN_F32 / T2S_TRAIN_BF16 (t2s_dit_set_train_dtype)

@@ -1,0 +1,365 @@
+// The row-local chain of a DiT block (t2s_rows.h) in "bf16x3" arithmetic (t2s_x3.h): the same
+// register-resident chain, chunk order and LDS-DMA weight ring, with every fp32 product evaluated
+// as six bf16 MFMAs (fp32-accurate) -- 48 v_mfma_f32_32x32x16_bf16 per chunk instead of 64
+// v_mfma_f32_32x32x2_f32 at half the cycles each.  Opt-in (T2S_MATH_BF16X3), not the headline path.
+//
+// Operand flow.  The 32x32 fp32 accumulator layout (lane = token, registers = features) is still the
+// next product's B operand: registers 8s..8s+7 of feature tile nt are k-step 2nt+s, split into three
+// bf16 planes in registers (split3_acc).  Where the register budget allows the planes stay resident
+// for the whole GEMM (attention output for proj, LayerNorm output for qkv: 96 registers); in the MLP
+// loop (64 fc2 accumulators + 64 LayerNorm outputs live) the LayerNorm output is re-split per chunk
+// -- bf16 MFMAs leave ~6 VALU issue slots each, so that work largely hides (tools/ubench_coissue.hip).
+//
+// Weights: three bf16 planes in chunk order, 24 KiB per chunk = 24 LDS-DMA pieces of 1 KiB:
+//   K = 128 chunks (proj / fc1 / qkv tile of 32 outputs): piece (ks, p), ks = k-step 0..7, p = plane,
+//     lane (n & 31, h) holds W[n][32 (ks>>1) + 16 (ks&1) + 8 (j>>2) + 4 h + (j&3)], j = 0..7;
+//   fc2 chunk c (the 32 hidden units of fc1 chunk c):  piece (nt, s, p), lane holds
+//     W2[32 nt + (n & 31)][32 c + 16 s + 8 (j>>2) + 4 h + (j&3)].
+#pragma once
+#include "t2s_rows.h"
+
+namespace t2s {
+
+constexpr int X3_CHUNK_UNITS = 24 * 64;                    // 16-byte units per chunk (24 KiB)
+constexpr int ROWS_X3_LDS_BYTES = 2 * X3_CHUNK_UNITS * 16 + (ROWS_CB_FLOATS + 4 * ROWS_CM_FLOATS) * 4;
+
+struct RowArgsX3 {
+    float* x;          // (M,128) residual stream, fragment-major, in place
+    const float* ao;   // (M,128) attention output (pre-proj), fragment-major
+    const float* mod;  // (S,MODROW)
+    int M;
+    int blk;
+    int qkv_blk;
+    const bf16x8 *Wp, *W1, *W2c, *Wq;   // split weights in chunk order (see above)
+    const float *bp, *b1, *b2, *bq;
+    float* q;          // q fragment-major fp32 (the attention scales and splits it once per head)
+    __bf16 *k3, *v3;   // k, V^T split planes (t2s_x3.h)
+};
+
+// fp32 packed weights (packed_index order, or the fc2 chunk order of pack_weight_kernel mode 1) ->
+// split planes in the chunk order above.  One thread per (chunk, piece-without-plane, lane).
+static __global__ void pack_rows_x3_kernel(const float* __restrict__ P, bf16x8* __restrict__ dst, int N, int K, int fc2) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_chunks = fc2 ? K / 32 : N / 32;
+    if (idx >= n_chunks * 8 * 64) return;
+    const int lane = idx & 63, piece = (idx >> 6) & 7, chunk = idx >> 9;
+    const int i = lane & 31, h = lane >> 5;
+    f32x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int n, k;
+        if (!fc2) {
+            n = chunk * 32 + i;
+            k = 32 * (piece >> 1) + 16 * (piece & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
+            v[j] = P[packed_index(n, k, K)];
+        } else {
+            const int nt = piece >> 1, s = piece & 1;
+            n = 32 * nt + i;
+            k = 32 * chunk + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+            const int G = k >> 3, hh = (k >> 2) & 1, e = k & 3, c = G >> 2, g = G & 3;
+            v[j] = P[((((size_t)(c * (N >> 5) + (n >> 5)) * 4 + g) * 64) + (hh * 32 + (n & 31))) * 4 + e];
+        }
+    }
+    const Split3 sp = split3(v);
+    bf16x8* d = dst + ((size_t)(chunk * 8 + piece) * 3) * 64 + lane;
+    d[0] = sp.h;
+    d[64] = sp.m;
+    d[128] = sp.l;
+}
+
+inline int pack_rows_x3(const float* P, bf16x8* dst, int N, int K, int fc2, hipStream_t st) {
+    const int n = (fc2 ? K / 32 : N / 32) * 8 * 64;
+    pack_rows_x3_kernel<<<(n + 255) / 256, 256, 0, st>>>(P, dst, N, K, fc2);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+// the three planes of weight piece `pc` of the chunk in ring slot `wb` (wb already offset by lane)
+__device__ __forceinline__ Split3 ldw3(const bf16x8* wb, int pc) {
+    Split3 w;
+    w.h = wb[(pc * 3 + 0) * 64];
+    w.m = wb[(pc * 3 + 1) * 64];
+    w.l = wb[(pc * 3 + 2) * 64];
+    return w;
+}
+
+template <bool DO_MLP, bool DO_QKV>
+__global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) {
+    extern __shared__ __attribute__((aligned(16))) bf16x8 wring3[];  // [2][X3_CHUNK_UNITS]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5;
+    const int n_tiles = a.M >> 5;
+    int tile = blockIdx.x * 4 + wave;             // 32-token tile of this wave
+    const bool active = tile < n_tiles;           // tail waves compute on a clamped tile, store nothing
+    if (!active) tile = n_tiles - 1;
+    const int seq = (tile * 32) / NTOK;           // 480 = 15*32: a tile never straddles sequences
+    const float* __restrict__ modrow = a.mod + (size_t)seq * MODROW;
+
+    constexpr int N_CHUNKS = (DO_MLP ? 20 : 0) + (DO_QKV ? 12 : 0);
+    auto chunk_src = [&](int ci) -> const bf16x8* {
+        if constexpr (DO_MLP) {
+            if (ci < 4) return a.Wp + (size_t)ci * X3_CHUNK_UNITS;
+            if (ci < 20) {
+                const int j = ci - 4;
+                return ((j & 1) ? a.W2c : a.W1) + (size_t)(j >> 1) * X3_CHUNK_UNITS;
+            }
+            ci -= 20;
+        }
+        return a.Wq + (size_t)ci * X3_CHUNK_UNITS;
+    };
+    // each wave DMAs pieces {wave, wave+4, ..., wave+20} of the chunk
+    auto fill = [&](int ci) {
+        const bf16x8* src = chunk_src(ci) + lane;
+        bf16x8* dst = wring3 + (ci & 1) * X3_CHUNK_UNITS;
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (wave + 4 * p) * 64),
+                                             (__attribute__((address_space(3))) void*)(dst + (wave + 4 * p) * 64), 16, 0, 0);
+    };
+
+    fill(0);
+
+    // ---- per-feature constants in LDS (visible after the first barrier), as in t2s_rows.h ----
+    float* cb = reinterpret_cast<float*>(wring3 + 2 * X3_CHUNK_UNITS);
+    float* cm = cb + ROWS_CB_FLOATS + wave * ROWS_CM_FLOATS;
+    if constexpr (DO_MLP) {
+        for (int i = threadIdx.x; i < 512; i += 256)
+            cb[i] = i < 128 ? a.bp[i] : (i < 384 ? a.b1[i - 128] : a.b2[i - 384]);
+        const float* src = modrow + a.blk * MODW;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            *reinterpret_cast<f32x4*>(cm + (i * 64 + lane) * 4) = *reinterpret_cast<const f32x4*>(src + (i * 64 + lane) * 4);
+    }
+    if constexpr (DO_QKV) {
+        for (int i = threadIdx.x; i < 384; i += 256) cb[512 + i] = a.bq[i];
+        const float* src = modrow + a.qkv_blk * MODW;   // shift_msa | scale_msa
+        *reinterpret_cast<f32x4*>(cm + 768 + lane * 4) = *reinterpret_cast<const f32x4*>(src + lane * 4);
+    }
+    const float* c_bp = cb;
+    const float* c_b1 = cb + 128;
+    const float* c_b2 = cb + 384;
+    const float* c_bq = cb + 512;
+
+    // residual stream of this lane's token, accumulator layout: x[nt][4g+e] = X[row][32nt+8g+4half+e]
+    f32x16 x[4];
+    {
+        const f32x4* xr = reinterpret_cast<const f32x4*>(a.x) + (size_t)tile * 16 * 64 + lane;
+#pragma unroll
+        for (int G = 0; G < 16; ++G) {
+            const f32x4 t = xr[G * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[G >> 2][4 * (G & 3) + e] = t[e];
+        }
+    }
+    int ci = 0;
+
+    if constexpr (DO_MLP) {
+        const float* mb = cm;   // [shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp] of a.blk
+        // ---------------- x += gate_msa * (proj(ao) + b): ao planes resident ----------------
+        {
+            Split3 aop[8];      // k-step ks = features 16 ks .. 16 ks + 15 in the permuted order
+            const f32x4* ar = reinterpret_cast<const f32x4*>(a.ao) + (size_t)tile * 16 * 64 + lane;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const f32x4 lo = ar[(2 * ks) * 64], hi = ar[(2 * ks + 1) * 64];
+                const f32x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                aop[ks] = split3(v);
+            }
+            __syncthreads();  // chunk 0 landed (vmcnt(0) + barrier)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                fill(ci + 1);
+                const bf16x8* wb = wring3 + (ci & 1) * X3_CHUNK_UNITS + lane;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) acc = mfma_x3(ldw3(wb, ks), aop[ks], acc);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bias = ldc4(c_bp, nt, g, half);
+                    const f32x4 gate = ldc4(mb + 2 * D, nt, g, half);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[nt][4 * g + e] += gate[e] * (acc[4 * g + e] + bias[e]);
+                }
+                __syncthreads();
+                ++ci;
+            }
+        }
+        // ---------------- x += gate_mlp * (fc2(gelu(fc1(mod(LN(x))))) + b2) ----------------
+        f32x4* xw = reinterpret_cast<f32x4*>(a.x) + (size_t)tile * 16 * 64 + lane;
+        {
+            f32x16 xm[4];
+            ln_modulate(x, xm, mb + 3 * D, mb + 4 * D, half, 1e-6f);
+            // park the post-attention residual in HBM for the MLP loop (t2s_rows.h)
+            if (active) {
+#pragma unroll
+                for (int G = 0; G < 16; ++G) {
+                    f32x4 t;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = x[G >> 2][4 * (G & 3) + e];
+                    xw[G * 64] = t;
+                }
+            }
+            f32x16 acc[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll 1
+            for (int c = 0; c < 8; ++c) {  // 32 hidden units per chunk; ci = 4 + 2c (even) here
+                fill(ci + 1);
+                // keep the LayerNorm output opaque per chunk: its split is loop-invariant and hipcc would
+                // otherwise hoist all 96 plane registers out of the loop (and spill them)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) asm volatile("" : "+v"(xm[nt]));
+                f32x16 hT;
+                {
+                    const bf16x8* wb = wring3 + lane;  // ci even -> ring slot 0
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hT[r] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks)      // LayerNorm output re-split per chunk (register budget)
+                        hT = mfma_x3(ldw3(wb, ks), split3_acc(xm[ks >> 1], ks & 1), hT);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 bias = *reinterpret_cast<const f32x4*>(c_b1 + 32 * c + 8 * g + 4 * half);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hT[4 * g + e] = gelu_tanh_f(hT[4 * g + e] + bias[e]);
+                    }
+                }
+                __syncthreads();
+                ++ci;
+                if (ci + 1 < N_CHUNKS) fill(ci + 1);
+                {   // fc2 partial over the 32 hidden units of this chunk: pieces (nt, s)
+                    const bf16x8* wb = wring3 + X3_CHUNK_UNITS + lane;  // ci odd -> ring slot 1
+                    const Split3 h0 = split3_acc(hT, 0), h1 = split3_acc(hT, 1);
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        acc[nt] = mfma_x3(ldw3(wb, nt * 2 + 0), h0, acc[nt]);
+                        acc[nt] = mfma_x3(ldw3(wb, nt * 2 + 1), h1, acc[nt]);
+                    }
+                }
+                __syncthreads();
+                ++ci;
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bias = ldc4(c_b2, nt, g, half);
+                    const f32x4 gate = ldc4(mb + 5 * D, nt, g, half);
+                    const f32x4 xo = xw[(nt * 4 + g) * 64];   // the parked residual
+                    f32x4 t;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        t[e] = xo[e] + gate[e] * (acc[nt][4 * g + e] + bias[e]);
+                        x[nt][4 * g + e] = t[e];
+                    }
+                    if (active) xw[(nt * 4 + g) * 64] = t;   // final residual stream of this block
+                }
+        }
+    } else {
+        __syncthreads();  // chunk 0 landed
+    }
+
+    if constexpr (DO_QKV) {
+        Split3 xmp[8];      // LayerNorm + modulate output as resident planes
+        {
+            f32x16 xm[4];
+            ln_modulate(x, xm, cm + 768, cm + 768 + D, half, 1e-6f);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) xmp[ks] = split3_acc(xm[ks >> 1], ks & 1);
+        }
+        const int tile_in_seq = tile - seq * (NTOK / 32);
+#pragma unroll 1
+        for (int t = 0; t < 12; ++t) {  // output tile t = which*4 + head
+            if (ci + 1 < N_CHUNKS) fill(ci + 1);
+            const bf16x8* wb = wring3 + (ci & 1) * X3_CHUNK_UNITS + lane;
+            const int which = t >> 2, head = t & 3;
+            const size_t head_tile = ((size_t)seq * NH + head) * (NTOK / 32) + tile_in_seq;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            if (which < 2) {
+                // q / k tile, transposed product: lane = token, registers = features d
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) acc = mfma_x3(ldw3(wb, ks), xmp[ks], acc);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bias = *reinterpret_cast<const f32x4*>(c_bq + 32 * t + 8 * g + 4 * half);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[4 * g + e] += bias[e];
+                }
+                if (active) {
+                    if (which == 0) {
+                        f32x4* dst = reinterpret_cast<f32x4*>(a.q) + head_tile * 4 * 64 + lane;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                            dst[g * 64] = o;
+                        }
+                    } else {
+                        bf16x8* d3 = reinterpret_cast<bf16x8*>(a.k3) + head_tile * X3_TILE_UNITS + lane;
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const Split3 sp = split3_acc(acc, s2);
+                            d3[(0 + s2) * 64] = sp.h;
+                            d3[(2 + s2) * 64] = sp.m;
+                            d3[(4 + s2) * 64] = sp.l;
+                        }
+                    }
+                }
+            } else {
+                // v tile with the MFMA operands swapped: lane = feature d, registers = keys
+                const float bias = c_bq[32 * t + (lane & 31)];
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) acc = mfma_x3(xmp[ks], ldw3(wb, ks), acc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += bias;
+                if (active) {
+                    bf16x8* d3 = reinterpret_cast<bf16x8*>(a.v3) + head_tile * X3_TILE_UNITS + lane;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const Split3 sp = split3_acc(acc, s2);
+                        d3[(0 + s2) * 64] = sp.h;
+                        d3[(2 + s2) * 64] = sp.m;
+                        d3[(4 + s2) * 64] = sp.l;
+                    }
+                }
+            }
+            // counted wait + raw barrier: the next chunk's 6 DMA pieces must have landed; the q (4) or
+            // k / v plane (6) stores issued after them stay in flight.  Tail waves store nothing.
+            if (!active)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (which >= 1)
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            ++ci;
+        }
+    }
+}
+
+template <bool DO_MLP, bool DO_QKV>
+inline int dit_rows_x3_init() {
+    T2S_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dit_rows_x3_kernel<DO_MLP, DO_QKV>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_X3_LDS_BYTES));
+    return T2S_OK;
+}
+
+template <bool DO_MLP, bool DO_QKV>
+inline int launch_dit_rows_x3(const RowArgsX3& a, hipStream_t st) {
+    if (a.M <= 0 || a.M % 32 != 0) {
+        set_error("dit_rows_x3: M=%d must be a positive multiple of 32", a.M);
+        return T2S_E_INVALID;
+    }
+    const int tiles = a.M / 32;
+    dit_rows_x3_kernel<DO_MLP, DO_QKV><<<(tiles + 3) / 4, 256, ROWS_X3_LDS_BYTES, st>>>(a);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+}  // namespace t2s
