@@ -137,8 +137,8 @@ def cpu_baseline(batch, diff_steps, cfg, length, n_cfg_steps=4):
 
 
 def alt_math_run(model, vae, args, dev, text):
-    """One extra batch of the same workload with the attention products in bf16x3 arithmetic (include/t2s.h
-    T2S_MATH_BF16X3: fp32-accurate, six bf16 MFMAs per product).  Reported NEXT TO the headline, never as it."""
+    """One extra batch of the same workload in bf16x3 arithmetic (include/t2s.h T2S_MATH_BF16X3: fp32-accurate,
+    six bf16 MFMAs per product, attention and row chain).  Reported NEXT TO the headline, never as it."""
     from t2ms_amd.sampler import Sampler
     model.set_math("bf16x3")
     try:
@@ -153,7 +153,7 @@ def alt_math_run(model, vae, args, dev, text):
         kt = time_kernels_in_situ(model, dev, torch.randn(args.batch, 64, 30, device=dev), text)
     finally:
         model.set_math("f32")
-    return {"math": "bf16x3 attention (fp32-accurate split-bf16 products; row chain on f32 MFMA)",
+    return {"math": "bf16x3: every product of the attention and the row chain as six bf16 MFMAs, fp32-accurate (include/t2s.h T2S_MATH_BF16X3)",
             "value": args.batch / el, "unit": "series/s", "ms_per_step": el * 1e3,
             "attention_us": kt["attn_us"], "row_chain_us": kt["rows_us"],
             "attention_bf16_tflops_executed": 6 * FLOP_ATTN_PER_SEQ_BLOCK * 2 * args.batch / (kt["attn_us"] * 1e-6) / 1e12,
@@ -174,7 +174,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the extra bf16x3 measurement reported as alt_math")
     ap.add_argument("--math", default="f32", choices=["f32", "bf16x3"],
-                    help="attention arithmetic: f32 MFMA (headline) or fp32-accurate split-bf16 products (include/t2s.h)")
+                    help="matrix arithmetic: f32 MFMA (headline) or fp32-accurate split-bf16 products (include/t2s.h)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

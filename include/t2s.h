@@ -90,13 +90,15 @@ int t2s_dit_create(const t2s_dit_weights* w, int max_seqs, t2s_dit** out);
 int t2s_dit_update_weights(t2s_dit* h, const t2s_dit_weights* w, void* stream);
 void t2s_dit_destroy(t2s_dit* h);
 int t2s_dit_max_seqs(const t2s_dit* h);
-/* Arithmetic of the attention products in t2s_dit_forward[_cfg] / the sampler.
+/* Matrix arithmetic of t2s_dit_forward[_cfg] / the sampler (attention and the row chain; the adaLN
+ * linear and the small layers always run in f32).
  *   T2S_MATH_F32 (default)  v_mfma_f32_32x32x2_f32: exact fp32 multiply-add chains.
  *   T2S_MATH_BF16X3         every fp32 operand split into three bf16 terms, each product evaluated as
  *                           the six bf16 MFMAs of weight >= 2^-16 with fp32 accumulation: the same
  *                           accuracy as an fp32 product (dropped terms <= 3 * 2^-24 relative; measured
- *                           against fp64 the kernel is as close as the f32 one) at 2.67x fewer matrix
- *                           cycles.  Allocates 2 x max_seqs x 368,640 B on first use.
+ *                           against fp64 the attention kernel is as close as the f32 one) at 2.67x
+ *                           fewer matrix cycles.  Allocates 2 x max_seqs x 368,640 B + 3.1 MB of split
+ *                           weights on first use; weights follow t2s_dit_update_weights.
  * Not capturable; a hipGraph captured under one mode keeps replaying that mode's kernels. */
 #define T2S_MATH_F32 0
 #define T2S_MATH_BF16X3 1

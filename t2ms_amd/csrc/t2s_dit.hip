@@ -312,7 +312,7 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
             a.bp = h->proj_b[blk]; a.b1 = h->fc1_b[blk]; a.b2 = h->fc2_b[blk];
         }
         if (qkv_blk >= 0) { a.Wq = h->qkv_p[qkv_blk]; a.bq = h->qkv_b[qkv_blk]; }
-        a.q = h->q; a.k = h->k; a.v = h->v; a.k3 = h->k3; a.v3 = h->v3;
+        a.q = h->q; a.k = h->k; a.v = h->v;
         return a;
     };
     // T2S_MATH_BF16X3: every product of the row chain and of the attention is evaluated as six bf16 MFMAs

@@ -25,7 +25,7 @@
 //
 // Per 32-token tile: 256 (proj) + 512 (fc1) + 512 (fc2) + 768 (qkv) MFMAs of 32x32x2.
 #pragma once
-#include "t2s_x3.h"
+#include "t2s_common.h"
 #include <stdlib.h>
 
 namespace t2s {
@@ -50,7 +50,6 @@ struct RowArgs {
     const f32x4 *Wp, *W1, *W2c, *Wq;    // packed weights; W2c is fc2 in chunk order [c][nt][g]
     const float *bp, *b1, *b2, *bq;
     float *q, *k, *v;  // per head (S*4, 480, 32): q, k fragment-major; v TRANSPOSED fragment-major (V^T)
-    __bf16 *k3, *v3;   // X3 instantiations: k and V^T as split bf16 planes (t2s_x3.h) instead of k, v
 };
 
 // GELU(tanh): 0.5 x (1 + tanh(u)) == x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3).
@@ -110,7 +109,7 @@ __device__ unsigned long long t2s_rows_dbg[8 * 8192];
 #define ROWS_STAMP(i)
 #endif
 
-template <bool DO_MLP, bool DO_QKV, bool X3 = false>
+template <bool DO_MLP, bool DO_QKV>
 __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
     extern __shared__ __attribute__((aligned(16))) f32x4 wring[];  // [2][1024]
 #if defined(T2S_EXP) && (T2S_EXP & 64)
@@ -339,23 +338,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
 #else
                 if (active) {
 #endif
-                    if (X3 && which == 1) {
-                        // k for the bf16x3 attention: the accumulator (lane = key, registers = features) IS the
-                        // A-operand fragment of k-step s in its registers 8s..8s+7; store its three bf16 planes
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[4 * g + e] += bias[g][e];
-                        bf16x8* d3 = reinterpret_cast<bf16x8*>(a.k3) +
-                                     (((size_t)seq * NH + head) * (NTOK / 32) + tile_in_seq) * X3_TILE_UNITS + lane;
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) {
-                            const Split3 sp = split3_acc(acc, s2);
-                            d3[(0 + s2) * 64] = sp.h;
-                            d3[(2 + s2) * 64] = sp.m;
-                            d3[(4 + s2) * 64] = sp.l;
-                        }
-                    } else {
+                    {
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             f32x4 o;
@@ -380,19 +363,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
 #else
                 if (active) {
 #endif
-                    if (X3) {   // V^T planes: lane = feature, registers = keys in the permuted order P^T uses
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[r] += bias;
-                        bf16x8* d3 = reinterpret_cast<bf16x8*>(a.v3) +
-                                     (((size_t)seq * NH + head) * (NTOK / 32) + tile_in_seq) * X3_TILE_UNITS + lane;
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) {
-                            const Split3 sp = split3_acc(acc, s2);
-                            d3[(0 + s2) * 64] = sp.h;
-                            d3[(2 + s2) * 64] = sp.m;
-                            d3[(4 + s2) * 64] = sp.l;
-                        }
-                    } else {
+                    {
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             f32x4 o;
@@ -407,12 +378,10 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
             // Counted wait + raw barrier: only the chunk's 4 DMA pieces must have landed; the 4
             // q/k/v stores issued after them (the youngest VM ops) stay in flight across the
             // barrier.  (__syncthreads() would drain them: vmcnt(0).)  Tail waves store nothing.
-            if (!active)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (X3 && which >= 1)
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // six plane stores per k / v tile
-            else
+            if (active)
                 asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
 #endif
             ++ci;
@@ -429,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
 #endif
 }
 
-template <bool DO_MLP, bool DO_QKV, bool X3 = false>
+template <bool DO_MLP, bool DO_QKV>
 inline int launch_dit_rows(const RowArgs& a, hipStream_t st) {
     if (a.M <= 0 || a.M % 32 != 0) {
         set_error("dit_rows: M=%d must be a positive multiple of 32", a.M);
@@ -437,8 +406,8 @@ inline int launch_dit_rows(const RowArgs& a, hipStream_t st) {
     }
     const int tiles = a.M / 32;
     static const int extra_lds = getenv("T2S_ROWS_EXTRA_LDS") ? atoi(getenv("T2S_ROWS_EXTRA_LDS")) : 0;  // diagnostic: force fewer workgroups per CU
-    if (extra_lds > 0) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dit_rows_kernel<DO_MLP, DO_QKV, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_LDS_BYTES + extra_lds);
-    dit_rows_kernel<DO_MLP, DO_QKV, X3><<<(tiles + 3) / 4, 256, ROWS_LDS_BYTES + extra_lds, st>>>(a);
+    if (extra_lds > 0) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dit_rows_kernel<DO_MLP, DO_QKV>), hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_LDS_BYTES + extra_lds);
+    dit_rows_kernel<DO_MLP, DO_QKV><<<(tiles + 3) / 4, 256, ROWS_LDS_BYTES + extra_lds, st>>>(a);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }

@@ -17,6 +17,7 @@
 //     W2[32 nt + (n & 31)][32 c + 16 s + 8 (j>>2) + 4 h + (j&3)].
 #pragma once
 #include "t2s_rows.h"
+#include "t2s_x3.h"
 
 namespace t2s {
 

@@ -256,9 +256,9 @@ class Transformer(nn.Module):
         return h.ptr
 
     def set_math(self, math: str):
-        """Arithmetic of the attention products in the (no-grad) forward / the sampler: "f32" (default, f32
-        MFMA) or "bf16x3" (fp32-accurate split-bf16 products on the bf16 matrix cores, include/t2s.h
-        T2S_MATH_BF16X3).  Set it before building a Sampler: a captured hipGraph keeps its kernels."""
+        """Matrix arithmetic of the (no-grad) forward / the sampler: "f32" (default, f32 MFMA) or "bf16x3"
+        (fp32-accurate split-bf16 products on the bf16 matrix cores for the attention and the row chain,
+        include/t2s.h T2S_MATH_BF16X3).  Set it before building a Sampler: a captured hipGraph keeps its kernels."""
         if math not in ("f32", "bf16x3"):
             raise ValueError(f"math must be 'f32' or 'bf16x3', got {math!r}")
         self.__dict__["_t2s_math"] = math
