@@ -6,9 +6,8 @@
 // Operand flow.  The 32x32 fp32 accumulator layout (lane = token, registers = features) is still the
 // next product's B operand: registers 8s..8s+7 of feature tile nt are k-step 2nt+s, split into three
 // bf16 planes in registers (split3_acc).  Where the register budget allows the planes stay resident
-// for the whole GEMM (attention output for proj, LayerNorm output for qkv: 96 registers); in the MLP
-// loop (64 fc2 accumulators + 64 LayerNorm outputs live) the LayerNorm output is re-split per chunk
-// -- bf16 MFMAs leave ~6 VALU issue slots each, so that work largely hides (tools/ubench_coissue.hip).
+// for the whole GEMM (attention output for proj, LayerNorm outputs for fc1 and qkv: 96 registers; the
+// fp32 copy is dead by then, and the residual stream is parked in HBM during the MLP loop).
 //
 // Weights: three bf16 planes in chunk order, 24 KiB per chunk = 24 LDS-DMA pieces of 1 KiB:
 //   K = 128 chunks (proj / fc1 / qkv tile of 32 outputs): piece (ks, p), ks = k-step 0..7, p = plane,
@@ -87,6 +86,10 @@ __device__ __forceinline__ Split3 ldw3(const bf16x8* wb, int pc) {
 template <bool DO_MLP, bool DO_QKV>
 __global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) {
     extern __shared__ __attribute__((aligned(16))) bf16x8 wring3[];  // [2][X3_CHUNK_UNITS]
+#if defined(T2S_EXP) && (T2S_EXP & 64)
+    unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    ROWS_STAMP(0)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
@@ -111,6 +114,9 @@ __global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) 
     };
     // each wave DMAs pieces {wave, wave+4, ..., wave+20} of the chunk
     auto fill = [&](int ci) {
+#if defined(T2S_EXP) && (T2S_EXP & 4096)
+        if (ci > 1) return;     // timing experiment: no weight DMA after the first two chunks (results are garbage)
+#endif
         const bf16x8* src = chunk_src(ci) + lane;
         bf16x8* dst = wring3 + (ci & 1) * X3_CHUNK_UNITS;
 #pragma unroll
@@ -168,6 +174,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) 
                 aop[ks] = split3(v);
             }
             __syncthreads();  // chunk 0 landed (vmcnt(0) + barrier)
+            ROWS_STAMP(1)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 fill(ci + 1);
@@ -188,11 +195,17 @@ __global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) 
                 ++ci;
             }
         }
+        ROWS_STAMP(2)
         // ---------------- x += gate_mlp * (fc2(gelu(fc1(mod(LN(x))))) + b2) ----------------
         f32x4* xw = reinterpret_cast<f32x4*>(a.x) + (size_t)tile * 16 * 64 + lane;
         {
-            f32x16 xm[4];
-            ln_modulate(x, xm, mb + 3 * D, mb + 4 * D, half, 1e-6f);
+            Split3 xmp[8];      // LayerNorm + modulate output as resident planes (the fp32 copy dies here)
+            {
+                f32x16 xm[4];
+                ln_modulate(x, xm, mb + 3 * D, mb + 4 * D, half, 1e-6f);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) xmp[ks] = split3_acc(xm[ks >> 1], ks & 1);
+            }
             // park the post-attention residual in HBM for the MLP loop (t2s_rows.h)
             if (active) {
 #pragma unroll
@@ -208,21 +221,17 @@ __global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) 
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+            ROWS_STAMP(3)
 #pragma unroll 1
             for (int c = 0; c < 8; ++c) {  // 32 hidden units per chunk; ci = 4 + 2c (even) here
                 fill(ci + 1);
-                // keep the LayerNorm output opaque per chunk: its split is loop-invariant and hipcc would
-                // otherwise hoist all 96 plane registers out of the loop (and spill them)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) asm volatile("" : "+v"(xm[nt]));
                 f32x16 hT;
                 {
                     const bf16x8* wb = wring3 + lane;  // ci even -> ring slot 0
 #pragma unroll
                     for (int r = 0; r < 16; ++r) hT[r] = 0.f;
 #pragma unroll
-                    for (int ks = 0; ks < 8; ++ks)      // LayerNorm output re-split per chunk (register budget)
-                        hT = mfma_x3(ldw3(wb, ks), split3_acc(xm[ks >> 1], ks & 1), hT);
+                    for (int ks = 0; ks < 8; ++ks) hT = mfma_x3(ldw3(wb, ks), xmp[ks], hT);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 bias = *reinterpret_cast<const f32x4*>(c_b1 + 32 * c + 8 * g + 4 * half);
@@ -265,6 +274,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) 
         __syncthreads();  // chunk 0 landed
     }
 
+    ROWS_STAMP(4)
     if constexpr (DO_QKV) {
         Split3 xmp[8];      // LayerNorm + modulate output as resident planes
         {
@@ -274,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) 
             for (int ks = 0; ks < 8; ++ks) xmp[ks] = split3_acc(xm[ks >> 1], ks & 1);
         }
         const int tile_in_seq = tile - seq * (NTOK / 32);
+        ROWS_STAMP(5)
 #pragma unroll 1
         for (int t = 0; t < 12; ++t) {  // output tile t = which*4 + head
             if (ci + 1 < N_CHUNKS) fill(ci + 1);
@@ -342,6 +353,15 @@ __global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) 
             ++ci;
         }
     }
+    ROWS_STAMP(6)
+#if defined(T2S_EXP) && (T2S_EXP & 64)
+    if (DO_MLP && DO_QKV && lane == 0 && blockIdx.x < 2048) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp[7] = __builtin_amdgcn_s_memtime();
+        unsigned long long* d = t2s_rows_dbg + (size_t)(blockIdx.x * 4 + wave) * 8;
+        for (int i = 0; i < 8; ++i) d[i] = stamp[i];
+    }
+#endif
 }
 
 template <bool DO_MLP, bool DO_QKV>

@@ -7,6 +7,7 @@ from model.denoiser.transformer import Transformer
 lib = C.CDLL(L.LIB_PATH)
 dev = torch.device("cuda:0")
 m = Transformer(); m.load_state_dict(synth.make_dit_state_dict(2025), strict=True); m = m.to(dev).eval()
+if len(sys.argv) > 1: m.set_math(sys.argv[1])   # "bf16x3": probe dit_rows_x3_kernel<true,true> instead
 B = 256
 x = synth.make_latents(1, B).to(dev); text = synth.make_text_embeddings(1, B).to(dev)
 h = m.t2s_handle(dev, 2 * B)
