@@ -20,6 +20,10 @@
 
 namespace t2s {
 
+// Raise the wave's issue priority for its VALU-heavy sections (LayerNorm, GELU, operand splits): the two
+// waves of a SIMD are arbitrated by priority, then age, and a partner in an MFMA section needs the issue
+// port for only 8 of every 32 cycles (measured: 375 -> 364 us average per launch).
+#define X3_PRIO(p) __builtin_amdgcn_s_setprio(p);
 constexpr int X3_CHUNK_UNITS = 24 * 64;                    // 16-byte units per chunk (24 KiB)
 constexpr int ROWS_X3_LDS_BYTES = 2 * X3_CHUNK_UNITS * 16 + (ROWS_CB_FLOATS + 4 * ROWS_CM_FLOATS) * 4;
 
@@ -200,6 +204,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) 
         f32x4* xw = reinterpret_cast<f32x4*>(a.x) + (size_t)tile * 16 * 64 + lane;
         {
             Split3 xmp[8];      // LayerNorm + modulate output as resident planes (the fp32 copy dies here)
+            X3_PRIO(2)
             {
                 f32x16 xm[4];
                 ln_modulate(x, xm, mb + 3 * D, mb + 4 * D, half, 1e-6f);
@@ -221,6 +226,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) 
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+            X3_PRIO(0)
             ROWS_STAMP(3)
 #pragma unroll 1
             for (int c = 0; c < 8; ++c) {  // 32 hidden units per chunk; ci = 4 + 2c (even) here
@@ -232,6 +238,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) 
                     for (int r = 0; r < 16; ++r) hT[r] = 0.f;
 #pragma unroll
                     for (int ks = 0; ks < 8; ++ks) hT = mfma_x3(ldw3(wb, ks), xmp[ks], hT);
+                    X3_PRIO(2)   // GELU + split: let this wave's VALU win the issue arbitration over the partner's MFMA stream
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 bias = *reinterpret_cast<const f32x4*>(c_b1 + 32 * c + 8 * g + 4 * half);
@@ -245,6 +252,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) 
                 {   // fc2 partial over the 32 hidden units of this chunk: pieces (nt, s)
                     const bf16x8* wb = wring3 + X3_CHUNK_UNITS + lane;  // ci odd -> ring slot 1
                     const Split3 h0 = split3_acc(hT, 0), h1 = split3_acc(hT, 1);
+                    X3_PRIO(0)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
                         acc[nt] = mfma_x3(ldw3(wb, nt * 2 + 0), h0, acc[nt]);
@@ -277,6 +285,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) 
     ROWS_STAMP(4)
     if constexpr (DO_QKV) {
         Split3 xmp[8];      // LayerNorm + modulate output as resident planes
+        X3_PRIO(2)
         {
             f32x16 xm[4];
             ln_modulate(x, xm, cm + 768, cm + 768 + D, half, 1e-6f);
@@ -284,6 +293,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) 
             for (int ks = 0; ks < 8; ++ks) xmp[ks] = split3_acc(xm[ks >> 1], ks & 1);
         }
         const int tile_in_seq = tile - seq * (NTOK / 32);
+        X3_PRIO(0)
         ROWS_STAMP(5)
 #pragma unroll 1
         for (int t = 0; t < 12; ++t) {  // output tile t = which*4 + head
