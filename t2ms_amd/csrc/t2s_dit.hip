@@ -425,6 +425,7 @@ int t2s_dit_create(const t2s_dit_weights* w, int max_seqs, t2s_dit** out) {
         }
     }
     int rc = attn_init();
+    if (rc == T2S_OK) rc = dit_rows_init();
     if (rc == T2S_OK) rc = upload_weights(h, w, nullptr);
     if (rc == T2S_OK && hipStreamSynchronize(nullptr) != hipSuccess) {
         set_error("t2s_dit_create: weight upload failed");

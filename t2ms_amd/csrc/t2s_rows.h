@@ -38,7 +38,10 @@ constexpr int ROWS_CHUNK_F4 = 1024;                       // float4 per chunk (1
 // weight DMA and all stores, once per 64 MFMAs (seen in the ISA; cost ~15 %).
 constexpr int ROWS_CB_FLOATS = 896;
 constexpr int ROWS_CM_FLOATS = 1024;                      // per wave
-constexpr int ROWS_LDS_BYTES = 2 * ROWS_CHUNK_F4 * 16 + (ROWS_CB_FLOATS + 4 * ROWS_CM_FLOATS) * 4;
+#ifndef T2S_ROWS_NW
+#define T2S_ROWS_NW 4
+#endif
+constexpr int ROWS_LDS_BYTES = 2 * ROWS_CHUNK_F4 * 16 + (ROWS_CB_FLOATS + T2S_ROWS_NW * ROWS_CM_FLOATS) * 4;
 
 struct RowArgs {
     float* x;          // (M,128) residual stream, fragment-major, in place
@@ -109,8 +112,15 @@ __device__ unsigned long long t2s_rows_dbg[8 * 8192];
 #define ROWS_STAMP(i)
 #endif
 
+// NW = waves per workgroup: 4 (two workgroups per CU; the default) or 8 (one; each wave then issues half the
+// weight DMA pieces and the weights cross L2 -> LDS once per 256 tokens).  Measured: 8 is slower, 510 vs 480 us
+// average per launch -- one barrier domain of 8 waves loses more than the halved DMA issue gains.
+#ifndef T2S_ROWS_NW
+#define T2S_ROWS_NW 4
+#endif
+constexpr int ROWS_NW = T2S_ROWS_NW;
 template <bool DO_MLP, bool DO_QKV>
-__global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
+__global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(const RowArgs a) {
     extern __shared__ __attribute__((aligned(16))) f32x4 wring[];  // [2][1024]
 #if defined(T2S_EXP) && (T2S_EXP & 64)
     unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -120,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: scalar addressing
     const int half = lane >> 5;
     const int n_tiles = a.M >> 5;
-    int tile = blockIdx.x * 4 + wave;             // 32-token tile of this wave
+    int tile = blockIdx.x * ROWS_NW + wave;       // 32-token tile of this wave
     const bool active = tile < n_tiles;           // tail waves compute on a clamped tile, store nothing
     if (!active) tile = n_tiles - 1;
     const int seq = (tile * 32) / NTOK;           // 480 = 15*32: a tile never straddles sequences
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
         const f32x4* src = chunk_src(ci) + lane;
         f32x4* dst = wring + (ci & 1) * ROWS_CHUNK_F4;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) glds16(src + (wave + 4 * p) * 64, dst + (wave + 4 * p) * 64);
+        for (int p = 0; p < 16 / ROWS_NW; ++p) glds16(src + (wave + ROWS_NW * p) * 64, dst + (wave + ROWS_NW * p) * 64);
     };
 
     fill(0);
@@ -152,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
     float* cb = reinterpret_cast<float*>(wring + 2 * ROWS_CHUNK_F4);
     float* cm = cb + ROWS_CB_FLOATS + wave * ROWS_CM_FLOATS;
     if constexpr (DO_MLP) {
-        for (int i = threadIdx.x; i < 512; i += 256)
+        for (int i = threadIdx.x; i < 512; i += 64 * ROWS_NW)
             cb[i] = i < 128 ? a.bp[i] : (i < 384 ? a.b1[i - 128] : a.b2[i - 384]);
         const float* src = modrow + a.blk * MODW;
 #pragma unroll
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
             *reinterpret_cast<f32x4*>(cm + (i * 64 + lane) * 4) = *reinterpret_cast<const f32x4*>(src + (i * 64 + lane) * 4);
     }
     if constexpr (DO_QKV) {
-        for (int i = threadIdx.x; i < 384; i += 256) cb[512 + i] = a.bq[i];
+        for (int i = threadIdx.x; i < 384; i += 64 * ROWS_NW) cb[512 + i] = a.bq[i];
         const float* src = modrow + a.qkv_blk * MODW;   // shift_msa | scale_msa
         *reinterpret_cast<f32x4*>(cm + 768 + lane * 4) = *reinterpret_cast<const f32x4*>(src + lane * 4);
     }
@@ -392,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_kernel(const RowArgs a) {
     if (DO_MLP && DO_QKV && lane == 0 && blockIdx.x < 2048) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp[7] = __builtin_amdgcn_s_memtime();
-        unsigned long long* d = t2s_rows_dbg + (size_t)(blockIdx.x * 4 + wave) * 8;
+        unsigned long long* d = t2s_rows_dbg + (size_t)(blockIdx.x * ROWS_NW + wave) * 8;
         for (int i = 0; i < 8; ++i) d[i] = stamp[i];
     }
 #endif
@@ -407,8 +417,16 @@ inline int launch_dit_rows(const RowArgs& a, hipStream_t st) {
     const int tiles = a.M / 32;
     static const int extra_lds = getenv("T2S_ROWS_EXTRA_LDS") ? atoi(getenv("T2S_ROWS_EXTRA_LDS")) : 0;  // diagnostic: force fewer workgroups per CU
     if (extra_lds > 0) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dit_rows_kernel<DO_MLP, DO_QKV>), hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_LDS_BYTES + extra_lds);
-    dit_rows_kernel<DO_MLP, DO_QKV><<<(tiles + 3) / 4, 256, ROWS_LDS_BYTES + extra_lds, st>>>(a);
+    dit_rows_kernel<DO_MLP, DO_QKV><<<(tiles + ROWS_NW - 1) / ROWS_NW, 64 * ROWS_NW, ROWS_LDS_BYTES + extra_lds, st>>>(a);
     T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+// raise the dynamic-LDS cap of the three instantiations (t2s_dit_create; never under stream capture)
+inline int dit_rows_init() {
+    T2S_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dit_rows_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_LDS_BYTES));
+    T2S_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dit_rows_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_LDS_BYTES));
+    T2S_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dit_rows_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_LDS_BYTES));
     return T2S_OK;
 }
 
