@@ -531,3 +531,40 @@ def test_dit_forward_bf16x3_matches_f32_path(dev, B):
         sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
         ref = O.dit_forward(sd, x.cpu(), t.cpu(), text.cpu())
         assert _maxdiff(y3, ref) < 1e-4
+
+
+@pytest.mark.parametrize("backbone", ["ddpm", "flowmatching"])
+def test_chain_golden_in_bf16x3(golden_dir, dev, vae, backbone):
+    """The reference-generated 20-step chains (tests/golden/chains.npz) with attention AND row chain in
+    T2S_MATH_BF16X3, through the captured hipGraph: same tolerance as the f32-MFMA path."""
+    g = _load(golden_dir, "chains")
+    m, Sampler, xT, text, noises = _chain_setup(dev, vae)
+    m.set_math("bf16x3")
+    s = Sampler(m, vae.decoder, backbone, 20, 7.0, 4, 96, dev, use_graph=True)
+    if backbone == "ddpm":
+        lat, series, _ = s.run(text, x_T=xT, noise=noises)
+        key = "ddpm"
+    else:
+        lat, series, _ = s.run(text, x_T=xT)
+        key = "rf"
+    scale = max(1.0, float(np.abs(g[key + "_latent"]).max()))
+    assert _maxdiff(lat, g[key + "_latent"]) < TOL * scale
+    assert _maxdiff(series, g[key + "_series"]) < TOL * scale
+
+
+def test_bf16x3_follows_weight_updates(dev):
+    """The split-plane weight copies are rebuilt by t2s_dit_update_weights (optimizer step / load_state_dict)."""
+    from model.denoiser.transformer import Transformer
+    m = Transformer()
+    m.load_state_dict(synth.make_dit_state_dict(2025), strict=True)
+    m = m.to(dev).eval().set_math("bf16x3")
+    x = synth.make_latents(5, 3).to(dev)
+    t = torch.tensor([1, 500, 999], device=dev)
+    text = synth.make_text_embeddings(5, 3).to(dev)
+    with torch.no_grad():
+        y0 = m(input=x, t=t, text_input=text)
+        m.load_state_dict(synth.make_dit_state_dict(7), strict=True)
+        y1 = m(input=x, t=t, text_input=text)
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        ref = O.dit_forward(sd, x.cpu(), t.cpu(), text.cpu())
+    assert _maxdiff(y1, ref) < 1e-4 and _maxdiff(y0, y1) > 1e-3
