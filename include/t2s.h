@@ -325,6 +325,15 @@ void t2s_sampler_destroy(t2s_sampler* s);
 int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, const float* noise,
                     float* series, float* trace0, void* stream);
 
+/* ------------------------------------------------------------------------ *
+ * Reconstruction metrics: evaluation.py:166-206 (calculate_mse, calculate_wape)
+ * ------------------------------------------------------------------------ */
+/* ori, gen: (n, len) device arrays, len = L * n_series of the (N, L, n_series) arrays infer.py writes;
+ * per_sample: (n, 2) output = [mse_i, wape_i (NaN when sum |ori_i| == 0)]; out: [MSE, WAPE] =
+ * [mean_i mse_i, nanmean_i wape_i].  Deterministic summation order. */
+int t2s_eval_mse_wape(const float* ori, const float* gen, float* per_sample, float* out, int n, int len,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

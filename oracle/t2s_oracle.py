@@ -405,3 +405,24 @@ def device_normal(seed: int, stream: int, row0: int, n_rows: int, row_elems: int
         out[..., a] = (rad * np.cos(2.0 * np.pi * u2)).astype(np.float32)
         out[..., b] = (rad * np.sin(2.0 * np.pi * u2)).astype(np.float32)
     return out.reshape(n_rows, row_elems)
+
+
+# ---------------------------------------------------------------------------- evaluation.py:166-206
+def eval_mse(ori, gen):
+    """calculate_mse (evaluation.py:166-180): mean over samples of the per-sample, per-series mean squared error."""
+    import numpy as np
+    ori, gen = np.asarray(ori, dtype=np.float64), np.asarray(gen, dtype=np.float64)
+    return float(np.mean([np.mean([np.mean((ori[i, :, j] - gen[i, :, j]) ** 2) for j in range(ori.shape[2])])
+                          for i in range(ori.shape[0])]))
+
+
+def eval_wape(ori, gen):
+    """calculate_wape (evaluation.py:183-206): nanmean over samples of sum |ori - gen| / sum |ori| (NaN if 0)."""
+    import numpy as np
+    ori, gen = np.asarray(ori, dtype=np.float64), np.asarray(gen, dtype=np.float64)
+    vals = []
+    for i in range(ori.shape[0]):
+        ae, av = np.abs(ori[i] - gen[i]).sum(), np.abs(ori[i]).sum()
+        vals.append(ae / av if av != 0 else np.nan)
+    return float(np.nanmean(np.asarray(vals)))
+

@@ -568,3 +568,21 @@ def test_bf16x3_follows_weight_updates(dev):
         sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
         ref = O.dit_forward(sd, x.cpu(), t.cpu(), text.cpu())
     assert _maxdiff(y1, ref) < 1e-4 and _maxdiff(y0, y1) > 1e-3
+
+
+def test_eval_mse_wape_vs_oracle(dev):
+    """t2s_eval_mse_wape on an (N, L, 1) pair as infer.py writes it, incl. an all-zero row (WAPE NaN, skipped)."""
+    from t2ms_amd.metrics import mse_wape
+    rs = np.random.RandomState(8)
+    ori = rs.uniform(0, 1, size=(37, 96, 1)).astype(np.float32)
+    gen = (ori + 0.1 * rs.randn(37, 96, 1)).astype(np.float32)
+    ori[5] = 0.0
+    mse, wape, per = mse_wape(ori, gen, dev)
+    np.testing.assert_allclose(mse, O.eval_mse(ori, gen), rtol=1e-5)
+    np.testing.assert_allclose(wape, O.eval_wape(ori, gen), rtol=1e-5)
+    assert np.isnan(per[5, 1].item()) and per.shape == (37, 2)
+    # multi-series layout (N, L, 3): len = L * n_series
+    o3, g3 = rs.randn(4, 24, 3).astype(np.float32), rs.randn(4, 24, 3).astype(np.float32)
+    m3, w3, _ = mse_wape(o3, g3, dev)
+    np.testing.assert_allclose(m3, O.eval_mse(o3, g3), rtol=1e-5)
+    np.testing.assert_allclose(w3, O.eval_wape(o3, g3), rtol=1e-5)

@@ -173,3 +173,14 @@ def test_philox_known_answer():
         assert tuple(int(x) for x in got) == want
     z = O.device_normal(2025, 3, 0, 64)
     assert z.shape == (64, 1920) and abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1) < 0.02
+
+
+def test_eval_metrics_restatement():
+    """oracle.eval_mse / eval_wape (evaluation.py:166-206) on a hand-checkable case incl. the all-zero row."""
+    import numpy as np
+    ori = np.zeros((3, 4, 1)); gen = np.zeros((3, 4, 1))
+    ori[0, :, 0] = [1, 2, 3, 4]; gen[0, :, 0] = [1, 2, 3, 6]        # mse 1.0, wape 2/10
+    ori[1, :, 0] = [0, 0, 0, 0]; gen[1, :, 0] = [1, 1, 1, 1]        # mse 1.0, wape NaN (skipped)
+    ori[2, :, 0] = [2, 2, 2, 2]; gen[2, :, 0] = [1, 1, 1, 1]        # mse 1.0, wape 0.5
+    assert abs(O.eval_mse(ori, gen) - 1.0) < 1e-12
+    assert abs(O.eval_wape(ori, gen) - 0.35) < 1e-12
