@@ -294,10 +294,16 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
         TimeScope ts(h, TC_OTHER, st);
         if ((rc = launch_gemm_rows<128, 3, PRO_SILU, EPI_BIAS>(a, st)) != T2S_OK) return rc;
     }
+    // patchify: the two branches of a CFG pass (S == 2B) see the same tokens, so only B sequences are
+    // computed, into their own buffer; block 0's kernels read sequence s % B from it (in place would race:
+    // the workgroup of sequence s overwrites slot s while that of s + B still reads it)
+    const bool shared_in = S == 2 * B;
+    float* tokens = shared_in ? h->h0 : h->h;
+    const int in_seqs = shared_in ? B : S;
     {
-        const int threads = S * NTOK * 32;
+        const int threads = in_seqs * NTOK * 32;
         TimeScope ts(h, TC_OTHER, st);
-        patchify_kernel<<<(threads + 255) / 256, 256, 0, st>>>(x, B, h->h, S, h->conv_w, h->conv_b,
+        patchify_kernel<<<(threads + 255) / 256, 256, 0, st>>>(x, B, tokens, in_seqs, h->conv_w, h->conv_b,
                                                                h->patch_w, h->patch_b, h->pos);
         T2S_LAUNCH_CHECK();
     }
@@ -307,6 +313,8 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
     auto rows_args = [&](int blk, int qkv_blk) {
         RowArgs a{};
         a.x = h->h; a.ao = h->ao; a.mod = h->mod; a.M = M; a.blk = blk; a.qkv_blk = qkv_blk;
+        const bool first = blk <= 0 && qkv_blk <= 1;     // rows<qkv 0> and rows<block 0, qkv 1> read the patchified tokens
+        a.x_in = first ? tokens : h->h; a.in_seqs = first ? in_seqs : S;
         if (blk >= 0) {
             a.Wp = h->proj_p[blk]; a.W1 = h->fc1_p[blk]; a.W2c = h->fc2_c[blk];
             a.bp = h->proj_b[blk]; a.b1 = h->fc1_b[blk]; a.b2 = h->fc2_b[blk];
@@ -321,6 +329,8 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
     auto rows_args_x3 = [&](int blk, int qkv_blk) {
         RowArgsX3 a{};
         a.x = h->h; a.ao = h->ao; a.mod = h->mod; a.M = M; a.blk = blk; a.qkv_blk = qkv_blk;
+        const bool first = blk <= 0 && qkv_blk <= 1;
+        a.x_in = first ? tokens : h->h; a.in_seqs = first ? in_seqs : S;
         if (blk >= 0) {
             a.Wp = reinterpret_cast<const bf16x8*>(h->proj3[blk]); a.W1 = reinterpret_cast<const bf16x8*>(h->fc13[blk]);
             a.W2c = reinterpret_cast<const bf16x8*>(h->fc2c3[blk]);
@@ -413,9 +423,9 @@ int t2s_dit_create(const t2s_dit_weights* w, int max_seqs, t2s_dit** out) {
         h->fc2_c[i] = reinterpret_cast<f32x4*>(A + o_fc2_c[i]);
     }
     const size_t S = (size_t)max_seqs, tokD = S * NTOK * D;
-    float** bufs[] = {&h->h, &h->q, &h->k, &h->v, &h->ao, &h->mod, &h->c};
-    const size_t sizes[] = {tokD, tokD, tokD, tokD, tokD, S * MODROW, S * D};
-    for (int i = 0; i < 7; ++i) {
+    float** bufs[] = {&h->h, &h->q, &h->k, &h->v, &h->ao, &h->mod, &h->c, &h->h0};
+    const size_t sizes[] = {tokD, tokD, tokD, tokD, tokD, S * MODROW, S * D, (S / 2 + 1) * NTOK * D};
+    for (int i = 0; i < 8; ++i) {
         e = hipMalloc(bufs[i], sizes[i] * sizeof(float));
         if (e != hipSuccess) {
             set_error("t2s_dit_create: hipMalloc(workspace %d, %zu B) failed: %s", i,
@@ -482,7 +492,7 @@ void t2s_dit_destroy(t2s_dit* h) {
     if (h->k3) (void)hipFree(h->k3);
     if (h->v3) (void)hipFree(h->v3);
     if (h->w3) (void)hipFree(h->w3);
-    float* bufs[] = {h->arena, h->h, h->q, h->k, h->v, h->ao, h->mod, h->c};
+    float* bufs[] = {h->arena, h->h, h->q, h->k, h->v, h->ao, h->mod, h->c, h->h0};
     for (float* b : bufs)
         if (b) (void)hipFree(b);
     delete h;

@@ -15,6 +15,7 @@ struct t2s_dit {
     t2s::f32x4 *qkv_p[t2s::NBLK], *proj_p[t2s::NBLK], *fc1_p[t2s::NBLK], *fc2_c[t2s::NBLK], *ada_p;
     // workspace (device), activations fragment-major
     float *h = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *ao = nullptr;
+    float* h0 = nullptr;         // patchified tokens of the B distinct sequences of a CFG pass (both branches share them)
     float *mod = nullptr, *c = nullptr;
     // T2S_MATH_BF16X3: k and V^T of the running block as split bf16 planes (t2s_x3.h), allocated on first use
     int math = 0;

@@ -45,6 +45,8 @@ constexpr int ROWS_LDS_BYTES = 2 * ROWS_CHUNK_F4 * 16 + (ROWS_CB_FLOATS + T2S_RO
 
 struct RowArgs {
     float* x;          // (M,128) residual stream, fragment-major, in place
+    const float* x_in; // where the stream is READ at kernel entry: x itself, or (block 0 of a CFG pass) the patchified
+    int in_seqs;       //   tokens of the in_seqs distinct sequences, sequence s reading slot s % in_seqs
     const float* ao;   // (M,128) attention output (pre-proj), fragment-major
     const float* mod;  // (S,MODROW)
     int M;             // S*480 (multiple of 32)
@@ -182,7 +184,8 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
     // residual stream of this lane's token, accumulator layout: x[nt][4g+e] = X[row][32nt+8g+4half+e]
     f32x16 x[4];
     {
-        const f32x4* xr = reinterpret_cast<const f32x4*>(a.x) + (size_t)tile * 16 * 64 + lane;
+        const int tile_src = tile - (seq - seq % a.in_seqs) * (NTOK / 32);   // same tile of sequence seq % in_seqs
+        const f32x4* xr = reinterpret_cast<const f32x4*>(a.x_in) + (size_t)tile_src * 16 * 64 + lane;
 #pragma unroll
         for (int G = 0; G < 16; ++G) {
             const f32x4 t = xr[G * 64];
