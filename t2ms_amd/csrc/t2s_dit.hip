@@ -116,65 +116,6 @@ __global__ __launch_bounds__(256) void patchify_kernel(
     reinterpret_cast<f32x4*>(h)[gid] = o;
 }
 
-// final layer (transformer.py:182-191): affine LayerNorm (eps 1e-5), Linear 128->4, unpatchify:
-// out[s][(2ww+pw)*30 + 2hh+ph] = y[ph*2+pw].  Sequences [0,split) go to out0, the rest to out1.
-// One wave per 32-token tile; lane (i,half) holds the 64 features {8G+4half+e} of token i.
-__global__ __launch_bounds__(256) void final_kernel(const float* __restrict__ h, int S,
-                                                    const float* __restrict__ lnw,
-                                                    const float* __restrict__ lnb,
-                                                    const float* __restrict__ ow,
-                                                    const float* __restrict__ ob,
-                                                    float* __restrict__ out0,
-                                                    float* __restrict__ out1, int split) {
-    const int lane = threadIdx.x & 63, half = lane >> 5;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile * 32 >= S * NTOK) return;
-    const f32x4* hr = reinterpret_cast<const f32x4*>(h) + (size_t)tile * 16 * 64 + lane;
-    f32x4 v[16];
-    float s1 = 0.f;
-#pragma unroll
-    for (int G = 0; G < 16; ++G) {
-        v[G] = hr[G * 64];
-        s1 += (v[G].x + v[G].y) + (v[G].z + v[G].w);
-    }
-    s1 += xhalf(s1);
-    const float mean = s1 * (1.0f / 128.0f);
-    float s2 = 0.f;
-#pragma unroll
-    for (int G = 0; G < 16; ++G) {
-        v[G] = v[G] - mean;
-        s2 += (v[G].x * v[G].x + v[G].y * v[G].y) + (v[G].z * v[G].z + v[G].w * v[G].w);
-    }
-    s2 += xhalf(s2);
-    const float rstd = rsqrtf(s2 * (1.0f / 128.0f) + 1e-5f);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int G = 0; G < 16; ++G) {
-        const int col = 8 * G + 4 * half;
-        const f32x4 g = *reinterpret_cast<const f32x4*>(lnw + col);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(lnb + col);
-        const f32x4 y = (v[G] * rstd) * g + b;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(ow + p * D + col);
-            acc[p] += (y.x * w.x + y.y * w.y) + (y.z * w.z + y.w * w.w);
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) acc[p] += xhalf(acc[p]);
-    // lane half 0 writes patch outputs p = 0,1; half 1 writes p = 2,3
-    const int tokg = tile * 32 + (lane & 31);
-    const int s = tokg / NTOK, n = tokg - s * NTOK;
-    const int hh = n >> 5, ww = n & 31;
-    float* dst = (s < split) ? out0 + (size_t)s * LAT : out1 + (size_t)(s - split) * LAT;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int p = 2 * half + q;
-        const int ph = p >> 1, pw = p & 1;
-        dst[(2 * ww + pw) * LATW + 2 * hh + ph] = (half ? acc[2 + q] : acc[q]) + ob[p];
-    }
-}
-
 // fragment-major (rows,128) -> row-major, for the test tap
 __global__ void unfrag128_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -280,7 +221,7 @@ struct TimeScope {   // records an event pair around one launch when timing is o
 // One DiT forward over S sequences (sequence s reads latent row s % B).
 int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const float* temb,
                 int temb_rows, const int* step_ptr, const float* text, float* out0, float* out1,
-                int split, hipStream_t st) {
+                int split, hipStream_t st, bool keep_stream = true) {
     int rc;
     {
         TimeScope ts(h, TC_OTHER, st);
@@ -315,6 +256,10 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
         a.x = h->h; a.ao = h->ao; a.mod = h->mod; a.M = M; a.blk = blk; a.qkv_blk = qkv_blk;
         const bool first = blk <= 0 && qkv_blk <= 1;     // rows<qkv 0> and rows<block 0, qkv 1> read the patchified tokens
         a.x_in = first ? tokens : h->h; a.in_seqs = first ? in_seqs : S;
+        if (blk == NBLK - 1) {   // the last kernel also runs the final layer
+            a.f_lnw = h->ln_w; a.f_lnb = h->ln_b; a.f_ow = h->out_w; a.f_ob = h->out_b;
+            a.out0 = out0; a.out1 = out1; a.split = split; a.keep_x = keep_stream;
+        }
         if (blk >= 0) {
             a.Wp = h->proj_p[blk]; a.W1 = h->fc1_p[blk]; a.W2c = h->fc2_c[blk];
             a.bp = h->proj_b[blk]; a.b1 = h->fc1_b[blk]; a.b2 = h->fc2_b[blk];
@@ -331,6 +276,10 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
         a.x = h->h; a.ao = h->ao; a.mod = h->mod; a.M = M; a.blk = blk; a.qkv_blk = qkv_blk;
         const bool first = blk <= 0 && qkv_blk <= 1;
         a.x_in = first ? tokens : h->h; a.in_seqs = first ? in_seqs : S;
+        if (blk == NBLK - 1) {
+            a.f_lnw = h->ln_w; a.f_lnb = h->ln_b; a.f_ow = h->out_w; a.f_ob = h->out_b;
+            a.out0 = out0; a.out1 = out1; a.split = split; a.keep_x = keep_stream;
+        }
         if (blk >= 0) {
             a.Wp = reinterpret_cast<const bf16x8*>(h->proj3[blk]); a.W1 = reinterpret_cast<const bf16x8*>(h->fc13[blk]);
             a.W2c = reinterpret_cast<const bf16x8*>(h->fc2c3[blk]);
@@ -359,13 +308,7 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
             rc = x3 ? launch_dit_rows_x3<true, false>(rows_args_x3(i, -1), st) : launch_dit_rows<true, false>(rows_args(i, -1), st);
         if (rc != T2S_OK) return rc;
     }
-    {
-        const int tiles = M / 32;
-        TimeScope ts(h, TC_OTHER, st);
-        final_kernel<<<(tiles + 3) / 4, 256, 0, st>>>(h->h, S, h->ln_w, h->ln_b, h->out_w, h->out_b,
-                                                      out0, out1, split);
-        T2S_LAUNCH_CHECK();
-    }
+    // (the final layer -- LayerNorm, Linear 128 -> 4, unpatchify -- ran inside the last row kernel)
     return T2S_OK;
 }
 
@@ -375,7 +318,7 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
 namespace t2s {
 int dit_forward_cfg_step(t2s_dit* h, const float* x, const float* temb_table, const int* step_ptr,
                          const float* text, float* out_u, float* out_c, int B, hipStream_t st) {
-    return run_forward(h, x, B, 2 * B, B, temb_table, 1, step_ptr, text, out_u, out_c, B, st);
+    return run_forward(h, x, B, 2 * B, B, temb_table, 1, step_ptr, text, out_u, out_c, B, st, /*keep_stream=*/false);
 }
 }  // namespace t2s
 

@@ -47,6 +47,11 @@ struct RowArgs {
     float* x;          // (M,128) residual stream, fragment-major, in place
     const float* x_in; // where the stream is READ at kernel entry: x itself, or (block 0 of a CFG pass) the patchified
     int in_seqs;       //   tokens of the in_seqs distinct sequences, sequence s reading slot s % in_seqs
+    // last block only (DO_MLP && !DO_QKV): fused final layer when out0 != NULL; sequences [0,split) -> out0, rest -> out1;
+    // keep_x = 0 skips the store of the final residual stream (only the t2s_dit_read_stream tap reads it)
+    const float *f_lnw, *f_lnb, *f_ow, *f_ob;
+    float *out0, *out1;
+    int split, keep_x;
     const float* ao;   // (M,128) attention output (pre-proj), fragment-major
     const float* mod;  // (S,MODROW)
     int M;             // S*480 (multiple of 32)
@@ -308,13 +313,69 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
                         t[e] = xo[e] + gate[e] * (acc[nt][4 * g + e] + bias[e]);
                         x[nt][4 * g + e] = t[e];
                     }
-                    if (active) xw[(nt * 4 + g) * 64] = t;   // final residual stream of this block
+                    if (active && (DO_QKV || a.out0 == nullptr || a.keep_x)) xw[(nt * 4 + g) * 64] = t;   // final residual stream of this block
                 }
         }
     } else {
         __syncthreads();  // chunk 0 landed
     }
 
+    // ---- fused final layer of the LAST block (transformer.py:182-191): affine LayerNorm (eps 1e-5),
+    // Linear 128 -> 4, unpatchify out[s][(2ww+pw)*30 + 2hh+ph] = y[ph*2+pw]; the lane pair of a token holds its
+    // 128 features, so everything is lane-local up to one cross-half add per output
+    if constexpr (DO_MLP && !DO_QKV) {
+        if (a.out0 != nullptr) {
+            float s1 = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    s1 += (x[nt][4 * g] + x[nt][4 * g + 1]) + (x[nt][4 * g + 2] + x[nt][4 * g + 3]);
+            s1 += xhalf(s1);
+            const float mean = s1 * (1.0f / 128.0f);
+            float s2 = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[nt][4 * g + e] -= mean;
+                    s2 += (x[nt][4 * g] * x[nt][4 * g] + x[nt][4 * g + 1] * x[nt][4 * g + 1]) +
+                          (x[nt][4 * g + 2] * x[nt][4 * g + 2] + x[nt][4 * g + 3] * x[nt][4 * g + 3]);
+                }
+            s2 += xhalf(s2);
+            const float rstd = rsqrtf(s2 * (1.0f / 128.0f) + 1e-5f);
+            float fa[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = 32 * nt + 8 * g + 4 * half;
+                    const f32x4 gam = *reinterpret_cast<const f32x4*>(a.f_lnw + col);
+                    const f32x4 bet = *reinterpret_cast<const f32x4*>(a.f_lnb + col);
+                    f32x4 y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = (x[nt][4 * g + e] * rstd) * gam[e] + bet[e];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(a.f_ow + p * D + col);
+                        fa[p] += (y.x * w.x + y.y * w.y) + (y.z * w.z + y.w * w.w);
+                    }
+                }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) fa[p] += xhalf(fa[p]);
+            if (active) {   // lane half 0 writes patch outputs p = 0,1; half 1 writes p = 2,3
+                const int n = (tile - seq * (NTOK / 32)) * 32 + (lane & 31);
+                const int hh = n >> 5, ww = n & 31;
+                float* dst = (seq < a.split) ? a.out0 + (size_t)seq * LAT : a.out1 + (size_t)(seq - a.split) * LAT;
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int p = 2 * half + q2;
+                    dst[(2 * ww + (p & 1)) * LATW + 2 * hh + (p >> 1)] = (half ? fa[2 + q2] : fa[q2]) + a.f_ob[p];
+                }
+            }
+        }
+    }
     ROWS_STAMP(4)
     if constexpr (DO_QKV) {
         f32x16 xm[4];
