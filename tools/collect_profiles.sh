@@ -11,12 +11,12 @@ echo "== bench"; timeout -k 10 500 python bench.py --gpus 1 --steps 3 --warmup 1
 tail -c 600 $out/${tag}_bench.json; echo
 echo "== rocprofv3 --kernel-trace --stats (same command, 1+1 batches)"
 rm -rf /tmp/prof_$tag
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_prof_bench.json 2> $out/${tag}_prof.err || exit 1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline --no-alt-math > $out/${tag}_prof_bench.json 2> $out/${tag}_prof.err || exit 1
 cp /tmp/prof_$tag/*/*kernel_stats.csv $out/${tag}_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   echo "== pmc $c"
   rm -rf /tmp/pmc_$c
-  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python bench.py --gpus 1 --steps 1 --warmup 1 --diffusion-steps 3 --no-cpu-baseline > /dev/null 2> $out/${tag}_pmc_$c.err || exit 1
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python bench.py --gpus 1 --steps 1 --warmup 1 --diffusion-steps 3 --no-cpu-baseline --no-alt-math > /dev/null 2> $out/${tag}_pmc_$c.err || exit 1
   python3 - "$c" /tmp/pmc_$c $out/${tag}_pmc_$c.csv <<'PY'
 import csv, glob, sys, collections
 c, d, dst = sys.argv[1:4]
@@ -45,3 +45,10 @@ rm -rf /tmp/proft_$tag
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/proft_$tag -- python3 tools/bench_train.py --batch 1152 --steps 3 --warmup 1 --dtype bf16 --cache_latents > /dev/null 2> $out/${tag}_train_prof.err || exit 1
 cp /tmp/proft_$tag/*/*kernel_stats.csv $out/${tag}_train_bf16_kernel_stats.csv
 head -12 $out/${tag}_train_bf16_kernel_stats.csv
+
+# ---- opt-in bf16x3 arithmetic (not the headline): kernel stats of a 50-step run
+echo "== bf16x3 kernel stats"
+rm -rf /tmp/profx_$tag
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profx_$tag -- python3 bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline --math bf16x3 --diffusion-steps 50 > /dev/null 2> $out/${tag}_x3_prof.err || exit 1
+cp /tmp/profx_$tag/*/*kernel_stats.csv $out/${tag}_x3_kernel_stats.csv
+head -6 $out/${tag}_x3_kernel_stats.csv
