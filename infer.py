@@ -51,6 +51,7 @@ def _load_models(args, device):
                          "the MLP denoiser (config-1 plumbing) is served by t2ms_amd.model.denoiser.mlp; "
                          "the fused sampler drives the DiT")
     model = Transformer().to(device)
+    model.set_math(getattr(args, "math", "f32"))
     model.encoder = vae.encoder                                                     # infer.py:47
     if args.random_init:
         sd = synth.make_dit_state_dict(args.seed)
@@ -151,6 +152,8 @@ def build_parser():
     p.add_argument("--synthetic", type=int, default=0, help="serve N synthetic rows instead of the CSV")
     p.add_argument("--random_init", action="store_true", help="seeded synthetic weights instead of checkpoints")
     p.add_argument("--trace", action="store_true", help="decode row 0 after every step of the first batch")
+    p.add_argument("--math", default="f32", choices=["f32", "bf16x3"],
+                   help="matrix arithmetic of the DiT: f32 MFMA (default) or fp32-accurate split-bf16 products (faster)")
     return p
 
 

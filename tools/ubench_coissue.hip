@@ -8,7 +8,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int KIND, int NM, int NV>   // KIND 0: bf16 32x32x16, 1: f32 32x32x2
+template <int KIND, int NM, int NV, int CH = 2>   // KIND 0: bf16 32x32x16, 1: f32 32x32x2; CH = accumulator chains
 __global__ __launch_bounds__(256) void k(float* out, unsigned long long* cyc, int iters, float a0) {
     extern __shared__ float pad[];
     f32x16 acc[2];
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* cyc, in
 #pragma unroll
         for (int m = 0; m < (NM > 0 ? NM : 1); ++m) {
             if (NM > 0) {
-                if (KIND == 0) acc[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc[m & 1], 0, 0, 0);
+                if (KIND == 0) acc[m % CH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc[m % CH], 0, 0, 0);
                 else acc[m & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[m & 1], 0, 0, 0);
             }
 #pragma unroll
@@ -40,16 +40,16 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* cyc, in
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
-template <int KIND, int NM, int NV>
+template <int KIND, int NM, int NV, int CH = 2>
 void run(const char* name, int waves_per_simd, float* d, unsigned long long* c) {
     const int lds = 160 * 1024 / waves_per_simd - 1024;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k<KIND, NM, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k<KIND, NM, NV, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int iters = 2000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    k<KIND, NM, NV><<<256 * waves_per_simd, 256, lds>>>(d, c, iters, 1.0f);
+    k<KIND, NM, NV, CH><<<256 * waves_per_simd, 256, lds>>>(d, c, iters, 1.0f);
     hipEventRecord(e0);
-    k<KIND, NM, NV><<<256 * waves_per_simd, 256, lds>>>(d, c, iters, 1.0f);
+    k<KIND, NM, NV, CH><<<256 * waves_per_simd, 256, lds>>>(d, c, iters, 1.0f);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
@@ -65,6 +65,7 @@ int main() {
     hipMalloc(&d, 1024); hipMalloc(&c, 64);
     for (int w : {1, 2}) {
         run<0, 16, 0>("bf16: 16 MFMA", w, d, c);
+        run<0, 16, 0, 1>("bf16: 16 MFMA, ONE dependent chain", w, d, c);
         run<0, 0, 96>("96 v_fma (no MFMA)", w, d, c);
         run<0, 16, 3>("bf16: 16 x (MFMA + 3 v_fma)", w, d, c);
         run<0, 16, 6>("bf16: 16 x (MFMA + 6 v_fma)", w, d, c);
