@@ -199,6 +199,18 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
 int t2s_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                    void* stream);
+/* The same update for up to 64 tensors in ONE launch (the DiT has 48 trainable tensors).  table_dev: device array
+ * of n_tensors entries; total_chunks = sum over entries of ceil(n / 1024).  All entries share lr / betas / eps /
+ * weight_decay / step. */
+typedef struct t2s_adamw_tensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    uint64_t n;
+} t2s_adamw_tensor;
+int t2s_adamw_step_multi(const t2s_adamw_tensor* table_dev, int n_tensors, uint64_t total_chunks, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
 /* Backward of t2s_mse: da = 2 (a-b) g / n, db = -da (either may be NULL); grad_out: device scalar. */
 int t2s_mse_backward(const float* a, const float* b, const float* grad_out, float* da, float* db,
                      uint64_t n, void* stream);

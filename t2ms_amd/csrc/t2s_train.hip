@@ -476,6 +476,41 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     p[i] = pv - (lr / bc1) * mv / denom;
 }
 
+// the same update for a whole parameter list in ONE launch: workgroup b handles chunk (b - first[t]) of tensor t,
+// t found by a short scan of the (<= 64 entry) table staged in LDS
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const t2s_adamw_tensor* __restrict__ tab, int n_tensors, float lr,
+                                                          float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+    __shared__ unsigned int first[65];
+    __shared__ t2s_adamw_tensor ent;
+    if (threadIdx.x == 0) {
+        unsigned int acc = 0;
+        int t = 0;
+        for (; t < n_tensors; ++t) {
+            const unsigned int nb = (unsigned int)((tab[t].n + 1023) / 1024);
+            if (blockIdx.x < acc + nb) break;
+            acc += nb;
+        }
+        first[0] = acc;
+        ent = tab[t < n_tensors ? t : n_tensors - 1];
+    }
+    __syncthreads();
+    const size_t base = (size_t)(blockIdx.x - first[0]) * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const size_t i = base + threadIdx.x + 256 * u;
+        if (i >= ent.n) return;
+        float pv = ent.param[i];
+        const float gv = ent.grad[i];
+        pv *= 1.0f - lr * wd;
+        const float mv = b1 * ent.exp_avg[i] + (1.0f - b1) * gv;
+        const float vv = b2 * ent.exp_avg_sq[i] + (1.0f - b2) * gv * gv;
+        ent.exp_avg[i] = mv;
+        ent.exp_avg_sq[i] = vv;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        ent.param[i] = pv - (lr / bc1) * mv / denom;
+    }
+}
+
 __global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                       const float* __restrict__ gout, float* __restrict__ da, size_t n,
                                                       float sign) {
@@ -958,6 +993,17 @@ int t2s_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
     adamw_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, (size_t)n, lr,
                                                                                 beta1, beta2, eps, weight_decay, bc1,
                                                                                 sqrtf(bc2));
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+int t2s_adamw_step_multi(const t2s_adamw_tensor* table_dev, int n_tensors, uint64_t total_chunks, float lr, float beta1,
+                         float beta2, float eps, float weight_decay, int step, void* stream) {
+    T2S_REQUIRE(table_dev && n_tensors > 0 && n_tensors <= 64 && total_chunks > 0 && step > 0, "t2s_adamw_step_multi: bad argument");
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2 = 1.0f - powf(beta2, (float)step);
+    adamw_multi_kernel<<<(unsigned)total_chunks, 256, 0, (hipStream_t)stream>>>(table_dev, n_tensors, lr, beta1, beta2, eps,
+                                                                                weight_decay, bc1, sqrtf(bc2));
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }

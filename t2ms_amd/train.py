@@ -156,6 +156,7 @@ class T2SAdamW(torch.optim.Optimizer):
         lib = L.lib()
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            todo = []
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -167,17 +168,46 @@ class T2SAdamW(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
-                g = L.as_f32(p.grad)
-                with torch.cuda.device(p.device):
-                    L.check(lib.t2s_adamw_step(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
-                                               st["exp_avg_sq"].data_ptr(), p.numel(), float(group["lr"]),
-                                               float(b1), float(b2), float(group["eps"]),
-                                               float(group["weight_decay"]), int(st["step"].item()),
-                                               L.stream_ptr(p.device)), "t2s_adamw_step")
-                # the kernel wrote p in place behind autograd's back: bump the version counter so the
-                # mirror's packed-weight cache (keyed on data_ptr + _version) notices
+                todo.append((p, L.as_f32(p.grad), st))
+            if not todo:
+                continue
+            steps = {int(st["step"].item()) for _, _, st in todo}
+            dev = todo[0][0].device
+            same_dev = all(p.device == dev for p, _, _ in todo)
+            if len(steps) == 1 and same_dev and len(todo) <= 64:
+                # one launch for the whole group: device table of (param, grad, exp_avg, exp_avg_sq, n), rebuilt
+                # only when a pointer changed (the flat gradient bucket is re-allocated by every backward)
+                rows = [(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+                        for p, g, st in todo]
+                key = tuple(rows)
+                cache = group.setdefault("_t2s_table", {})
+                if cache.get("key") != key:
+                    cache["key"] = key
+                    cache["dev"] = torch.tensor(rows, dtype=torch.int64).to(dev)      # 5 x 8 bytes = t2s_adamw_tensor
+                    cache["chunks"] = sum((r[4] + 1023) // 1024 for r in rows)
+                with torch.cuda.device(dev):
+                    L.check(lib.t2s_adamw_step_multi(cache["dev"].data_ptr(), len(rows), cache["chunks"], float(group["lr"]),
+                                                     float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                                     steps.pop(), L.stream_ptr(dev)), "t2s_adamw_step_multi")
+            else:
+                for p, g, st in todo:
+                    with torch.cuda.device(p.device):
+                        L.check(lib.t2s_adamw_step(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
+                                                   st["exp_avg_sq"].data_ptr(), p.numel(), float(group["lr"]),
+                                                   float(b1), float(b2), float(group["eps"]),
+                                                   float(group["weight_decay"]), int(st["step"].item()),
+                                                   L.stream_ptr(p.device)), "t2s_adamw_step")
+            # the kernels wrote the parameters in place behind autograd's back: bump the version counters so the
+            # mirror's packed-weight cache (keyed on data_ptr + _version) notices
+            for p, _, _ in todo:
                 torch.autograd.graph.increment_version(p)
         return loss
+
+    def state_dict(self):
+        sd = super().state_dict()
+        for g in sd["param_groups"]:
+            g.pop("_t2s_table", None)      # device pointers: never part of a checkpoint
+        return sd
 
 
 # ---------------------------------------------------------------------------- data parallel
