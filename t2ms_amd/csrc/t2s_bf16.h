@@ -104,6 +104,8 @@ struct BGemmArgs {
 // (lane-linear 16-byte fragments: conflict-free ds_read_b128) -> epilogue stores.  No barrier after
 // the weight load; HBM latency is hidden by the three waves per SIMD.
 constexpr int BG_THREADS = 768;
+constexpr int BG_STAGE_STRIDE = 144;                     // bytes per staged token row (128 data + 16 pad)
+constexpr int BG_STAGE_BYTES = 32 * BG_STAGE_STRIDE;     // per wave
 
 template <int K, int N, int PRO, int EPI>
 __global__ __launch_bounds__(BG_THREADS) void bgemm_kernel(const BGemmArgs a) {
@@ -112,6 +114,11 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_kernel(const BGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char wl[];
     bf16x8* wlds = reinterpret_cast<bf16x8*>(wl);
     float* blds = reinterpret_cast<float*>(wl + (size_t)N * K * 2);
+    // per-wave output staging tile: 32 token rows x (128 + 16) bytes.  The accumulator hands each lane 8-byte
+    // pieces of a row; written straight to HBM they arrive as partial lines (measured 2.6 TB/s of stores against
+    // 5.6 TB/s of loads), so two 32-column n-tiles are gathered in LDS and leave as whole 128-byte lines, 16 bytes per
+    // lane (q / k / v head tiles: 64-byte rows that are contiguous across tokens, one 2 KiB run per n-tile).
+    char* stage = wl + (size_t)N * K * 2 + (size_t)N * 4 + (size_t)(threadIdx.x >> 6) * BG_STAGE_BYTES;
     for (int c = threadIdx.x; c < N * K / 8; c += BG_THREADS) wlds[c] = a.Wp[c];
     for (int c = threadIdx.x; c < N; c += BG_THREADS) blds[c] = a.bias != nullptr ? a.bias[c] : 0.f;
     __syncthreads();
@@ -198,17 +205,30 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_kernel(const BGemmArgs a) {
                 const int col = nt * 32 + 8 * g + 4 * h;
                 f32x4 y = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
                 y += *reinterpret_cast<const f32x4*>(blds + col);
-                if constexpr (EPI == BEPI_BF16) {
-                    *reinterpret_cast<bf16x4*>(a.out + row * N + col) = pack4(y);
-                } else if constexpr (EPI == BEPI_GELUBWD) {
+                if constexpr (EPI == BEPI_GELUBWD) {
                     const f32x4 u = unpack4(aux4[g]);
                     y.x *= gelu_tanh_grad(u.x); y.y *= gelu_tanh_grad(u.y);
                     y.z *= gelu_tanh_grad(u.z); y.w *= gelu_tanh_grad(u.w);
-                    *reinterpret_cast<bf16x4*>(a.out + row * N + col) = pack4(y);
-                } else {   // BEPI_QKV: n-tile nt = (which, head)
-                    __bf16* base = (nt >> 2) == 0 ? a.q : ((nt >> 2) == 1 ? a.k : a.v);
-                    const int head = nt & 3;
-                    *reinterpret_cast<bf16x4*>(base + (((size_t)seq * NH + head) * NTOK + tok) * DH + 8 * g + 4 * h) = pack4(y);
+                }
+                // stage: row i, byte (nt & 1) * 64 + 2 * (8g + 4h)
+                *reinterpret_cast<bf16x4*>(stage + i * BG_STAGE_STRIDE + (EPI == BEPI_QKV ? 0 : (nt & 1) * 64) + 16 * g + 8 * h) = pack4(y);
+            }
+            if constexpr (EPI == BEPI_QKV) {
+                // one head tile: 32 tokens x 64 B, contiguous in the (bh, tok, d) tensor: two 1 KiB stores
+                __bf16* base = (nt >> 2) == 0 ? a.q : ((nt >> 2) == 1 ? a.k : a.v);
+                char* dst = reinterpret_cast<char*>(base + (((size_t)seq * NH + (nt & 3)) * NTOK + (tok - i)) * DH);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int r = 16 * u + (lane >> 2), c16 = lane & 3;
+                    *reinterpret_cast<bf16x8*>(dst + r * 64 + c16 * 16) = *reinterpret_cast<const bf16x8*>(stage + r * BG_STAGE_STRIDE + c16 * 16);
+                }
+            } else if (nt & 1) {
+                // two n-tiles = 64 columns = one 128-byte line per row: four stores of 8 rows x 128 B
+                char* dst = reinterpret_cast<char*>(a.out + ((size_t)tile * 32) * N + (nt - 1) * 32);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = 8 * u + (lane >> 3), c16 = lane & 7;
+                    *reinterpret_cast<bf16x8*>(dst + (size_t)r * N * 2 + c16 * 16) = *reinterpret_cast<const bf16x8*>(stage + r * BG_STAGE_STRIDE + c16 * 16);
                 }
             }
         }
@@ -221,7 +241,7 @@ inline int launch_bgemm(const BGemmArgs& a, hipStream_t st) {
         set_error("bgemm: M=%d must be a positive multiple of 32 and N=%d must equal %d", a.M, a.N, N);
         return T2S_E_INVALID;
     }
-    constexpr int lds = N * K * 2 + N * 4;
+    constexpr int lds = N * K * 2 + N * 4 + (BG_THREADS / 64) * BG_STAGE_BYTES;
     static int n_cu = 0;
     static bool attr = false;   // first call is never under stream capture (training is not captured)
     if (n_cu == 0) {
