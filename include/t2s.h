@@ -338,13 +338,24 @@ int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, const float* no
                     float* series, float* trace0, void* stream);
 
 /* ------------------------------------------------------------------------ *
- * Reconstruction metrics: evaluation.py:166-206 (calculate_mse, calculate_wape)
+ * Evaluation metrics: evaluation.py:166-206 (calculate_mse, calculate_wape), :21-45 (calculate_mrr)
  * ------------------------------------------------------------------------ */
 /* ori, gen: (n, len) device arrays, len = L * n_series of the (N, L, n_series) arrays infer.py writes;
  * per_sample: (n, 2) output = [mse_i, wape_i (NaN when sum |ori_i| == 0)]; out: [MSE, WAPE] =
  * [mean_i mse_i, nanmean_i wape_i].  Deterministic summation order. */
 int t2s_eval_mse_wape(const float* ori, const float* gen, float* per_sample, float* out, int n, int len,
                       void* stream);
+
+/* MRR over repeated generations: evaluation.py:21-45 (calculate_mrr) with cosine_similarity of
+ * Dataset_Construction_Pipeline/Evaluate_Datasets.py:6-15, as evaluation.py:298-314 feeds it (x_1.npy against the
+ * x_t.npy of run_0..run_{runs-1}).
+ * ori (n, len); gen (runs, n, len), run-major (the reference stacks the runs on a trailing axis; the host mirror
+ * passes them in the order it loads them); sims (n, runs) output: the cosine similarities (0 where not finite);
+ * score (n) output: 1 / (g + 1) for the best run g when its similarity exceeds `threshold` (the reference uses
+ * 0.5, evaluation.py:300), else 0 -- g is the run INDEX, as the reference computes it; ties go to the largest
+ * index; out[0] = mean score. */
+int t2s_eval_mrr(const float* ori, const float* gen, float* sims, float* score, float* out, int n, int len,
+                 int runs, float threshold, void* stream);
 
 #ifdef __cplusplus
 }

@@ -426,3 +426,30 @@ def eval_wape(ori, gen):
         vals.append(ae / av if av != 0 else np.nan)
     return float(np.nanmean(np.asarray(vals)))
 
+
+
+def eval_cosine(a, b):
+    """cosine_similarity (Dataset_Construction_Pipeline/Evaluate_Datasets.py:6-15): flattened dot / norms, nan_to_num."""
+    import numpy as np
+    a, b = np.asarray(a, dtype=np.float64).ravel(), np.asarray(b, dtype=np.float64).ravel()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s = np.sum(a * b) / (np.linalg.norm(a) * np.linalg.norm(b))
+    return float(np.nan_to_num(s))
+
+
+def eval_mrr(ori, gen, threshold=0.5):
+    """calculate_mrr (evaluation.py:21-45) with k = all runs: ori (N, L, S), gen (N, L, S, G).  The runs are
+    visited by descending similarity (reversed argsort) and the first one above the threshold gives
+    rank = its run index + 1 (:37-41; the index, not the position in the ordering); 0 if none."""
+    import numpy as np
+    ori, gen = np.asarray(ori), np.asarray(gen)
+    scores = np.zeros(ori.shape[0])
+    for i in range(ori.shape[0]):
+        sims = [eval_cosine(ori[i], gen[i, :, :, g]) for g in range(gen.shape[3])]
+        rank = None
+        for idx in np.argsort(sims, kind="stable")[::-1]:
+            if sims[idx] > threshold:
+                rank = idx + 1
+                break
+        scores[i] = 1.0 / rank if rank is not None else 0.0
+    return float(np.mean(scores))

@@ -84,6 +84,7 @@ SYMBOLS = {
     "t2s_dit_set_train_dtype": (_I, [_VP, _I]),
     "t2s_dit_set_math": (_I, [_VP, _I]),
     "t2s_eval_mse_wape": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP]),
+    "t2s_eval_mrr": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _F, _VP]),
     "t2s_attn_fwd_x3": (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_attn_fwd_bf16": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_dit_train_forward": (_I, [_VP, C.POINTER(DitWeights), _VP, _VP, _I, _VP, _VP, _I, _VP]),

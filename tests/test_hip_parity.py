@@ -586,3 +586,27 @@ def test_eval_mse_wape_vs_oracle(dev):
     m3, w3, _ = mse_wape(o3, g3, dev)
     np.testing.assert_allclose(m3, O.eval_mse(o3, g3), rtol=1e-5)
     np.testing.assert_allclose(w3, O.eval_wape(o3, g3), rtol=1e-5)
+
+
+def test_eval_mrr_vs_oracle(dev):
+    """t2s_eval_mrr (evaluation.py:21-45) on 10 runs of (N, L, 1) series as `infer.py --run_multi` writes them:
+    similarities, per-sample scores and the mean against the oracle, incl. a below-threshold row, an exact tie
+    (later run wins) and an all-zero original."""
+    from t2ms_amd.metrics import mrr
+    rs = np.random.RandomState(9)
+    n, runs = 41, 10
+    ori = rs.uniform(-1, 1, size=(n, 96, 1)).astype(np.float32)
+    gens = [(ori * rs.uniform(0.2, 1.0, size=(n, 1, 1)) + rs.uniform(0.1, 1.5) * rs.randn(n, 96, 1)).astype(np.float32)
+            for _ in range(runs)]
+    for g in gens:
+        g[3] = rs.randn(96, 1)           # unrelated: every similarity below the threshold
+    gens[2][7] = gens[6][7] = 2.0 * ori[7]   # exact tie at similarity 1: run 6 wins
+    ori[11] = 0.0
+    m, sims, score = mrr(ori, gens, 0.5, dev)
+    stacked = np.stack(gens, axis=-1)
+    ref_sims = np.array([[O.eval_cosine(ori[i], stacked[i, :, :, g]) for g in range(runs)] for i in range(n)])
+    np.testing.assert_allclose(sims.numpy(), ref_sims, atol=2e-7)
+    assert abs(m - O.eval_mrr(ori, stacked, 0.5)) < 1e-6
+    assert score[3] == 0 and score[11] == 0 and abs(score[7].item() - 1 / 7) < 1e-7
+    m2, _, _ = mrr(ori, stacked, 0.5, dev)   # the stacked (N, L, 1, G) form evaluation.py builds
+    assert m2 == m

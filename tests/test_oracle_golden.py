@@ -184,3 +184,19 @@ def test_eval_metrics_restatement():
     ori[2, :, 0] = [2, 2, 2, 2]; gen[2, :, 0] = [1, 1, 1, 1]        # mse 1.0, wape 0.5
     assert abs(O.eval_mse(ori, gen) - 1.0) < 1e-12
     assert abs(O.eval_wape(ori, gen) - 0.35) < 1e-12
+
+
+def test_eval_mrr_restatement():
+    """oracle.eval_mrr (evaluation.py:21-45) on hand-checkable cases: the score is 1 / (run index + 1) of the best
+    run when it clears the threshold, ties go to the later run, a zero vector has similarity 0."""
+    import numpy as np
+    ori = np.zeros((4, 3, 1)); gen = np.zeros((4, 3, 1, 3))
+    ori[0, :, 0] = [1, 0, 0]; gen[0, :, 0, :] = np.array([[0, 1, 0], [1, 1, 0], [1, 0, 0]]).T   # best = run 2 -> 1/3
+    ori[1, :, 0] = [1, 0, 0]; gen[1, :, 0, :] = np.array([[2, 0, 0], [0, 1, 0], [3, 0, 0]]).T   # tie 0 / 2 -> run 2 -> 1/3
+    ori[2, :, 0] = [1, 0, 0]; gen[2, :, 0, :] = np.array([[1, 2, 0], [0, 1, 0], [0, 0, 1]]).T   # best 0.447 < 0.5 -> 0
+    ori[3, :, 0] = [0, 0, 0]; gen[3, :, 0, :] = 1.0                                              # zero vector -> 0
+    assert abs(O.eval_cosine([1, 0, 0], [1, 1, 0]) - 2 ** -0.5) < 1e-12
+    assert O.eval_cosine([0, 0], [1, 1]) == 0.0
+    assert abs(O.eval_mrr(ori, gen) - (1 / 3 + 1 / 3) / 4) < 1e-12
+    gen[1, :, 0, 0] = [2, 0, 0]; gen[1, :, 0, 2] = [3, 0.1, 0]                                   # run 0 now best -> 1
+    assert abs(O.eval_mrr(ori, gen) - (1 / 3 + 1.0) / 4) < 1e-12
