@@ -143,7 +143,7 @@ def alt_math_run(model, vae, args, dev, text):
     model.set_math("bf16x3")
     try:
         s2 = Sampler(model, vae.decoder, args.backbone, args.diffusion_steps, args.cfg_scale, args.batch, args.length,
-                     dev, use_graph=not args.no_graph, seed=2025, row0=0)
+                     dev, use_graph=not args.no_graph, seed=2025, row0=0, lanes=args.lanes)
         s2.run(text, decode=True)                 # captures its own graph with the x3 kernels
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--length", type=int, default=96)
     ap.add_argument("--backbone", default="ddpm", choices=["ddpm", "flowmatching"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2],
+                    help="sampler lanes: 0 = the library's default (two half-batch chains on two streams from B >= 128), 1, 2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the extra bf16x3 measurement reported as alt_math")
     ap.add_argument("--math", default="f32", choices=["f32", "bf16x3"],
@@ -197,7 +199,7 @@ def main():
     model, vae = build_models(dev)
     model.set_math(args.math)
     sampler = Sampler(model, vae.decoder, args.backbone, args.diffusion_steps, args.cfg_scale, B, args.length,
-                      dev, use_graph=not args.no_graph, seed=2025, row0=rank * B)
+                      dev, use_graph=not args.no_graph, seed=2025, row0=rank * B, lanes=args.lanes)
     text = synth.make_text_embeddings(2025, B, row0=rank * B).to(dev)
     sampler.run(text, decode=True)                      # allocates persistent buffers, captures the graph
     for _ in range(max(0, args.warmup - 1)):

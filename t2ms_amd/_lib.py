@@ -108,6 +108,7 @@ SYMBOLS = {
     "t2s_sampler_create": (_I, [_VP, _VP, C.POINTER(SampleConfig), C.POINTER(_VP)]),
     "t2s_sampler_destroy": (None, [_VP]),
     "t2s_sampler_run": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "t2s_sampler_set_lanes": (_I, [_VP, _I]),
 }
 
 _lib: Optional[C.CDLL] = None

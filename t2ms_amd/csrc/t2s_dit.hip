@@ -219,19 +219,32 @@ struct TimeScope {   // records an event pair around one launch when timing is o
 };
 
 // One DiT forward over S sequences (sequence s reads latent row s % B).
+// ws_seq0: first workspace slot (in sequences) this pass may use -- the sampler runs two half batches as independent
+// lanes on two streams, each in its own slice of the workspace (slots [ws_seq0, ws_seq0 + S))
 int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const float* temb,
                 int temb_rows, const int* step_ptr, const float* text, float* out0, float* out1,
-                int split, hipStream_t st, bool keep_stream = true) {
+                int split, hipStream_t st, bool keep_stream = true, int ws_seq0 = 0) {
     int rc;
+    const size_t tok0 = (size_t)ws_seq0 * NTOK * D;
+    float* const w_h = h->h + tok0;
+    float* const w_q = h->q + tok0;
+    float* const w_k = h->k + tok0;
+    float* const w_v = h->v + tok0;
+    float* const w_ao = h->ao + tok0;
+    float* const w_h0 = h->h0 + tok0 / 2;                      // one slot per PAIR of sequences (CFG pass)
+    float* const w_mod = h->mod + (size_t)ws_seq0 * MODROW;
+    float* const w_c = h->c + (size_t)ws_seq0 * D;
+    __bf16* const w_k3 = h->k3 ? h->k3 + tok0 * 3 : nullptr;
+    __bf16* const w_v3 = h->v3 ? h->v3 + tok0 * 3 : nullptr;
     {
         TimeScope ts(h, TC_OTHER, st);
-        cond_kernel<<<(S * D + 255) / 256, 256, 0, st>>>(h->c, temb, temb_rows, step_ptr, text,
+        cond_kernel<<<(S * D + 255) / 256, 256, 0, st>>>(w_c, temb, temb_rows, step_ptr, text,
                                                          uncond_rows, S);
     }
     T2S_LAUNCH_CHECK();
     {   // adaLN for all 4 blocks at once: mod = silu(c) @ W_ada^T + b   (transformer.py:106-109,115)
         GemmArgs a{};
-        a.A = h->c; a.Wp = h->ada_p; a.bias = h->ada_b; a.out = h->mod; a.M = S; a.N = MODROW;
+        a.A = w_c; a.Wp = h->ada_p; a.bias = h->ada_b; a.out = w_mod; a.M = S; a.N = MODROW;
         TimeScope ts(h, TC_OTHER, st);
         if ((rc = launch_gemm_rows<128, 3, PRO_SILU, EPI_BIAS>(a, st)) != T2S_OK) return rc;
     }
@@ -239,7 +252,7 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
     // computed, into their own buffer; block 0's kernels read sequence s % B from it (in place would race:
     // the workgroup of sequence s overwrites slot s while that of s + B still reads it)
     const bool shared_in = S == 2 * B;
-    float* tokens = shared_in ? h->h0 : h->h;
+    float* tokens = shared_in ? w_h0 : w_h;
     const int in_seqs = shared_in ? B : S;
     {
         const int threads = in_seqs * NTOK * 32;
@@ -253,9 +266,9 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
     //   rows<qkv only>(block 0) ; { attention(i) ; rows<proj+MLP of i, qkv of i+1> } x 4
     auto rows_args = [&](int blk, int qkv_blk) {
         RowArgs a{};
-        a.x = h->h; a.ao = h->ao; a.mod = h->mod; a.M = M; a.blk = blk; a.qkv_blk = qkv_blk;
+        a.x = w_h; a.ao = w_ao; a.mod = w_mod; a.M = M; a.blk = blk; a.qkv_blk = qkv_blk;
         const bool first = blk <= 0 && qkv_blk <= 1;     // rows<qkv 0> and rows<block 0, qkv 1> read the patchified tokens
-        a.x_in = first ? tokens : h->h; a.in_seqs = first ? in_seqs : S;
+        a.x_in = first ? tokens : w_h; a.in_seqs = first ? in_seqs : S;
         if (blk == NBLK - 1) {   // the last kernel also runs the final layer
             a.f_lnw = h->ln_w; a.f_lnb = h->ln_b; a.f_ow = h->out_w; a.f_ob = h->out_b;
             a.out0 = out0; a.out1 = out1; a.split = split; a.keep_x = keep_stream;
@@ -265,7 +278,7 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
             a.bp = h->proj_b[blk]; a.b1 = h->fc1_b[blk]; a.b2 = h->fc2_b[blk];
         }
         if (qkv_blk >= 0) { a.Wq = h->qkv_p[qkv_blk]; a.bq = h->qkv_b[qkv_blk]; }
-        a.q = h->q; a.k = h->k; a.v = h->v;
+        a.q = w_q; a.k = w_k; a.v = w_v;
         return a;
     };
     // T2S_MATH_BF16X3: every product of the row chain and of the attention is evaluated as six bf16 MFMAs
@@ -273,9 +286,9 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
     const bool x3 = h->math == T2S_MATH_BF16X3;
     auto rows_args_x3 = [&](int blk, int qkv_blk) {
         RowArgsX3 a{};
-        a.x = h->h; a.ao = h->ao; a.mod = h->mod; a.M = M; a.blk = blk; a.qkv_blk = qkv_blk;
+        a.x = w_h; a.ao = w_ao; a.mod = w_mod; a.M = M; a.blk = blk; a.qkv_blk = qkv_blk;
         const bool first = blk <= 0 && qkv_blk <= 1;
-        a.x_in = first ? tokens : h->h; a.in_seqs = first ? in_seqs : S;
+        a.x_in = first ? tokens : w_h; a.in_seqs = first ? in_seqs : S;
         if (blk == NBLK - 1) {
             a.f_lnw = h->ln_w; a.f_lnb = h->ln_b; a.f_ow = h->out_w; a.f_ob = h->out_b;
             a.out0 = out0; a.out1 = out1; a.split = split; a.keep_x = keep_stream;
@@ -286,7 +299,7 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
             a.bp = h->proj_b[blk]; a.b1 = h->fc1_b[blk]; a.b2 = h->fc2_b[blk];
         }
         if (qkv_blk >= 0) { a.Wq = reinterpret_cast<const bf16x8*>(h->qkv3[qkv_blk]); a.bq = h->qkv_b[qkv_blk]; }
-        a.q = h->q; a.k3 = h->k3; a.v3 = h->v3;
+        a.q = w_q; a.k3 = w_k3; a.v3 = w_v3;
         return a;
     };
     {
@@ -297,8 +310,8 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
     for (int i = 0; i < NBLK; ++i) {
         {
             TimeScope ts(h, TC_ATTN, st);
-            rc = x3 ? launch_attn_x3(h->q, h->k3, h->v3, h->ao, S * NH, st)
-                    : launch_attn_packed(h->q, h->k, h->v, h->ao, S * NH, st);
+            rc = x3 ? launch_attn_x3(w_q, w_k3, w_v3, w_ao, S * NH, st)
+                    : launch_attn_packed(w_q, w_k, w_v, w_ao, S * NH, st);
             if (rc != T2S_OK) return rc;
         }
         TimeScope ts(h, TC_ROWS, st);
@@ -317,8 +330,9 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
 // exported to the sampler TU
 namespace t2s {
 int dit_forward_cfg_step(t2s_dit* h, const float* x, const float* temb_table, const int* step_ptr,
-                         const float* text, float* out_u, float* out_c, int B, hipStream_t st) {
-    return run_forward(h, x, B, 2 * B, B, temb_table, 1, step_ptr, text, out_u, out_c, B, st, /*keep_stream=*/false);
+                         const float* text, float* out_u, float* out_c, int B, hipStream_t st, int ws_seq0) {
+    return run_forward(h, x, B, 2 * B, B, temb_table, 1, step_ptr, text, out_u, out_c, B, st, /*keep_stream=*/false,
+                       ws_seq0);
 }
 }  // namespace t2s
 
@@ -466,7 +480,7 @@ int t2s_dit_forward_cfg(t2s_dit* h, const float* x, const float* temb, const flo
     T2S_REQUIRE(B > 0 && 2 * B <= h->max_seqs, "t2s_dit_forward_cfg: 2*B=%d exceeds max_seqs=%d", 2 * B,
                 h->max_seqs);
     return t2s::dit_forward_cfg_step(h, x, temb, nullptr, text, out_uncond, out_cond, B,
-                                     (hipStream_t)stream);
+                                     (hipStream_t)stream, 0);
 }
 
 int t2s_dit_timing_begin(t2s_dit* h) {

@@ -6,6 +6,7 @@
 // into a hipGraph and replayed `steps` times; everything that changes from step to step
 // (time-embedding row, DDPM coefficients, noise stream / injected-noise slice) is looked up on
 // the device through a step counter that the last node of the graph advances.
+#include <stdlib.h>
 #include <vector>
 
 #include "t2s_common.h"
@@ -15,7 +16,7 @@ struct t2s_vae;
 
 namespace t2s {
 int dit_forward_cfg_step(t2s_dit* h, const float* x, const float* temb_table, const int* step_ptr,
-                         const float* text, float* out_u, float* out_c, int B, hipStream_t st);
+                         const float* text, float* out_u, float* out_c, int B, hipStream_t st, int ws_seq0);
 
 // ---------------------------------------------------------------- Philox4x32-10 + Box-Muller
 struct u32x4 { uint32_t x, y, z, w; };
@@ -70,7 +71,8 @@ struct StepArgs {
     float* x;             // (B,1920) in place
     const float* eps_u;   // (B,1920)
     const float* eps_c;   // (B,1920) or NULL
-    const float* noise;   // injected draws: (steps,B,1920) indexed by step, or (B,1920) if step_ptr NULL
+    const float* noise;   // injected draws: (steps,noise_rows,1920) indexed by step (this shard's first row), or
+                          // (B,1920) if step_ptr NULL
     const float* coef;    // DEVICE (T,3)
     const int* step_ptr;  // device loop index j, or NULL (then t_index / stream_id are immediate)
     int steps;            // T (t = steps-1-j when step_ptr != NULL)
@@ -80,6 +82,7 @@ struct StepArgs {
     uint32_t stream_id;
     uint32_t row0;
     int B;
+    int noise_rows;       // rows per step of the injected-noise array (>= B: a lane steps a row range of the batch)
 };
 
 __global__ __launch_bounds__(256) void ddpm_step_kernel(const StepArgs a) {
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const StepArgs a) {
         const int j = *a.step_ptr;
         t = a.steps - 1 - j;
         sid = (uint32_t)j;
-        if (noise) noise += (size_t)j * a.B * LAT;
+        if (noise) noise += (size_t)j * a.noise_rows * LAT;
     }
     const float c0 = a.coef[t * 3 + 0], c1 = a.coef[t * 3 + 1], c2 = a.coef[t * 3 + 2];
     const f32x4 x = reinterpret_cast<const f32x4*>(a.x)[idx];
@@ -303,10 +306,19 @@ struct t2s_sampler {
     float* eps_u = nullptr;       // (B,1920)
     float* eps_c = nullptr;
     float* tvals = nullptr;       // (steps)
-    int* step = nullptr;          // device loop index
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    // pointers the captured graph was built for
+    int* step = nullptr;          // device loop indices, one per lane (16 ints apart)
+    // Lanes: the rows of the batch are independent through the whole loop, so the batch can run as TWO half
+    // batches, each a complete chain (own step counter, own hipGraph, own slice of the DiT workspace) on its own
+    // stream, joined only before the decode.  One chain alone drains and refills the chip at each of its 9 kernel
+    // boundaries per pass and the row-chain kernel quantises to 7.5 tiles per SIMD at 512 sequences; the other
+    // lane's kernels fill those holes.  Results are bitwise those of one lane (batch-invariant kernels).
+    int lanes_req = 0;            // 0 = automatic, 1, 2 (t2s_sampler_set_lanes)
+    int lanes_cap = 0;            // lanes the graphs below were captured for
+    hipGraph_t graph[2] = {nullptr, nullptr};
+    hipGraphExec_t exec[2] = {nullptr, nullptr};
+    hipStream_t side = nullptr;   // lane 1
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // pointers the captured graphs were built for
     float* g_x = nullptr;
     const float* g_text = nullptr;
     const float* g_noise = nullptr;
@@ -314,32 +326,50 @@ struct t2s_sampler {
 
 namespace {
 
-int enqueue_step(t2s_sampler* s, float* x, const float* text, const float* noise, hipStream_t st) {
+// one loop iteration of rows [r0, r0 + n) of the batch on stream st, stepping the lane's counter
+int enqueue_step(t2s_sampler* s, float* x, const float* text, const float* noise, hipStream_t st, int lane, int r0,
+                 int n) {
     const t2s_sample_config& c = s->cfg;
-    int rc = dit_forward_cfg_step(s->dit, x, s->temb_table, s->step, text, s->eps_u, s->eps_c, c.batch, st);
+    int* step = s->step + 16 * lane;
+    float* xl = x + (size_t)r0 * LAT;
+    float* eu = s->eps_u + (size_t)r0 * LAT;
+    float* ec = s->eps_c + (size_t)r0 * LAT;
+    int rc = dit_forward_cfg_step(s->dit, xl, s->temb_table, step, text + (size_t)r0 * D, eu, ec, n, st, 2 * r0);
     if (rc != T2S_OK) return rc;
     if (c.mode == T2S_MODE_DDPM) {
         StepArgs a{};
-        a.x = x; a.eps_u = s->eps_u; a.eps_c = s->eps_c; a.noise = noise; a.coef = s->coef;
-        a.step_ptr = s->step; a.steps = c.steps; a.cfg = c.cfg_scale; a.seed = c.seed; a.row0 = c.row0;
-        a.B = c.batch;
-        const int total = c.batch * (LAT / 4);
+        a.x = xl; a.eps_u = eu; a.eps_c = ec; a.noise = noise ? noise + (size_t)r0 * LAT : nullptr; a.coef = s->coef;
+        a.step_ptr = step; a.steps = c.steps; a.cfg = c.cfg_scale; a.seed = c.seed; a.row0 = c.row0 + (uint32_t)r0;
+        a.B = n; a.noise_rows = c.batch;
+        const int total = n * (LAT / 4);
         ddpm_step_kernel<<<(total + 255) / 256, 256, 0, st>>>(a);
     } else {
-        const int n4 = c.batch * (LAT / 4);
-        rf_step_kernel<<<(n4 + 255) / 256, 256, 0, st>>>(x, s->eps_u, s->eps_c, c.cfg_scale, 1.0f / (float)c.steps, n4);
+        const int n4 = n * (LAT / 4);
+        rf_step_kernel<<<(n4 + 255) / 256, 256, 0, st>>>(xl, eu, ec, c.cfg_scale, 1.0f / (float)c.steps, n4);
     }
     T2S_LAUNCH_CHECK();
-    set_step_kernel<<<1, 64, 0, st>>>(s->step, 0, 1);
+    set_step_kernel<<<1, 64, 0, st>>>(step, 0, 1);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }
 
 void drop_graph(t2s_sampler* s) {
-    if (s->exec) (void)hipGraphExecDestroy(s->exec);
-    if (s->graph) (void)hipGraphDestroy(s->graph);
-    s->exec = nullptr;
-    s->graph = nullptr;
+    for (int l = 0; l < 2; ++l) {
+        if (s->exec[l]) (void)hipGraphExecDestroy(s->exec[l]);
+        if (s->graph[l]) (void)hipGraphDestroy(s->graph[l]);
+        s->exec[l] = nullptr;
+        s->graph[l] = nullptr;
+    }
+    s->lanes_cap = 0;
+}
+
+// lanes of this run: two when asked for, or automatically when each half batch still fills the chip
+// (>= 64 series = 128 sequences per lane; measured: 4.0 % faster at B = 256, nothing to gain at 2 x 32)
+int pick_lanes(const t2s_sampler* s, bool trace) {
+    if (trace || s->cfg.batch < 2) return 1;
+    if (s->lanes_req) return s->lanes_req;
+    if (const char* e = getenv("T2S_SAMPLER_LANES")) return atoi(e) == 2 ? 2 : 1;
+    return s->cfg.batch >= 128 ? 2 : 1;
 }
 
 }  // namespace
@@ -367,7 +397,7 @@ extern "C" int t2s_sampler_create(t2s_dit* dit, t2s_vae* vae, const t2s_sample_c
     alloc((void**)&s->eps_u, B * LAT * sizeof(float));
     alloc((void**)&s->eps_c, B * LAT * sizeof(float));
     alloc((void**)&s->tvals, T * sizeof(float));
-    alloc((void**)&s->step, 64);
+    alloc((void**)&s->step, 2 * 16 * sizeof(int));   // one counter per lane, 64 B apart
     if (e == hipSuccess) e = hipMemcpy(s->tvals, cfg->t_values, T * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess && cfg->mode == T2S_MODE_DDPM)
         e = hipMemcpy(s->coef, cfg->ddpm_coef, T * 3 * sizeof(float), hipMemcpyHostToDevice);
@@ -390,9 +420,18 @@ extern "C" int t2s_sampler_create(t2s_dit* dit, t2s_vae* vae, const t2s_sample_c
     return T2S_OK;
 }
 
+extern "C" int t2s_sampler_set_lanes(t2s_sampler* s, int lanes) {
+    T2S_REQUIRE(s && lanes >= 0 && lanes <= 2, "t2s_sampler_set_lanes: lanes=%d (0 = automatic, 1, 2)", lanes);
+    s->lanes_req = lanes;
+    return T2S_OK;
+}
+
 extern "C" void t2s_sampler_destroy(t2s_sampler* s) {
     if (!s) return;
     drop_graph(s);
+    if (s->side) (void)hipStreamDestroy(s->side);
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     void* bufs[] = {s->temb_table, s->coef, s->eps_u, s->eps_c, s->tvals, s->step};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -409,15 +448,32 @@ extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, cons
     hipStream_t st = (hipStream_t)stream;
     const t2s_sample_config& c = s->cfg;
     int rc;
-    set_step_kernel<<<1, 64, 0, st>>>(s->step, 0, 0);
-    T2S_LAUNCH_CHECK();
+    const int lanes = pick_lanes(s, trace0 != nullptr);
+    if (lanes == 2 && !s->side) {
+        T2S_HIP_CHECK(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+        T2S_HIP_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+        T2S_HIP_CHECK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+    }
+    // lane l steps rows [r0[l], r0[l] + nr[l]) on lst[l]
+    // split point: half the batch, rounded to a multiple of 32 rows when both lanes keep >= 32 -- the persistent
+    // attention kernel walks 8 * rows / n_cu (sequence, head) items per CU, a whole number only in steps of 32 rows
+    // (a 144 + 112 split of 256 measured 12 % SLOWER than one lane, 128 + 128 or 160 + 96 4 % faster)
+    int cut = c.batch;
+    if (lanes == 2) {
+        cut = (c.batch + 1) / 2;
+        const int cut32 = (cut + 31) / 32 * 32;
+        if (c.batch - cut32 >= 32) cut = cut32;
+    }
+    const int r0[2] = {0, cut};
+    const int nr[2] = {r0[1], c.batch - r0[1]};
+    hipStream_t lst[2] = {st, s->side};
     const bool graph_ok = c.use_graph && !trace0 && st != nullptr;
-    if (graph_ok) {
-        if (!s->exec || s->g_x != x || s->g_text != text || s->g_noise != noise) {
-            drop_graph(s);
-            T2S_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            rc = enqueue_step(s, x, text, noise, st);
-            hipError_t e = hipStreamEndCapture(st, &s->graph);
+    if (graph_ok && (!s->exec[0] || s->lanes_cap != lanes || s->g_x != x || s->g_text != text || s->g_noise != noise)) {
+        drop_graph(s);
+        for (int l = 0; l < lanes; ++l) {
+            T2S_HIP_CHECK(hipStreamBeginCapture(lst[l], hipStreamCaptureModeThreadLocal));
+            rc = enqueue_step(s, x, text, noise, lst[l], l, r0[l], nr[l]);
+            hipError_t e = hipStreamEndCapture(lst[l], &s->graph[l]);
             if (rc != T2S_OK) {
                 drop_graph(s);
                 return rc;
@@ -427,19 +483,36 @@ extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, cons
                 drop_graph(s);
                 return T2S_E_HIP;
             }
-            T2S_HIP_CHECK(hipGraphInstantiate(&s->exec, s->graph, nullptr, nullptr, 0));
-            s->g_x = x; s->g_text = text; s->g_noise = noise;
+            T2S_HIP_CHECK(hipGraphInstantiate(&s->exec[l], s->graph[l], nullptr, nullptr, 0));
         }
-        for (int j = 0; j < c.steps; ++j) T2S_HIP_CHECK(hipGraphLaunch(s->exec, st));
-    } else {
-        for (int j = 0; j < c.steps; ++j) {
-            if ((rc = enqueue_step(s, x, text, noise, st)) != T2S_OK) return rc;
-            if (trace0) {
-                // infer.py:90-93: decode row 0 of the first batch after every step
-                if ((rc = t2s_vae_decode(s->vae, x, trace0 + (size_t)j * c.length, nullptr, 1, c.length, st)) != T2S_OK)
-                    return rc;
+        s->lanes_cap = lanes;
+        s->g_x = x; s->g_text = text; s->g_noise = noise;
+    }
+    if (lanes == 2) {   // fork: lane 1 starts after everything already queued on the caller's stream
+        T2S_HIP_CHECK(hipEventRecord(s->ev_fork, st));
+        T2S_HIP_CHECK(hipStreamWaitEvent(s->side, s->ev_fork, 0));
+    }
+    for (int l = 0; l < lanes; ++l) {
+        set_step_kernel<<<1, 64, 0, lst[l]>>>(s->step + 16 * l, 0, 0);
+        T2S_LAUNCH_CHECK();
+    }
+    for (int j = 0; j < c.steps; ++j) {
+        for (int l = 0; l < lanes; ++l) {
+            if (graph_ok) {
+                T2S_HIP_CHECK(hipGraphLaunch(s->exec[l], lst[l]));
+            } else if ((rc = enqueue_step(s, x, text, noise, lst[l], l, r0[l], nr[l])) != T2S_OK) {
+                return rc;
             }
         }
+        if (trace0) {
+            // infer.py:90-93: decode row 0 of the first batch after every step
+            if ((rc = t2s_vae_decode(s->vae, x, trace0 + (size_t)j * c.length, nullptr, 1, c.length, st)) != T2S_OK)
+                return rc;
+        }
+    }
+    if (lanes == 2) {   // join before the decode (and before anything the caller queues next)
+        T2S_HIP_CHECK(hipEventRecord(s->ev_join, s->side));
+        T2S_HIP_CHECK(hipStreamWaitEvent(st, s->ev_join, 0));
     }
     if (series) {
         if ((rc = t2s_vae_decode(s->vae, x, series, nullptr, c.batch, c.length, st)) != T2S_OK) return rc;

@@ -35,7 +35,9 @@ def loop_t_values(backbone: str, steps: int) -> torch.Tensor:
 
 class Sampler:
     def __init__(self, model, decoder, backbone: str, steps: int, cfg_scale: float, batch: int, length: int,
-                 device, use_graph: bool = True, seed: int = 2025, row0: int = 0):
+                 device, use_graph: bool = True, seed: int = 2025, row0: int = 0, lanes: int = 0):
+        """lanes: 0 = automatic (two half-batch chains on two streams from batch >= 128), 1, 2 -- see
+        t2s_sampler_set_lanes; a scheduling choice only, the results are bitwise the same."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise L.T2SError("Sampler needs a GPU device; the HIP path has no CPU fallback")
@@ -43,6 +45,7 @@ class Sampler:
         self.backbone, self.steps, self.cfg_scale = backbone, int(steps), float(cfg_scale)
         self.batch, self.length, self.seed, self.row0 = int(batch), int(length), int(seed), int(row0)
         self.use_graph = bool(use_graph)
+        self.lanes = int(lanes)
         self.stream = torch.cuda.Stream(self.device)
         self.ptr = None
         self._create()
@@ -69,6 +72,7 @@ class Sampler:
             torch.cuda.synchronize(self.device)
             self.ptr = C.c_void_p()
             L.check(L.lib().t2s_sampler_create(dit, vae, C.byref(cfg), C.byref(self.ptr)), "t2s_sampler_create")
+            L.check(L.lib().t2s_sampler_set_lanes(self.ptr, self.lanes), "t2s_sampler_set_lanes")
         self._fin = weakref.finalize(self, L.lib().t2s_sampler_destroy, self.ptr)
         self._keep = (tvals, coef)
 

@@ -352,11 +352,12 @@ def _chain_setup(dev, vae):
     return m, Sampler, xT, text, noises
 
 
+@pytest.mark.parametrize("lanes", [1, 2])
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_chain_ddpm_golden(golden_dir, dev, vae, use_graph):
+def test_chain_ddpm_golden(golden_dir, dev, vae, use_graph, lanes):
     g = _load(golden_dir, "chains")
     m, Sampler, xT, text, noises = _chain_setup(dev, vae)
-    s = Sampler(m, vae.decoder, "ddpm", 20, 7.0, 4, 96, dev, use_graph=use_graph)
+    s = Sampler(m, vae.decoder, "ddpm", 20, 7.0, 4, 96, dev, use_graph=use_graph, lanes=lanes)
     lat, series, _ = s.run(text, x_T=xT, noise=noises)
     scale = max(1.0, float(np.abs(g["ddpm_latent"]).max()))
     assert _maxdiff(lat, g["ddpm_latent"]) < TOL * scale
@@ -366,11 +367,12 @@ def test_chain_ddpm_golden(golden_dir, dev, vae, use_graph):
     assert torch.equal(lat, lat2) and torch.equal(series, series2)
 
 
+@pytest.mark.parametrize("lanes", [1, 2])
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_chain_rf_golden(golden_dir, dev, vae, use_graph):
+def test_chain_rf_golden(golden_dir, dev, vae, use_graph, lanes):
     g = _load(golden_dir, "chains")
     m, Sampler, xT, text, _ = _chain_setup(dev, vae)
-    s = Sampler(m, vae.decoder, "flowmatching", 20, 7.0, 4, 96, dev, use_graph=use_graph)
+    s = Sampler(m, vae.decoder, "flowmatching", 20, 7.0, 4, 96, dev, use_graph=use_graph, lanes=lanes)
     lat, series, _ = s.run(text, x_T=xT)
     scale = max(1.0, float(np.abs(g["rf_latent"]).max()))
     assert _maxdiff(lat, g["rf_latent"]) < TOL * scale
@@ -610,3 +612,36 @@ def test_eval_mrr_vs_oracle(dev):
     assert score[3] == 0 and score[11] == 0 and abs(score[7].item() - 1 / 7) < 1e-7
     m2, _, _ = mrr(ori, stacked, 0.5, dev)   # the stacked (N, L, 1, G) form evaluation.py builds
     assert m2 == m
+
+
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_two_lane_sampler_is_bitwise_one_lane(dev, vae, math):
+    """t2s_sampler_set_lanes: the loop run as two half-batch chains on two streams (own graph, own step counter,
+    own workspace slice, Philox rows by global index) gives bit for bit the one-lane result -- odd batch (19 + 18
+    rows), perf-mode noise, graph and eager, and a re-run on the same sampler."""
+    from model.denoiser.transformer import Transformer
+    from t2ms_amd.sampler import Sampler
+    m = Transformer()
+    m.load_state_dict(synth.make_dit_state_dict(2025), strict=True)
+    m = m.to(dev).eval().set_math(math)
+    B = 37
+    text = synth.make_text_embeddings(5, B)
+    ref = None
+    for lanes, use_graph in ((1, True), (2, True), (2, False)):
+        s = Sampler(m, vae.decoder, "ddpm", 6, 9.0, B, 96, dev, use_graph=use_graph, seed=11, row0=100, lanes=lanes)
+        lat, series, _ = s.run(text)
+        if ref is None:
+            ref = (lat, series)
+            assert bool(torch.isfinite(series).all())
+        else:
+            assert torch.equal(lat, ref[0]) and torch.equal(series, ref[1]), (lanes, use_graph)
+        lat2, series2 = s.run_inplace()
+        assert torch.equal(lat2, ref[0]) and torch.equal(series2, ref[1])
+    # the automatic choice (two lanes from 128 series) against one lane, rectified flow
+    B = 128
+    text = synth.make_text_embeddings(6, B)
+    outs = []
+    for lanes in (1, 0):
+        s = Sampler(m, vae.decoder, "flowmatching", 4, 5.0, B, 96, dev, seed=3, lanes=lanes)
+        outs.append(s.run(text)[:2])
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
