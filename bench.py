@@ -214,6 +214,8 @@ def main():
     assert bool(torch.isfinite(series).all()) and bool(torch.isfinite(lat).all())
 
     total_series = args.steps * B * world
+    lanes_used = args.lanes or (int(os.environ["T2S_SAMPLER_LANES"]) if os.environ.get("T2S_SAMPLER_LANES") in ("1", "2")
+                                else (2 if B >= 128 else 1))
     value = total_series / elapsed
     out = {
         "metric": "generated series/sec (B=256, L=96, 1000-step DDPM)",
@@ -222,8 +224,10 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{'configs[1]' if (args.backbone, args.diffusion_steps, B) == ('ddpm', 1000, 256) else 'custom'}: DiT denoiser, {args.diffusion_steps}-step {args.backbone} with CFG "
                                f"(2 forwards/step), B={B}/GPU, L={args.length}, cfg_scale={args.cfg_scale}, "
-                               f"LA-VAE decode; Philox noise on device; hipGraph={'off' if args.no_graph else 'on'}",
-                   "global_batch": B * world, "diffusion_steps": args.diffusion_steps, "parallelism": f"batch-shard x{world}"},
+                               f"LA-VAE decode; Philox noise on device; hipGraph={'off' if args.no_graph else 'on'}; "
+                               f"sampler lanes={lanes_used} (half-batch chains on own streams, include/t2s.h t2s_sampler_set_lanes)",
+                   "global_batch": B * world, "diffusion_steps": args.diffusion_steps, "parallelism": f"batch-shard x{world}",
+                   "sampler_lanes": lanes_used},
     }
     if rank == 0:
         # roofline of the dominant kernel (fused attention; 48 % of all FLOPs), same shapes as the workload
@@ -245,7 +249,12 @@ def main():
                            "avg_launch_us": t_attn * 1e6,
                            "flop_per_launch": flop_attn, "launches_timed": kt["attn_calls"],
                            "timing": "HIP events on the launch stream around every attention launch of "
-                                     "8 eager 512-sequence CFG forwards (in situ)"}
+                                     "8 eager 512-sequence CFG forwards (in situ), the kernel alone on the chip -- the "
+                                     "launch shape of `--lanes 1`, whose rocprofv3 average agrees "
+                                     "(profiles/*_kernel_stats_lanes1.csv). With 2 lanes the timed region issues this kernel "
+                                     "as two 256-sequence launches that time-share the CUs with the other lane's kernels; "
+                                     "per-launch durations there are not a kernel property, the pipelined figure is "
+                                     "whole_path_frac_of_fp32_mfma_peak"}
         out["kernel_breakdown_us"] = {"attention_x4": kt["attn_us"], "row_chain_x5": kt["rows_us"],
                                       "other_x4": kt["other_us"], "forward_total": kt["forward_us"]}
         # whole-step figure for context: all DiT FLOPs / wall time

@@ -9,14 +9,21 @@ out=gpurun_out
 mkdir -p $out
 echo "== bench"; timeout -k 10 500 python bench.py --gpus 1 --steps 3 --warmup 1 > $out/${tag}_bench.json 2> $out/${tag}_bench.err || exit 1
 tail -c 600 $out/${tag}_bench.json; echo
-echo "== rocprofv3 --kernel-trace --stats (same command, 1+1 batches)"
+echo "== rocprofv3 --kernel-trace --stats (same command, 1+1 batches; two sampler lanes = the default)"
 rm -rf /tmp/prof_$tag
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline --no-alt-math > $out/${tag}_prof_bench.json 2> $out/${tag}_prof.err || exit 1
 cp /tmp/prof_$tag/*/*kernel_stats.csv $out/${tag}_kernel_stats.csv
+# one lane: every kernel alone on the chip at the 512-sequence launch shape -- the configuration the roofline block
+# of bench.py is quoted on (per-kernel durations of the two-lane run include time-sharing with the other lane)
+echo "== rocprofv3 --kernel-trace --stats, --lanes 1"
+rm -rf /tmp/prof1_$tag
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1_$tag -- python bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline --no-alt-math --lanes 1 > $out/${tag}_prof_bench_lanes1.json 2> $out/${tag}_prof1.err || exit 1
+cp /tmp/prof1_$tag/*/*kernel_stats.csv $out/${tag}_kernel_stats_lanes1.csv
+head -8 $out/${tag}_kernel_stats_lanes1.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   echo "== pmc $c"
   rm -rf /tmp/pmc_$c
-  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python bench.py --gpus 1 --steps 1 --warmup 1 --diffusion-steps 3 --no-cpu-baseline --no-alt-math > /dev/null 2> $out/${tag}_pmc_$c.err || exit 1
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python bench.py --gpus 1 --steps 1 --warmup 1 --diffusion-steps 3 --no-cpu-baseline --no-alt-math --lanes 1 > /dev/null 2> $out/${tag}_pmc_$c.err || exit 1
   python3 - "$c" /tmp/pmc_$c $out/${tag}_pmc_$c.csv <<'PY'
 import csv, glob, sys, collections
 c, d, dst = sys.argv[1:4]
