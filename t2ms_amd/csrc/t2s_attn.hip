@@ -183,11 +183,13 @@ __device__ __forceinline__ void attn_packed_body(f32x4* ring, const f32x4* qg, c
 #pragma unroll
         for (int g = 0; g < 4; ++g) vf[g] = slot[256 + g * 64];
 
-        f32x16 sta = ta.negm, stb = tb.negm;     // scores relative to the sticky reference
+        // scores relative to the sticky reference (C operand of the first MFMA, kept in its own registers)
+        f32x16 sta = mfma32_from(kf[0][0], qa[0][0], ta.negm);
+        f32x16 stb = (NT == 2) ? mfma32_from(kf[0][0], qb[0][0], tb.negm) : tb.negm;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = (g == 0 ? 1 : 0); e < 4; ++e) {
                 sta = mfma32(kf[g][e], qa[g][e], sta);
                 if (NT == 2) stb = mfma32(kf[g][e], qb[g][e], stb);
             }
@@ -376,11 +378,12 @@ __device__ __forceinline__ void attn_persistent_body(f32x4* ring, const f32x4* q
             f32x4 vf[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) vf[g] = slot[256 + g * 64];
-            f32x16 sta = ta.negm, stb = tb.negm;
+            f32x16 sta = mfma32_from(kf[0][0], qa[0][0], ta.negm);
+            f32x16 stb = (NT == 2) ? mfma32_from(kf[0][0], qb[0][0], tb.negm) : tb.negm;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = (g == 0 ? 1 : 0); e < 4; ++e) {
                     sta = mfma32(kf[g][e], qa[g][e], sta);
                     if (NT == 2) stb = mfma32(kf[g][e], qb[g][e], stb);
                 }

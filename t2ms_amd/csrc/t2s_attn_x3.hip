@@ -9,6 +9,7 @@
 // k, v^T pre-split bf16 planes written by the row-chain kernel (t2s_x3.h: X3_TILE_UNITS); the
 // exponentiated tile P^T is split in registers.  Per 32-key block and query tile: 12 + 12 MFMAs of
 // 32 cycles (768) instead of 16 + 16 of 64 (2048).
+#include <stdlib.h>
 #include "t2s_x3.h"
 
 namespace t2s {
@@ -60,6 +61,19 @@ __device__ __forceinline__ void glds16u(const bf16x8* gsrc_lane, bf16x8* lds_wav
 __device__ __forceinline__ f32x16 scores(const Split3 (&kf)[2], const Split3 (&q)[2], f32x16 c) {
     c = mfma_x3(kf[0], q[0], c);
     return mfma_x3(kf[1], q[1], c);
+}
+
+// the same with a C operand that must survive (the sticky reference): the first MFMA writes registers of its own
+// instead of hipcc's copy + tied accumulate (see mfma32_from, t2s_common.h); same order of additions as scores()
+__device__ __forceinline__ f32x16 scores_from(const Split3 (&kf)[2], const Split3 (&q)[2], const f32x16& c) {
+    f32x16 acc;
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(kf[0].m), "v"(q[0].m), "v"(c));
+    acc = mfma16(kf[0].l, q[0].h, acc);
+    acc = mfma16(kf[0].h, q[0].l, acc);
+    acc = mfma16(kf[0].m, q[0].h, acc);
+    acc = mfma16(kf[0].h, q[0].m, acc);
+    acc = mfma16(kf[0].h, q[0].h, acc);
+    return mfma_x3(kf[1], q[1], acc);
 }
 
 // rare path: raw scores (C = 0) -> new reference, rescale the running sum / output, P^T in st
@@ -185,16 +199,17 @@ __device__ __forceinline__ void attn_x3_body(bf16x8* ring, const f32x4* qall, co
 #pragma unroll 1
         for (int jb = 0; jb < NKB; ++jb, ++gb) {
             // ---- QK^T (MFMA)
-            f32x16 sta = scores(kf, qa, ta.negm);
+            f32x16 sta = scores_from(kf, qa, ta.negm);
             f32x16 stb = tb.negm;
-            if (NT == 2) stb = scores(kf, qb, tb.negm);
+            if (NT == 2) stb = scores_from(kf, qb, tb.negm);
             X3_STAMP(0)
             if (STAG) {
                 wait_but(1);
+                X3_STAMP(1)
                 __builtin_amdgcn_s_barrier();
                 issue_block(bh, jb + 3, gb + 3);
+                X3_STAMP(4)
             }
-            X3_STAMP(1)
             const bf16x8* slot = ring + (gb & (X3_SLOTS - 1)) * X3_SLOT_UNITS + lane;
             Split3 vf[2];
 #pragma unroll
@@ -220,10 +235,11 @@ __device__ __forceinline__ void attn_x3_body(bf16x8* ring, const f32x4* qall, co
             X3_STAMP(3)
             if (!STAG) {
                 wait_but(1);
+                X3_STAMP(1)
                 __builtin_amdgcn_s_barrier();
                 issue_block(bh, jb + 3, gb + 3);
+                X3_STAMP(4)
             }
-            X3_STAMP(4)
             // K fragments of the next block (landed: barrier above), read behind the PV MFMAs
             load_k(kf, gb + 1);
             // ---- PV (MFMA): O^T += V^T P^T
@@ -277,7 +293,7 @@ __device__ __forceinline__ void attn_x3_body(bf16x8* ring, const f32x4* qall, co
 }
 
 // k3 / vT3: split planes (BH*15 tiles x 6 KiB each); q, o: fp32 fragment-major as in t2s_attn_fwd_packed
-__global__ __launch_bounds__(X3_THREADS, 2) void attn_fwd_x3_kernel(const float* __restrict__ q,
+__global__ __launch_bounds__(X3_THREADS, 2) T2S_X3_KERNEL void attn_fwd_x3_kernel(const float* __restrict__ q,
                                                                     const __bf16* __restrict__ k3,
                                                                     const __bf16* __restrict__ vT3,
                                                                     float* __restrict__ o, int BH) {
@@ -340,7 +356,14 @@ int launch_attn_x3(const float* q, const __bf16* k3, const __bf16* vT3, float* o
         else
             n_cu = 256;
     }
-    const int grid = BH < n_cu ? BH : n_cu;
+    static int wg_per_cu = 0;
+    if (wg_per_cu == 0) {
+        const char* e = getenv("T2S_X3_WGS_PER_CU");
+        wg_per_cu = e ? atoi(e) : 1;
+        if (wg_per_cu < 1 || wg_per_cu > 2) wg_per_cu = 1;
+    }
+    const int slots = n_cu * wg_per_cu;
+    const int grid = BH < slots ? BH : slots;
     attn_fwd_x3_kernel<<<grid, X3_THREADS, X3_LDS_BYTES, st>>>(q, k3, vT3, o, BH);
     T2S_LAUNCH_CHECK();
     return T2S_OK;

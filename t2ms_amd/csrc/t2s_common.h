@@ -58,6 +58,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+
+// First MFMA of an accumulation chain whose C operand must SURVIVE (the sticky softmax reference, 16 registers per
+// query tile, reused by every key block): d = a.b + c with d in registers of its own.  hipcc always selects the tied
+// form (vdst == src2) for the builtin and copies c first -- 16 v_mov_b64 per key block and tile pair in the attention
+// loops; the instruction itself takes any src2.  The builtin MFMAs that follow accumulate in place on d
+// (vdst == src2 exactly overlapped: back to back, no software wait states).
+__device__ __forceinline__ f32x16 mfma32_from(float a, float b, const f32x16& c) {
+    f32x16 d;
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
 __device__ __forceinline__ float xhalf(float v) {  // value held by lane ^ 32

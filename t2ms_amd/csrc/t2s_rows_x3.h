@@ -95,7 +95,7 @@ __device__ __forceinline__ Split3 ldw3(const bf16x8* wb, int pc) {
 }
 
 template <bool DO_MLP, bool DO_QKV>
-__global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) {
+__global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const RowArgsX3 a) {
     extern __shared__ __attribute__((aligned(16))) bf16x8 wring3[];  // [2][X3_CHUNK_UNITS]
 #if defined(T2S_EXP) && (T2S_EXP & 64)
     unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) 
     const float* __restrict__ modrow = a.mod + (size_t)seq * MODROW;
 
     constexpr int N_CHUNKS = (DO_MLP ? 20 : 0) + (DO_QKV ? 12 : 0);
-    auto chunk_src = [&](int ci) -> const bf16x8* {
+    auto chunk_src = [&](int ci) T2S_X3_KERNEL -> const bf16x8* {
         if constexpr (DO_MLP) {
             if (ci < 4) return a.Wp + (size_t)ci * X3_CHUNK_UNITS;
             if (ci < 20) {
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) 
         return a.Wq + (size_t)ci * X3_CHUNK_UNITS;
     };
     // each wave DMAs pieces {wave, wave+4, ..., wave+20} of the chunk
-    auto fill = [&](int ci) {
+    auto fill = [&](int ci) T2S_X3_KERNEL {
 #if defined(T2S_EXP) && (T2S_EXP & 4096)
         if (ci > 1) return;     // timing experiment: no weight DMA after the first two chunks (results are garbage)
 #endif
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) 
                 const f32x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 aop[ks] = split3(v);
             }
-            __syncthreads();  // chunk 0 landed (vmcnt(0) + barrier)
+            wg_sync();  // chunk 0 landed (vmcnt(0) + barrier)
             ROWS_STAMP(1)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[nt][4 * g + e] += gate[e] * (acc[4 * g + e] + bias[e]);
                 }
-                __syncthreads();
+                wg_sync();
                 ++ci;
             }
         }
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) 
                         for (int e = 0; e < 4; ++e) hT[4 * g + e] = gelu_tanh_f(hT[4 * g + e] + bias[e]);
                     }
                 }
-                __syncthreads();
+                wg_sync();
                 ++ci;
                 if (ci + 1 < N_CHUNKS) fill(ci + 1);
                 {   // fc2 partial over the 32 hidden units of this chunk: pieces (nt, s)
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) 
                         acc[nt] = mfma_x3(ldw3(wb, nt * 2 + 1), h1, acc[nt]);
                     }
                 }
-                __syncthreads();
+                wg_sync();
                 ++ci;
             }
 #pragma unroll
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows_x3_kernel(const RowArgsX3 a) 
                 }
         }
     } else {
-        __syncthreads();  // chunk 0 landed
+        wg_sync();  // chunk 0 landed
     }
 
     // ---- fused final layer of the LAST block (transformer.py:182-191): affine LayerNorm (eps 1e-5),

@@ -11,7 +11,26 @@
 #pragma once
 #include "t2s_bf16.h"
 
+// Packed fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) do NOT overlap with bf16 MFMAs on gfx950:
+// a wave issuing them while its SIMD partner streams MFMAs takes the SUM of both times, every other VALU
+// instruction hides behind the matrix pipe (tools/ubench_valu.hip: 8 MFMA | 48 x v_pk_add_f32: 214 ns together vs
+// 112 / 108 alone; v_fma_f32: 135 vs 114 / 105).  The bf16x3 kernels live on that overlap, so they are compiled
+// without packed fp32 (T2S_X3_KERNEL on the __global__ function; the inlined helpers follow the kernel).
+#if defined(__HIP_DEVICE_COMPILE__) && !(defined(T2S_EXP) && (T2S_EXP & 2048))
+#define T2S_X3_KERNEL __attribute__((target("no-packed-fp32-ops")))
+#else
+#define T2S_X3_KERNEL
+#endif
+
 namespace t2s {
+
+// __syncthreads() spelled out: the HIP header's inline function is not inlined into a kernel whose target features
+// differ from the default (it became a call), the builtins are
+__device__ __forceinline__ void wg_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 struct Split3 {   // the three bf16 planes of one 8-element MFMA operand fragment
     bf16x8 h, m, l;

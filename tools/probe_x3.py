@@ -16,7 +16,7 @@ n = 8 * 8 * 256
 buf = (C.c_ulonglong * n)()
 assert lib.t2s_debug_read_x3(buf, n) == 0
 a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 8, 8).astype(np.float64)
-names = ["QK (24 mfma)", "STAG barrier section", "exp+sum+check", "split P", "non-STAG barrier section", "Kload+PV (24 mfma)+prefetch", "head end (O store, Q split)"]
+names = ["QK (24 mfma)", "DMA wait (vmcnt) before the barrier", "V loads + exp+sum+check", "split P", "s_barrier + DMA issue", "Kload+PV (24 mfma)+prefetch", "head end (O store, Q split)"]
 for grp, ws in (("waves 0-3 (STAG=0)", slice(0, 4)), ("waves 4-6 (STAG=1)", slice(4, 7)), ("wave 7 (NT=1)", slice(7, 8))):
     g = a[:, ws, :].reshape(-1, 8)
     tot = g[:, 7].mean()
