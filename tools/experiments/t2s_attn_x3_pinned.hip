@@ -1,3 +1,6 @@
+// EXPERIMENT RECORD (not built): t2s_attn_x3.hip with the pinned in-wave schedule -- MFMAs as asm volatile statements,
+// tile A's exponentials / split between the MFMAs of tile B and vice versa (template flag PIPE).  Parity-green,
+// interleaved exactly as written (ISA checked), and SLOWER: 377 us vs 342 us per launch.  See DESIGN.md 4.4.
 // Fused attention of the DiT forward in "bf16x3" arithmetic (t2s_x3.h): fp32-accurate QK^T and PV
 // on v_mfma_f32_32x32x16_bf16.  Same algorithm and skeleton as attn_fwd_persistent_kernel
 // (t2s_attn.hip; timm 1.0.11 Attention core, reference call site model/denoiser/transformer.py:116):
@@ -117,6 +120,81 @@ __device__ __forceinline__ void load_q(const f32x4 (&raw)[4], Split3 (&q)[2]) {
     }
 }
 
+// ---- pinned schedule (PIPE): MFMAs as asm volatile statements, so that hipcc (which clusters the builtin MFMAs of a
+// block and runs a wave's VALU work strictly between the clusters) keeps tile A's exponentials and split between
+// the MFMAs of tile B and vice versa.  Measured background: the kernel's time is the SUM of its matrix time and its
+// VALU time (timing ablations) although a wave issuing bf16 MFMAs and VALU work in the gaps runs at
+// the MFMA pace (tools/ubench_valu.hip).  hipcc does not see these MFMAs: the wait states it would insert between an
+// MFMA and a VALU read of its result are spelled out (x3_result_guard), dependent MFMAs accumulate in place
+// (vdst == src2: back to back, as hipcc itself emits them).
+__device__ __forceinline__ void mfma16_pin(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void x3_result_guard() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
+
+// term T (0..5) of acc += a . b in mfma_x3's order (smallest first)
+template <int T>
+__device__ __forceinline__ void x3_term(f32x16& acc, const Split3& a, const Split3& b) {
+    if constexpr (T == 0) mfma16_pin(acc, a.m, b.m);
+    if constexpr (T == 1) mfma16_pin(acc, a.l, b.h);
+    if constexpr (T == 2) mfma16_pin(acc, a.h, b.l);
+    if constexpr (T == 3) mfma16_pin(acc, a.m, b.h);
+    if constexpr (T == 4) mfma16_pin(acc, a.h, b.m);
+    if constexpr (T == 5) mfma16_pin(acc, a.h, b.h);
+}
+// MFMA I (0..11) of a two-k-step product; I == 0 may take a surviving C operand (scores_from)
+template <int I>
+__device__ __forceinline__ void x3_mfma(f32x16& acc, const Split3 (&a)[2], const Split3 (&b)[2]) {
+    x3_term<I % 6>(acc, a[I / 6], b[I / 6]);
+}
+__device__ __forceinline__ void x3_mfma0_from(f32x16& acc, const Split3 (&a)[2], const Split3 (&b)[2], const f32x16& c) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a[0].m), "v"(b[0].m), "v"(c));
+}
+
+// the split of eight accumulator values in three steps (20 + 20 + 4 VALU instructions)
+struct SplitJob {
+    f32x8 r;
+    Split3 p;
+};
+template <int STEP>
+__device__ __forceinline__ void split_step(SplitJob& j) {
+    // the empty asm statements are uses at this program point: without them LLVM sinks a slice to where its result is
+    // first needed (past the pinned MFMAs it is meant to sit between)
+    if constexpr (STEP == 0) { j.p.h = __builtin_convertvector(j.r, bf16x8); j.r = j.r - widen8(j.p.h); asm volatile("" : "+v"(j.r), "+v"(j.p.h)); }
+    if constexpr (STEP == 1) { j.p.m = __builtin_convertvector(j.r, bf16x8); j.r = j.r - widen8(j.p.m); asm volatile("" : "+v"(j.r), "+v"(j.p.m)); }
+    if constexpr (STEP == 2) { j.p.l = __builtin_convertvector(j.r, bf16x8); asm volatile("" : "+v"(j.p.l)); }
+}
+__device__ __forceinline__ f32x8 acc_half(const f32x16& c, int s) {
+    return f32x8{c[8 * s + 0], c[8 * s + 1], c[8 * s + 2], c[8 * s + 3], c[8 * s + 4], c[8 * s + 5], c[8 * s + 6], c[8 * s + 7]};
+}
+// VALU slice I (0..11) of one tile's softmax + split, to sit behind MFMA I of the other tile's product
+template <int I, class Stale>
+__device__ __forceinline__ void x3_valu_slice(f32x16& st, float& l_lane, SplitJob& j0, SplitJob& j1, Stale&& on_stale) {
+    if constexpr (I == 0) {
+        x3_result_guard();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) st[r] = __builtin_amdgcn_exp2f(st[r]);
+        asm volatile("" : "+v"(st));
+    }
+    if constexpr (I == 1) {
+#pragma unroll
+        for (int r = 8; r < 16; ++r) st[r] = __builtin_amdgcn_exp2f(st[r]);
+        asm volatile("" : "+v"(st));
+    }
+    if constexpr (I == 2) {
+        float ps = ((st[0] + st[1]) + (st[2] + st[3])) + ((st[4] + st[5]) + (st[6] + st[7])) +
+                   (((st[8] + st[9]) + (st[10] + st[11])) + ((st[12] + st[13]) + (st[14] + st[15])));
+        if (__builtin_amdgcn_ballot_w64(!(ps < SM_BIG)) != 0) ps = on_stale();   // wave-uniform, rare
+        l_lane += ps;
+    }
+    if constexpr (I == 3) { j0.r = acc_half(st, 0); split_step<0>(j0); }
+    if constexpr (I == 4) split_step<1>(j0);
+    if constexpr (I == 5) { split_step<2>(j0); j1.r = acc_half(st, 1); }
+    if constexpr (I == 6) split_step<0>(j1);
+    if constexpr (I == 7) split_step<1>(j1);
+    if constexpr (I == 8) split_step<2>(j1);
+}
+
 // NT = query tiles of this wave (2; 1 for the wave that holds tile 14 alone).
 // STAG: the two waves of a SIMD (waves w and w+4) run the same loop with the per-block barrier at
 // DIFFERENT points -- after the softmax (STAG = 0) or right after QK^T (STAG = 1) -- so that they
@@ -129,7 +207,7 @@ __device__ __forceinline__ void load_q(const f32x4 (&raw)[4], Split3 (&q)[2]) {
 //   * block j+1 has landed (every DMA-issuing wave waited until only its youngest block is in flight),
 //   * every wave is done with block j-1 (both variants finish PV(j-1) before QK(j)),
 // so after it a wave may read K(j+1) and refill slot (j+3) & 3 == (j-1) & 3 with block j+3.
-template <int NT, int STAG>
+template <int NT, int STAG, int PIPE = 0>
 __device__ __forceinline__ void attn_x3_body(bf16x8* ring, const f32x4* qall, const bf16x8* kall, const bf16x8* vall,
                                              f32x4* og, int BH, int lane, int wave) {
     const int stride = gridDim.x;
@@ -205,6 +283,59 @@ __device__ __forceinline__ void attn_x3_body(bf16x8* ring, const f32x4* qall, co
 
 #pragma unroll 1
         for (int jb = 0; jb < NKB; ++jb, ++gb) {
+            if constexpr (PIPE && NT == 2) {
+                // stage 1: QK_A                      stage 2: QK_B  with softmax + split of A in the gaps
+                // barrier, DMA                        stage 3: PV_A  with softmax + split of B in the gaps
+                // K(j+1) fragment reads               stage 4: PV_B
+                f32x16 sta, stb;
+                SplitJob a0, a1, b0, b1;
+                x3_mfma0_from(sta, kf, qa, ta.negm);
+#define X3_S1(I) x3_mfma<I>(sta, kf, qa);
+                X3_S1(1) X3_S1(2) X3_S1(3) X3_S1(4) X3_S1(5) X3_S1(6) X3_S1(7) X3_S1(8) X3_S1(9) X3_S1(10) X3_S1(11)
+#undef X3_S1
+                const bf16x8* slot = ring + (gb & (X3_SLOTS - 1)) * X3_SLOT_UNITS + lane;
+                Split3 vf[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    vf[s].h = slot[(6 + 0 + s) * 64];
+                    vf[s].m = slot[(6 + 2 + s) * 64];
+                    vf[s].l = slot[(6 + 4 + s) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                auto stale_a = [&]() { return rereference(kf, qa, sta, oa, ta); };
+                x3_mfma0_from(stb, kf, qb, tb.negm);
+                x3_valu_slice<0>(sta, ta.l_lane, a0, a1, stale_a);
+                __builtin_amdgcn_sched_barrier(0);
+#define X3_S2(I) x3_mfma<I>(stb, kf, qb); x3_valu_slice<I>(sta, ta.l_lane, a0, a1, stale_a); __builtin_amdgcn_sched_barrier(0);
+                X3_S2(1) X3_S2(2) X3_S2(3) X3_S2(4) X3_S2(5) X3_S2(6) X3_S2(7) X3_S2(8) X3_S2(9) X3_S2(10) X3_S2(11)
+#undef X3_S2
+                wait_but(1);
+                __builtin_amdgcn_s_barrier();
+                issue_block(bh, jb + 3, gb + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                // the stale path of B recomputes raw scores from K(j): kf is only reloaded after stage 3
+                auto stale_b = [&]() { return rereference(kf, qb, stb, ob, tb); };
+                const Split3 pa[2] = {a0.p, a1.p};
+#define X3_S3(I) x3_mfma<I>(oa, vf, pa); x3_valu_slice<I>(stb, tb.l_lane, b0, b1, stale_b); __builtin_amdgcn_sched_barrier(0);
+                X3_S3(0) X3_S3(1) X3_S3(2) X3_S3(3) X3_S3(4) X3_S3(5) X3_S3(6) X3_S3(7) X3_S3(8) X3_S3(9) X3_S3(10) X3_S3(11)
+#undef X3_S3
+                load_k(kf, gb + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const Split3 pb[2] = {b0.p, b1.p};
+#define X3_S4(I) x3_mfma<I>(ob, vf, pb);
+                X3_S4(0) X3_S4(1) X3_S4(2) X3_S4(3) X3_S4(4) X3_S4(5) X3_S4(6) X3_S4(7) X3_S4(8) X3_S4(9) X3_S4(10) X3_S4(11)
+#undef X3_S4
+                if (jb == NKB - 4 && bh + stride < BH) {
+                    const f32x4* qg = qall + (size_t)(bh + stride) * NKB * 256;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        qna[g] = qg[(t0 * 4 + g) * 64 + lane];
+                        qnb[g] = qg[((t0 + 1) * 4 + g) * 64 + lane];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
             // ---- QK^T (MFMA)
             f32x16 sta = ta.negm;
             f32x16 stb = tb.negm;
@@ -306,6 +437,7 @@ __device__ __forceinline__ void attn_x3_body(bf16x8* ring, const f32x4* qall, co
             X3_STAMP(5)
         }
         // ---- normalise and store O of this head; swap in the prefetched Q ----
+        if constexpr (PIPE && NT == 2) x3_result_guard();   // the last pinned PV MFMAs
         const int seq = bh / NH, head = bh % NH;
         {
             const float inv = 1.0f / pair_sum(ta.l_lane);
@@ -351,10 +483,13 @@ __global__ __launch_bounds__(X3_THREADS, 2) T2S_X3_KERNEL void attn_fwd_x3_kerne
     f32x4* og = reinterpret_cast<f32x4*>(o);
     // (measured: without the stagger 324 us, with 313 us; s_setprio 1 for waves 4-7 on top: 320 us)
     constexpr int SG = 1;
+#ifndef T2S_X3_PIPE
+#define T2S_X3_PIPE 1
+#endif
     if (wave < 4)
-        attn_x3_body<2, 0>(ring3, qg, kg, vg, og, BH, lane, wave);
+        attn_x3_body<2, 0, T2S_X3_PIPE>(ring3, qg, kg, vg, og, BH, lane, wave);
     else if (wave < 7)
-        attn_x3_body<2, SG>(ring3, qg, kg, vg, og, BH, lane, wave);
+        attn_x3_body<2, SG, T2S_X3_PIPE>(ring3, qg, kg, vg, og, BH, lane, wave);
     else
         attn_x3_body<1, SG>(ring3, qg, kg, vg, og, BH, lane, wave);   // tile 14 only (15 is void)
 }
