@@ -32,9 +32,8 @@ void train_free(t2s_dit* h);
 // W (N,K) row-major -> MFMA-fragment order.  mode 0: packed_index (tile-major: [nt][G][lane][e]);
 // mode 1 (fc2, K=256): chunk order [c = G/4][nt][g = G%4][lane][e] so the 16 fragments one fc1
 // chunk feeds into fc2 are one contiguous 16 KiB (t2s_rows.h).
-__global__ void pack_weight_kernel(const float* __restrict__ W, float* __restrict__ P, int N, int K,
-                                   int n_offset, int mode) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_weight_elem(const float* __restrict__ W, float* __restrict__ P, int N, int K,
+                                                 int n_offset, int mode, int idx) {
     if (idx >= N * K) return;
     const int n = idx / K + n_offset, k = idx - (idx / K) * K;
     if (mode == 0) {
@@ -44,6 +43,39 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, float* __restric
         const int c = G >> 2, g = G & 3;
         P[((((size_t)(c * (N >> 5) + nt) * 4 + g) * 64) + (h * 32 + j)) * 4 + e] = W[idx];
     }
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ W, float* __restrict__ P, int N, int K,
+                                   int n_offset, int mode) {
+    pack_weight_elem(W, P, N, K, n_offset, mode, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Every parameter refresh of a handle in TWO launches instead of 50 (30 device-to-device copies + 20 packs, 3-5 us
+// each: 0.25 ms of a 14.5 ms bf16 training step): the job tables travel as kernel arguments, blockIdx.y = job.
+constexpr int MULTI_JOBS = 32;
+struct PackJob {
+    const float* W;
+    float* P;
+    int N, K, n_offset, mode;
+};
+struct PackTable {
+    PackJob j[MULTI_JOBS];
+};
+__global__ void pack_weight_multi_kernel(const PackTable t) {
+    const PackJob& j = t.j[blockIdx.y];
+    pack_weight_elem(j.W, j.P, j.N, j.K, j.n_offset, j.mode, blockIdx.x * blockDim.x + threadIdx.x);
+}
+struct CopyJob {
+    const float* src;
+    float* dst;
+    int n;
+};
+struct CopyTable {
+    CopyJob j[MULTI_JOBS];
+};
+__global__ void copy_multi_kernel(const CopyTable t) {
+    const CopyJob& j = t.j[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < j.n; i += gridDim.x * blockDim.x) j.dst[i] = j.src[i];
 }
 
 // TimeEmbedding.forward (transformer.py:30-40): out[b] = [sin(100 t / f) | cos(100 t / f)]
@@ -141,19 +173,6 @@ struct ArenaPlan {
     }
 };
 
-int copy_param(float* dst, const float* src, size_t n, hipStream_t st) {
-    T2S_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-    return T2S_OK;
-}
-
-int pack(const float* W, f32x4* P, int N, int K, int n_offset, int mode, hipStream_t st) {
-    const int total = N * K;
-    pack_weight_kernel<<<(total + 255) / 256, 256, 0, st>>>(W, reinterpret_cast<float*>(P), N, K,
-                                                            n_offset, mode);
-    T2S_LAUNCH_CHECK();
-    return T2S_OK;
-}
-
 // split planes of the row-chain weights from the handle's packed fp32 copies (T2S_MATH_BF16X3)
 int pack_x3_weights(t2s_dit* h, hipStream_t st) {
     int rc;
@@ -171,36 +190,45 @@ int upload_weights(t2s_dit* h, const t2s_dit_weights* w, hipStream_t st) {
     T2S_REQUIRE(w->conv_w && w->conv_b && w->patch_w && w->patch_b && w->pos_embed && w->ln_w &&
                     w->ln_b && w->out_w && w->out_b && w->time_freqs,
                 "t2s_dit weights: NULL top-level pointer");
-    int rc;
-#define CP(dst, src, n) \
-    if ((rc = copy_param(dst, src, n, st)) != T2S_OK) return rc
-    CP(h->conv_w, w->conv_w, 16);
-    CP(h->conv_b, w->conv_b, 4);
-    CP(h->patch_w, w->patch_w, 128 * 4);
-    CP(h->patch_b, w->patch_b, 128);
-    CP(h->pos, w->pos_embed, NTOK * D);
-    CP(h->ln_w, w->ln_w, D);
-    CP(h->ln_b, w->ln_b, D);
-    CP(h->out_w, w->out_w, 4 * D);
-    CP(h->out_b, w->out_b, 4);
-    CP(h->freqs, w->time_freqs, 64);
+    CopyTable ct{};
+    PackTable pt{};
+    int nc = 0, np = 0, max_pack = 0;
+    auto cp = [&](float* dst, const float* src, int n) { ct.j[nc++] = CopyJob{src, dst, n}; };
+    auto pk = [&](const float* W, f32x4* P, int N, int K, int n_offset, int mode) {
+        pt.j[np++] = PackJob{W, reinterpret_cast<float*>(P), N, K, n_offset, mode};
+        max_pack = N * K > max_pack ? N * K : max_pack;
+    };
+    cp(h->conv_w, w->conv_w, 16);
+    cp(h->conv_b, w->conv_b, 4);
+    cp(h->patch_w, w->patch_w, 128 * 4);
+    cp(h->patch_b, w->patch_b, 128);
+    cp(h->pos, w->pos_embed, NTOK * D);
+    cp(h->ln_w, w->ln_w, D);
+    cp(h->ln_b, w->ln_b, D);
+    cp(h->out_w, w->out_w, 4 * D);
+    cp(h->out_b, w->out_b, 4);
+    cp(h->freqs, w->time_freqs, 64);
     for (int i = 0; i < NBLK; ++i) {
         const t2s_dit_block_weights& b = w->blk[i];
         T2S_REQUIRE(b.qkv_w && b.qkv_b && b.proj_w && b.proj_b && b.fc1_w && b.fc1_b && b.fc2_w &&
                         b.fc2_b && b.ada_w && b.ada_b,
                     "t2s_dit weights: NULL pointer in block %d", i);
-        CP(h->qkv_b[i], b.qkv_b, 3 * D);
-        CP(h->proj_b[i], b.proj_b, D);
-        CP(h->fc1_b[i], b.fc1_b, 2 * D);
-        CP(h->fc2_b[i], b.fc2_b, D);
-        CP(h->ada_b + i * MODW, b.ada_b, MODW);
-        if ((rc = pack(b.qkv_w, h->qkv_p[i], 3 * D, D, 0, 0, st)) != T2S_OK) return rc;
-        if ((rc = pack(b.proj_w, h->proj_p[i], D, D, 0, 0, st)) != T2S_OK) return rc;
-        if ((rc = pack(b.fc1_w, h->fc1_p[i], 2 * D, D, 0, 0, st)) != T2S_OK) return rc;
-        if ((rc = pack(b.fc2_w, h->fc2_c[i], D, 2 * D, 0, 1, st)) != T2S_OK) return rc;
-        if ((rc = pack(b.ada_w, h->ada_p, MODW, D, i * MODW, 0, st)) != T2S_OK) return rc;
+        cp(h->qkv_b[i], b.qkv_b, 3 * D);
+        cp(h->proj_b[i], b.proj_b, D);
+        cp(h->fc1_b[i], b.fc1_b, 2 * D);
+        cp(h->fc2_b[i], b.fc2_b, D);
+        cp(h->ada_b + i * MODW, b.ada_b, MODW);
+        pk(b.qkv_w, h->qkv_p[i], 3 * D, D, 0, 0);
+        pk(b.proj_w, h->proj_p[i], D, D, 0, 0);
+        pk(b.fc1_w, h->fc1_p[i], 2 * D, D, 0, 0);
+        pk(b.fc2_w, h->fc2_c[i], D, 2 * D, 0, 1);
+        pk(b.ada_w, h->ada_p, MODW, D, i * MODW, 0);
     }
-#undef CP
+    static_assert(10 + 5 * NBLK <= MULTI_JOBS && 5 * NBLK <= MULTI_JOBS, "job tables too small");
+    copy_multi_kernel<<<dim3(16, nc), 256, 0, st>>>(ct);
+    T2S_LAUNCH_CHECK();
+    pack_weight_multi_kernel<<<dim3((max_pack + 255) / 256, np), 256, 0, st>>>(pt);
+    T2S_LAUNCH_CHECK();
     if (h->w3 != nullptr) return pack_x3_weights(h, st);
     return T2S_OK;
 }

@@ -720,10 +720,23 @@ int ensure_ws(t2s_dit* h, int S) {
     return T2S_OK;
 }
 
-int pack16(const float* W, bf16x8* P, int N, int K, int transpose, hipStream_t st) {
-    pack16_kernel<<<(N * K + 255) / 256, 256, 0, st>>>(W, reinterpret_cast<__bf16*>(P), N, K, transpose);
-    T2S_LAUNCH_CHECK();
-    return T2S_OK;
+// the 32 bf16 weight packs of a training forward (4 blocks x 4 matrices x 2 orientations) in one launch: job table
+// as a kernel argument, blockIdx.y = job (each single launch costs ~3 us against ~1 us of work)
+struct Pack16Job {
+    const float* W;
+    __bf16* P;
+    int N, K, transpose;
+};
+struct Pack16Table {
+    Pack16Job j[8 * NBLK];
+};
+__global__ void pack16_multi_kernel(const Pack16Table t) {
+    const Pack16Job& j = t.j[blockIdx.y];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= j.N * j.K) return;
+    const int n = idx / j.K, k = idx - n * j.K;
+    const size_t dst = j.transpose ? packed16_index(k, n, j.N) : packed16_index(n, k, j.K);
+    j.P[dst] = (__bf16)j.W[idx];
 }
 
 template <int K, int N, int PRO, int EPI>
@@ -817,13 +830,24 @@ int t2s_dit_train_forward(t2s_dit* h, const t2s_dit_weights* w, const float* x, 
                 (rc = pack_any(b.fc1_w, ws->fc1_t[i], 2 * D, D, 1, st)) || (rc = pack_any(b.fc2_w, ws->fc2_f[i], D, 2 * D, 0, st)) ||
                 (rc = pack_any(b.fc2_w, ws->fc2_t[i], D, 2 * D, 1, st)))
                 return rc;
-        } else {     // bf16 copies of the fp32 master weights, both orientations
-            if ((rc = pack16(b.qkv_w, ws->qkv_f16[i], 3 * D, D, 0, st)) || (rc = pack16(b.qkv_w, ws->qkv_t16[i], 3 * D, D, 1, st)) ||
-                (rc = pack16(b.proj_w, ws->proj_f16[i], D, D, 0, st)) || (rc = pack16(b.proj_w, ws->proj_t16[i], D, D, 1, st)) ||
-                (rc = pack16(b.fc1_w, ws->fc1_f16[i], 2 * D, D, 0, st)) || (rc = pack16(b.fc1_w, ws->fc1_t16[i], 2 * D, D, 1, st)) ||
-                (rc = pack16(b.fc2_w, ws->fc2_f16[i], D, 2 * D, 0, st)) || (rc = pack16(b.fc2_w, ws->fc2_t16[i], D, 2 * D, 1, st)))
-                return rc;
         }
+    }
+    if (bf) {        // bf16 copies of the fp32 master weights, both orientations
+        Pack16Table pt{};
+        int np = 0;
+        auto pk = [&](const float* W, bf16x8* plain, bf16x8* transposed, int N, int K) {
+            pt.j[np++] = Pack16Job{W, reinterpret_cast<__bf16*>(plain), N, K, 0};
+            pt.j[np++] = Pack16Job{W, reinterpret_cast<__bf16*>(transposed), N, K, 1};
+        };
+        for (int i = 0; i < NBLK; ++i) {
+            const t2s_dit_block_weights& b = w->blk[i];
+            pk(b.qkv_w, ws->qkv_f16[i], ws->qkv_t16[i], 3 * D, D);
+            pk(b.proj_w, ws->proj_f16[i], ws->proj_t16[i], D, D);
+            pk(b.fc1_w, ws->fc1_f16[i], ws->fc1_t16[i], 2 * D, D);
+            pk(b.fc2_w, ws->fc2_f16[i], ws->fc2_t16[i], D, 2 * D);
+        }
+        pack16_multi_kernel<<<dim3((3 * D * D + 255) / 256, np), 256, 0, st>>>(pt);
+        T2S_LAUNCH_CHECK();
     }
     T2S_HIP_CHECK(hipMemcpyAsync(ws->lat, x, (size_t)S * LAT * sizeof(float), hipMemcpyDeviceToDevice, st));
     cond_rows_kernel<<<(S * D + 255) / 256, 256, 0, st>>>(ws->c, temb, temb_rows, text, S);
@@ -896,9 +920,16 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
         zs.insert(zs.end(), {{b.qkv_w, 3 * D * D}, {b.qkv_b, 3 * D}, {b.proj_w, D * D}, {b.proj_b, D}, {b.fc1_w, 2 * D * D},
                              {b.fc1_b, 2 * D}, {b.fc2_w, 2 * D * D}, {b.fc2_b, D}, {b.ada_w, MODW * D}, {b.ada_b, MODW}});
     }
-    for (const Z& z : zs) {
-        T2S_REQUIRE(z.p, "t2s_dit_train_backward: NULL gradient pointer");
-        T2S_HIP_CHECK(hipMemsetAsync(z.p, 0, z.n * sizeof(float), st));
+    // adjacent ranges are merged: the host mirror carves all of them out of one flat bucket (what the data-parallel
+    // all-reduce sends), so this is normally ONE memset instead of 48
+    for (size_t i = 0; i < zs.size();) {
+        T2S_REQUIRE(zs[i].p, "t2s_dit_train_backward: NULL gradient pointer");
+        float* p = zs[i].p;
+        size_t n = zs[i].n;
+        size_t k = i + 1;
+        while (k < zs.size() && zs[k].p == p + n) n += zs[k++].n;
+        T2S_HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(float), st));
+        i = k;
     }
     // ---- final layer
     final_bwd_kernel<<<(M + TAIL_ROWS - 1) / TAIL_ROWS, 256, 0, st>>>(ws->x_in[NBLK], dout, h->ln_w, h->ln_b, h->out_w, ws->dx, g->ln_w,
