@@ -53,7 +53,7 @@ def timed(fn, n):
 t_full = timed(run_full, iters)
 print(f"{math}: one stream, B={B}: {t_full:.3f} ms per CFG pass")
 
-for sizes in ((128, 128), (144, 112), (160, 96), (86, 85, 85), (64, 64, 64, 64)):
+for sizes in ((128, 128), (160, 96), (192, 64), (96, 96, 64), (128, 64, 64), (64, 64, 64, 64), (96, 64, 64, 32)):
     parts = len(sizes)
     starts = [sum(sizes[:p]) for p in range(parts)]
     models = [make() for _ in range(parts)]

@@ -1,5 +1,5 @@
 """Write profiles/<tag>_summary.md from the files tools/collect_profiles.sh <tag> produced (copied into profiles/).
-    python tools/summarize_profiles.py r01_v6"""
+    python tools/summarize_profiles.py r01_v7"""
 import csv
 import json
 import os
