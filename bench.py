@@ -245,7 +245,7 @@ def main():
         out["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_persistent_kernel", "achieved": achieved,
                            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                            "traffic": traffic, "hbm_gbps": (traffic / t_attn / 1e9) if traffic else None,
-                           "mfma_busy_frac_pmc": 0.775, "pmc_source": "profiles/r01_v4_pmc_mfma_utilisation.md",
+                           "mfma_busy_frac_pmc": 0.79, "pmc_source": "profiles/r01_v7_pmc_mfma_utilisation.md",
                            "avg_launch_us": t_attn * 1e6,
                            "flop_per_launch": flop_attn, "launches_timed": kt["attn_calls"],
                            "timing": "HIP events on the launch stream around every attention launch of "
