@@ -645,6 +645,11 @@ def test_two_lane_sampler_is_bitwise_one_lane(dev, vae, math):
         s = Sampler(m, vae.decoder, "flowmatching", 4, 5.0, B, 96, dev, seed=3, lanes=lanes)
         outs.append(s.run(text)[:2])
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # the smallest batches two lanes can take (1 + 1 and 2 + 1 rows)
+    for B in (2, 3):
+        text = synth.make_text_embeddings(7, B)
+        outs = [Sampler(m, vae.decoder, "ddpm", 3, 9.0, B, 96, dev, seed=5, lanes=lanes).run(text)[:2] for lanes in (1, 2)]
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), B
     # bad lane counts are refused with the library's error code, not clamped
     assert L.lib().t2s_sampler_set_lanes(s.ptr, 3) != 0 and L.lib().t2s_sampler_set_lanes(s.ptr, -1) != 0
     assert L.lib().t2s_sampler_set_lanes(s.ptr, 2) == 0

@@ -1,5 +1,7 @@
 #!/bin/bash
-# A/B of two library builds on the same box: tools/bin/libt2s_prev.so vs the in-tree one, alternating runs
+# A/B of two library builds on the same box (boxes differ by 2-3 %): tools/bin/libt2s_prev.so vs the in-tree one,
+# alternating runs.  Build the baseline from another commit first:
+#   git worktree add /tmp/prev <commit> && make -C /tmp/prev/t2ms_amd/csrc && cp /tmp/prev/t2ms_amd/libt2s_hip.so tools/bin/libt2s_prev.so
 cp t2ms_amd/libt2s_hip.so /tmp/new.so
 for rep in 1 2 3; do
   for which in prev new; do
