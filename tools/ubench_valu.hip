@@ -148,6 +148,78 @@ void het_row(float* d) {
            op_name[OP], m, v, b, m > v ? m : v, m + v);
 }
 
+// Two MIXED waves per SIMD, each alternating a matrix phase (MG MFMAs, two accumulator chains) and a VALU phase (VG
+// instructions, 3/4 v_fma + 1/4 v_exp like the bf16x3 attention loop): does the pair run in max(...) or in the sum?
+// OFFSET 1: waves 4-7 start with their VALU phase (anti-phase start); GRAIN: the phases are cut into GRAIN slices that
+// alternate (GRAIN = 1: one matrix block then one VALU block; 12: [4 MFMA, 20 VALU] x 12).
+template <int MG, int VG, int OFFSET, int GRAIN>
+__global__ __launch_bounds__(512) void phases(float* out, int iters, float a0) {
+    extern __shared__ float pad[];
+    const int wave = threadIdx.x >> 6;
+    f32x16 acc[2];
+    for (int c = 0; c < 2; ++c)
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    float v[8], w[8];
+    f32x2 p[8];
+    for (int i = 0; i < 8; ++i) { v[i] = a0 + i + threadIdx.x * 1e-6f; w[i] = 0.25f * i; p[i] = f32x2{v[i], w[i]}; }
+    bf16x8 ab;
+    for (int i = 0; i < 8; ++i) ab[i] = (__bf16)(a0 + i);
+    auto mphase = [&]() {
+#pragma unroll
+        for (int m = 0; m < MG / GRAIN; ++m) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %1, %0" : "+v"(acc[m & 1]) : "v"(ab));
+    };
+    auto vphase = [&]() {
+#pragma unroll
+        for (int j = 0; j < VG / GRAIN; ++j) {
+            if ((j & 3) == 3) one<OP_EXP>(v[j & 7], w[j & 7], p[j & 7], a0);
+            else one<OP_FMA>(v[j & 7], w[j & 7], p[j & 7], a0);
+        }
+    };
+    if (OFFSET && wave >= 4) {
+#pragma unroll
+        for (int g = 0; g < GRAIN; ++g) vphase();
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int g = 0; g < GRAIN; ++g) {
+            mphase();
+            vphase();
+        }
+    }
+    float s = 0.f;
+    for (int c = 0; c < 2; ++c)
+        for (int r = 0; r < 16; ++r) s += acc[c][r];
+    for (int i = 0; i < 8; ++i) s += v[i] + w[i] + p[i].x + p[i].y;
+    if (s == 12345.678f) out[0] = s + pad[0];
+}
+
+template <int MG, int VG, int OFFSET, int GRAIN>
+double run_phases(float* d, int waves) {
+    const int lds = 150 * 1024;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(phases<MG, VG, OFFSET, GRAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int iters = 400;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    phases<MG, VG, OFFSET, GRAIN><<<256, 64 * waves, lds>>>(d, iters, 1.0f);
+    hipEventRecord(e0);
+    phases<MG, VG, OFFSET, GRAIN><<<256, 64 * waves, lds>>>(d, iters, 1.0f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return (double)ms * 1e6 / iters;
+}
+
+template <int MG, int VG>
+void phase_rows(float* d) {
+    const double m1 = run_phases<MG, 0, 0, 1>(d, 4), v1 = run_phases<0, VG, 0, 1>(d, 4), b1 = run_phases<MG, VG, 0, 1>(d, 4);
+    printf("mixed waves, %d MFMA + %d VALU per iteration: ONE wave/SIMD: matrix only %.0f ns, VALU only %.0f ns, both %.0f ns\n", MG, VG, m1, v1, b1);
+    printf("   TWO waves/SIMD (ideal = 2 x matrix only = %.0f ns; serial = 2 x both = %.0f ns): same phase %.0f | anti-phase start %.0f | "
+           "12 slices in phase %.0f | 12 slices anti-phase %.0f\n", 2 * m1, 2 * b1,
+           run_phases<MG, VG, 0, 1>(d, 8), run_phases<MG, VG, 1, 1>(d, 8), run_phases<MG, VG, 0, 12>(d, 8), run_phases<MG, VG, 1, 12>(d, 8));
+}
+
 int main() {
     float* d; unsigned long long* c;
     hipMalloc(&d, 1024); hipMalloc(&c, 64);
@@ -161,6 +233,8 @@ int main() {
     op_rows<OP_PKMUL>(d, c); op_rows<OP_AND>(d, c); op_rows<OP_LSHL>(d, c); op_rows<OP_MAX3>(d, c); op_rows<OP_MOV>(d, c);
     op_rows<OP_RCP>(d, c);
     het_row<OP_SUB>(d); het_row<OP_FMA>(d); het_row<OP_EXP>(d); het_row<OP_CVTPK>(d); het_row<OP_PKADD>(d); het_row<OP_LSHL>(d);
+    phase_rows<48, 240>(d);
+    phase_rows<48, 120>(d);
     printf("%s\n", hipGetErrorString(hipGetLastError()));
     return 0;
 }
