@@ -215,7 +215,7 @@ def main():
 
     total_series = args.steps * B * world
     lanes_used = args.lanes or (int(os.environ["T2S_SAMPLER_LANES"]) if os.environ.get("T2S_SAMPLER_LANES") in ("1", "2")
-                                else (2 if B >= 128 else 1))
+                                else (2 if B >= 128 and B % 64 == 0 else 1))
     value = total_series / elapsed
     out = {
         "metric": "generated series/sec (B=256, L=96, 1000-step DDPM)",

@@ -339,8 +339,8 @@ int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, const float* no
 /* Lanes of t2s_sampler_run: the rows of a batch never interact (infer.py:76-88), so the loop may run as two half
  * batches, each a complete chain with its own hipGraph on its own stream (lane 1 on a stream the sampler owns,
  * forked from / joined to `stream` inside the call), so that one chain's kernels fill the chip while the other's
- * drain.  Bitwise the same result.  lanes: 0 = automatic (two from batch >= 128; env T2S_SAMPLER_LANES=1|2
- * overrides), 1, 2.  trace0 runs always use one lane. */
+ * drain.  Bitwise the same result.  lanes: 0 = automatic (two when batch >= 128 and a multiple of 64; env
+ * T2S_SAMPLER_LANES=1|2 overrides), 1, 2.  trace0 runs always use one lane. */
 int t2s_sampler_set_lanes(t2s_sampler* s, int lanes);
 
 /* ------------------------------------------------------------------------ *

@@ -363,13 +363,14 @@ void drop_graph(t2s_sampler* s) {
     s->lanes_cap = 0;
 }
 
-// lanes of this run: two when asked for, or automatically when each half batch still fills the chip
-// (>= 64 series = 128 sequences per lane; measured: 4.0 % faster at B = 256, nothing to gain at 2 x 32)
+// lanes of this run: two when asked for, or automatically when each half batch still fills the chip (>= 64 series =
+// 128 sequences per lane; measured: 4 % faster at B = 256, 0.6 % at 1024, nothing to gain at 2 x 32) AND splits into two
+// halves of whole 32-row groups (see the split point below: other splits can lose more than the second lane gains)
 int pick_lanes(const t2s_sampler* s, bool trace) {
     if (trace || s->cfg.batch < 2) return 1;
     if (s->lanes_req) return s->lanes_req;
     if (const char* e = getenv("T2S_SAMPLER_LANES")) return atoi(e) == 2 ? 2 : 1;
-    return s->cfg.batch >= 128 ? 2 : 1;
+    return (s->cfg.batch >= 128 && s->cfg.batch % 64 == 0) ? 2 : 1;
 }
 
 }  // namespace

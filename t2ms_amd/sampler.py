@@ -36,7 +36,7 @@ def loop_t_values(backbone: str, steps: int) -> torch.Tensor:
 class Sampler:
     def __init__(self, model, decoder, backbone: str, steps: int, cfg_scale: float, batch: int, length: int,
                  device, use_graph: bool = True, seed: int = 2025, row0: int = 0, lanes: int = 0):
-        """lanes: 0 = automatic (two half-batch chains on two streams from batch >= 128), 1, 2 -- see
+        """lanes: 0 = automatic (two half-batch chains on two streams when batch >= 128 and a multiple of 64), 1, 2 -- see
         t2s_sampler_set_lanes; a scheduling choice only, the results are bitwise the same."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
