@@ -152,8 +152,8 @@ void het_row(float* d) {
 // instructions, 3/4 v_fma + 1/4 v_exp like the bf16x3 attention loop): does the pair run in max(...) or in the sum?
 // OFFSET 1: waves 4-7 start with their VALU phase (anti-phase start); GRAIN: the phases are cut into GRAIN slices that
 // alternate (GRAIN = 1: one matrix block then one VALU block; 12: [4 MFMA, 20 VALU] x 12).
-template <int MG, int VG, int OFFSET, int GRAIN>
-__global__ __launch_bounds__(512) void phases(float* out, int iters, float a0) {
+template <int MG, int VG, int OFFSET, int GRAIN, int DEP = 0>
+__global__ __launch_bounds__(1024) void phases(float* out, int iters, float a0) {
     extern __shared__ float pad[];
     const int wave = threadIdx.x >> 6;
     f32x16 acc[2];
@@ -169,10 +169,25 @@ __global__ __launch_bounds__(512) void phases(float* out, int iters, float a0) {
         for (int m = 0; m < MG / GRAIN; ++m) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %1, %0" : "+v"(acc[m & 1]) : "v"(ab));
     };
     auto vphase = [&]() {
+        if (DEP) {   // the VALU phase consumes the matrix results (after the wait states hipcc would insert) ...
+            asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[j]) : "v"(acc[j & 1][j]));
+        }
 #pragma unroll
         for (int j = 0; j < VG / GRAIN; ++j) {
             if ((j & 3) == 3) one<OP_EXP>(v[j & 7], w[j & 7], p[j & 7], a0);
             else one<OP_FMA>(v[j & 7], w[j & 7], p[j & 7], a0);
+        }
+        if (DEP) {   // ... and produces the next matrix phase's operand
+            typedef float f32x2v __attribute__((ext_vector_type(2)));
+            typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x2v c = __builtin_convertvector(f32x2v{v[2 * j], v[2 * j + 1]}, bf16x2v);
+                ab[2 * j] = c[0]; ab[2 * j + 1] = c[1];
+            }
+            asm volatile("" : "+v"(ab));
         }
     };
     if (OFFSET && wave >= 4) {
@@ -193,16 +208,16 @@ __global__ __launch_bounds__(512) void phases(float* out, int iters, float a0) {
     if (s == 12345.678f) out[0] = s + pad[0];
 }
 
-template <int MG, int VG, int OFFSET, int GRAIN>
+template <int MG, int VG, int OFFSET, int GRAIN, int DEP = 0>
 double run_phases(float* d, int waves) {
     const int lds = 150 * 1024;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(phases<MG, VG, OFFSET, GRAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(phases<MG, VG, OFFSET, GRAIN, DEP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int iters = 400;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    phases<MG, VG, OFFSET, GRAIN><<<256, 64 * waves, lds>>>(d, iters, 1.0f);
+    phases<MG, VG, OFFSET, GRAIN, DEP><<<256, 64 * waves, lds>>>(d, iters, 1.0f);
     hipEventRecord(e0);
-    phases<MG, VG, OFFSET, GRAIN><<<256, 64 * waves, lds>>>(d, iters, 1.0f);
+    phases<MG, VG, OFFSET, GRAIN, DEP><<<256, 64 * waves, lds>>>(d, iters, 1.0f);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0.f;
@@ -235,6 +250,12 @@ int main() {
     het_row<OP_SUB>(d); het_row<OP_FMA>(d); het_row<OP_EXP>(d); het_row<OP_CVTPK>(d); het_row<OP_PKADD>(d); het_row<OP_LSHL>(d);
     phase_rows<48, 240>(d);
     phase_rows<48, 120>(d);
+    // true dependencies (VALU phase reads the matrix results, matrix phase reads the VALU results), same work per SIMD
+    // spread over 1, 2 and 4 waves
+    printf("dependent phases, 96 MFMA + 480 VALU per SIMD and round: 1 wave x (96 + 480): %.0f ns | 2 waves x (48 + 240): %.0f ns | "
+           "4 waves x (24 + 120): %.0f ns   (matrix bound %.0f ns)\n",
+           run_phases<96, 480, 0, 1, 1>(d, 4), run_phases<48, 240, 0, 1, 1>(d, 8), run_phases<24, 120, 0, 1, 1>(d, 16),
+           2 * run_phases<48, 0, 0, 1>(d, 4));
     printf("%s\n", hipGetErrorString(hipGetLastError()));
     return 0;
 }
