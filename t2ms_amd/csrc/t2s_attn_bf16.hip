@@ -14,7 +14,7 @@
 //   col read  (ds_read_b64_tr_b16)  -> MFMA operand with the image COLUMN on the lane  (K^T, V^T, Q^T, dO^T)
 // The 32x32 score tile never leaves registers: the fp32 accumulator, converted pairwise to bf16,
 // is the next MFMA's operand (acc_frag; its permuted k order is matched by the column reads).
-#include "t2s_bf16.h"
+#include "t2s_x3.h"   // T2S_X3_KERNEL (no packed fp32: it serialises with bf16 MFMAs), wg_sync; includes t2s_bf16.h
 
 namespace t2s {
 
@@ -60,7 +60,7 @@ __device__ __forceinline__ bf16x8 col_frag(const char* img, int base, int lane, 
 }  // namespace
 
 // ------------------------------------------------------------------ forward with lse
-__global__ __launch_bounds__(512) void attn16_fwd_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
+__global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_fwd_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
                                                          const __bf16* __restrict__ v, __bf16* __restrict__ o_rows,
                                                          float* __restrict__ lse) {
     __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(const __bf16* __restric
     const int seq = bh / NH, head = bh % NH;
     stage_img(Ks, k + (size_t)bh * NTOK * DH, DH, tid, 512);
     stage_img(Vs, v + (size_t)bh * NTOK * DH, DH, tid, 512);
-    __syncthreads();
+    wg_sync();
     const __bf16* qg = q + (size_t)bh * NTOK * DH;
     for (int qt = wave; qt < NKB; qt += 8) {
         const int tok = qt * 32 + i;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(const __bf16* __restric
                 pt[r] = __builtin_amdgcn_exp2f(st[r] * QS - mq);
                 ps += pt[r];
             }
-            if (__any(!(ps < 1.0995116e12f))) {      // 2^40; also catches inf / NaN
+            if (__builtin_amdgcn_ballot_w64(!(ps < 1.0995116e12f)) != 0) {      // 2^40; also catches inf / NaN
                 float mloc = st[0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[r]);
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void attn16_dsum_kernel(const __bf16* __restri
 }
 
 // ------------------------------------------------------------------ kernel A: dQ (queries on lanes)
-__global__ __launch_bounds__(512) void attn16_bwd_dq_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
+__global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_bwd_dq_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
                                                             const __bf16* __restrict__ v, const __bf16* __restrict__ do_rows,
                                                             const float* __restrict__ lse, const float* __restrict__ dsum,
                                                             __bf16* __restrict__ dqkv) {
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(512) void attn16_bwd_dq_kernel(const __bf16* __rest
     const int seq = bh / NH, head = bh % NH;
     stage_img(Ks, k + (size_t)bh * NTOK * DH, DH, tid, 512);
     stage_img(Vs, v + (size_t)bh * NTOK * DH, DH, tid, 512);
-    __syncthreads();
+    wg_sync();
     const __bf16* qg = q + (size_t)bh * NTOK * DH;
     for (int qt = wave; qt < NKB; qt += 8) {
         const int tok = qt * 32 + i;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(512) void attn16_bwd_dq_kernel(const __bf16* __rest
 }
 
 // ------------------------------------------------------------------ kernel B: dK, dV (keys on lanes)
-__global__ __launch_bounds__(512) void attn16_bwd_dkv_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
+__global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_bwd_dkv_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
                                                              const __bf16* __restrict__ v, const __bf16* __restrict__ do_rows,
                                                              const float* __restrict__ lse, const float* __restrict__ dsum,
                                                              __bf16* __restrict__ dqkv) {
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(512) void attn16_bwd_dkv_kernel(const __bf16* __res
         Ls[t] = lse[(size_t)bh * NTOK + t];
         Ds[t] = dsum[(size_t)bh * NTOK + t];
     }
-    __syncthreads();
+    wg_sync();
     const __bf16* kg = k + (size_t)bh * NTOK * DH;
     const __bf16* vg = v + (size_t)bh * NTOK * DH;
     for (int kb = wave; kb < NKB; kb += 8) {
