@@ -92,20 +92,9 @@ def usable_cores() -> int:
     return max(1, min(n, int(os.environ.get("T2S_CPU_BASELINE_THREADS", "16"))))
 
 
-def cpu_baseline(batch, diff_steps, cfg, length, n_cfg_steps=4):
-    """The CPU oracle (torch fp32, all host threads) on a bounded sample of the same workload:
-    n_cfg_steps CFG steps at the full batch + one decode, extrapolated to diff_steps steps (every
-    step costs the same)."""
-    from oracle import t2s_oracle as O
-    from t2ms_amd import synth
-    cores = usable_cores()
-    torch.set_num_threads(cores)
-    sd = synth.make_dit_state_dict(2025)
-    vsd = synth.make_vae_state_dict(2025)
-    x = synth.make_latents(2025, batch)
-    text = synth.make_text_embeddings(2025, batch)
-    tab = O.ddpm_tables(diff_steps)
-    g = torch.Generator().manual_seed(0)
+def _cpu_cfg_steps(O, sd, x, text, tab, diff_steps, cfg, n_steps, g):
+    """Wall time per CFG step (2 DiT forwards + DDPM update) of the oracle, after one warm step."""
+    batch = x.shape[0]
 
     def one_step(x, j):
         t = torch.full((batch,), diff_steps - 1 - j, dtype=torch.long)
@@ -116,12 +105,43 @@ def cpu_baseline(batch, diff_steps, cfg, length, n_cfg_steps=4):
     with torch.no_grad():
         x = one_step(x, 0)  # warm
         t0 = time.perf_counter()
-        for j in range(1, 1 + n_cfg_steps):
+        for j in range(1, 1 + n_steps):
             x = one_step(x, j)
-        t_step = (time.perf_counter() - t0) / n_cfg_steps
-        t0 = time.perf_counter()
-        O.vae_decode(vsd, x, length)
-        t_dec = time.perf_counter() - t0
+        return (time.perf_counter() - t0) / n_steps, x
+
+
+def cpu_baseline(batch, diff_steps, cfg, length, n_cfg_steps=4, one_thread_batch=16):
+    """The CPU oracle (torch fp32) on a bounded sample of the same workload: n_cfg_steps CFG steps at the full batch
+    on this job's host cores + one decode, extrapolated to diff_steps steps (every step costs the same); plus the
+    single-thread figure BASELINE.md section 3 asks for, on a smaller batch (series/s on a CPU is flat in the batch:
+    SURVEY.md section 6 measured 0.110 at B=32 and 0.114 at B=256).  Attention runs as F.scaled_dot_product_attention --
+    what timm 1.0.11's Attention.forward (fused_attn) executes in the reference -- not the oracle's explicit softmax."""
+    from oracle import t2s_oracle as O
+    from t2ms_amd import synth
+    cores = usable_cores()
+    sd = synth.make_dit_state_dict(2025)
+    vsd = synth.make_vae_state_dict(2025)
+    text = synth.make_text_embeddings(2025, batch)
+    tab = O.ddpm_tables(diff_steps)
+    g = torch.Generator().manual_seed(0)
+    O.set_attention_impl("sdpa")
+    try:
+        torch.set_num_threads(cores)
+        t_step, x = _cpu_cfg_steps(O, sd, synth.make_latents(2025, batch), text, tab, diff_steps, cfg, n_cfg_steps, g)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            O.vae_decode(vsd, x, length)
+            t_dec = time.perf_counter() - t0
+        torch.set_num_threads(1)
+        b1 = min(batch, one_thread_batch)
+        t1_step, x1 = _cpu_cfg_steps(O, sd, synth.make_latents(2025, b1), text[:b1], tab, diff_steps, cfg, 1, g)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            O.vae_decode(vsd, x1, length)
+            t1_dec = time.perf_counter() - t0
+    finally:
+        O.set_attention_impl("explicit")
+        torch.set_num_threads(cores)
     total = t_step * diff_steps + t_dec
     cpu_model = "unknown"
     try:
@@ -131,9 +151,126 @@ def cpu_baseline(batch, diff_steps, cfg, length, n_cfg_steps=4):
                 break
     except OSError:
         pass
-    return {"value": batch / total, "unit": "series/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_cfg_steps} CFG steps (2 DiT forwards + DDPM update) at B={batch} + 1 decode, "
-                      f"extrapolated x{diff_steps}/{n_cfg_steps}; {t_step:.3f} s/step; CPU: {cpu_model}"}
+    return {"value": batch / total, "unit": "series/s", "cores": cores, "kind": "port",
+            "sample": f"{n_cfg_steps} CFG steps (2 DiT forwards + DDPM update) at B={batch} + 1 decode on {cores} threads, "
+                      f"extrapolated x{diff_steps}/{n_cfg_steps}; {t_step:.3f} s/step; attention = "
+                      f"F.scaled_dot_product_attention (the reference's timm fused_attn path); CPU: {cpu_model}",
+            "one_thread": {"value": b1 / (t1_step * diff_steps + t1_dec), "unit": "series/s", "cores": 1,
+                           "sample": f"1 CFG step at B={b1} + 1 decode on 1 thread, extrapolated x{diff_steps}; "
+                                     f"{t1_step:.3f} s/step"}}
+
+
+# ---------------------------------------------------------------------------- training leg (BASELINE configs[3])
+FLOP_TRAIN_PER_SAMPLE = 3 * 0.977e9            # forward + backward = 3 x the forward
+TRAIN_CLASSES = ("attention", "row_chain", "other", "train_gemm", "train_attn_fwd", "train_attn_bwd", "train_wgrad",
+                 "train_elementwise", "train_tail")
+
+
+def train_leg(dev, dist, rank, world, batch=1152, length=96, steps=30, warmup=4, dtype="bf16"):
+    """BASELINE configs[3] shape under the same clock discipline as the headline: DiT training step of train.py
+    (train.train_step: cached LA-VAE latents -> q_sample -> forward -> MSE -> backward -> ONE flat-bucket all-reduce
+    -> fused AdamW), bf16 MFMA operands with fp32 master weights, per-GPU batch 1152 (global 9216 on 8 GPUs), L=96,
+    DDPM T=100, synthetic rows.  Every rank runs it; the time is the max over ranks."""
+    import ctypes as C
+    import train as drv
+    from t2ms_amd import _lib as L
+    from t2ms_amd import dist as tdist
+    from t2ms_amd import latent_cache, synth
+    from t2ms_amd.train import T2SAdamW
+    from model.backbone.DDPM import DDPM
+    model, vae = build_models(dev)
+    model.train().set_train_dtype(dtype)
+    model.encoder = vae.encoder
+    for n, p in model.named_parameters():
+        if "encoder" in n:
+            p.requires_grad = False
+    opt = T2SAdamW(model.parameters(), lr=1e-4, weight_decay=0.0)
+    ddpm = DDPM(100, dev)
+    args = types.SimpleNamespace(backbone="ddpm", total_step=100, seed=2025)
+    n_global = batch * world
+    x = synth.make_series(1, batch, length)                       # this rank's rows; the driver slices a global batch
+    text = synth.make_text_embeddings(1, batch)
+    lat_local = latent_cache.encode_all(model.encoder, x, dev)
+    # train_step shards a GLOBAL batch by rank: hand it global-shaped inputs whose slice [lo, hi) is this rank's data
+    lo, _ = tdist.shard_rows(n_global, rank, world)
+    xg = torch.zeros(n_global, length)
+    eg = torch.zeros(n_global, 128)
+    eg[lo:lo + batch] = text
+    latents = torch.zeros(n_global, 64, 30, device=dev)
+    latents[lo:lo + batch] = lat_local
+    idx = torch.arange(n_global)
+    torch.manual_seed(2025)
+
+    def run(n, d, first):
+        loss = None
+        for i in range(n):
+            loss = drv.train_step(model, ddpm, opt, d, args, xg, eg, dev, rank, world, latents, idx, first + i)
+        return loss
+
+    run(warmup, dist, 0)
+    tdist.barrier(dist, dev)
+    t0 = time.perf_counter()
+    loss = run(steps, dist, warmup)
+    tdist.barrier(dist, dev)
+    el = tdist.max_over_ranks(dist, time.perf_counter() - t0, dev)
+    out = {"metric": "DiT training samples/sec (configs[3] shape: bf16, B=1152/GPU, L=96, DDPM T=100, cached latents)",
+           "value": n_global * steps / el, "unit": "samples/s", "ms_per_step": el / steps * 1e3, "steps": steps,
+           "warmup": warmup, "per_gpu_batch": batch, "global_batch": n_global, "dtype": dtype,
+           "tflops_algorithmic": FLOP_TRAIN_PER_SAMPLE * n_global * steps / el / 1e12,
+           "loss": float(loss), "optimizer": "fused AdamW lr 1e-4 (t2s_adamw_step_multi)", "data": "synthetic"}
+    if dist is not None:        # the same steps with the collective skipped: its share of the step
+        tdist.barrier(dist, dev)
+        t0 = time.perf_counter()
+        run(steps, None, warmup + steps)
+        tdist.barrier(dist, dev)
+        el0 = tdist.max_over_ranks(dist, time.perf_counter() - t0, dev)
+        out["ms_per_step_without_allreduce"] = el0 / steps * 1e3
+        out["allreduce_share"] = max(0.0, 1.0 - el0 / el)
+        out["allreduce"] = "one SUM all-reduce of the flat 3.7 MB fp32 gradient bucket per step (RCCL)"
+    if rank == 0:               # per-class kernel time, in situ (HIP events around every launch of 3 eager steps)
+        h = model.t2s_handle(dev, batch)
+        torch.cuda.synchronize(dev)
+        L.check(L.lib().t2s_dit_timing_begin(h))
+        n_t = 3
+        run(n_t, None, 10_000)
+        buf = (C.c_double * 18)()
+        L.check(L.lib().t2s_dit_timing_end_ex(h, buf, 9))
+        br = {TRAIN_CLASSES[i]: {"ms_per_step": buf[2 * i] / n_t, "launches_per_step": buf[2 * i + 1] / n_t}
+              for i in range(3, 9) if buf[2 * i + 1] > 0}
+        out["kernel_classes"] = br
+        top = max(br, key=lambda k: br[k]["ms_per_step"])
+        bytes_model = train_bytes_model(batch)
+        out["hbm_bytes_per_step_model"] = bytes_model["total"]
+        out["hbm_bytes_model_note"] = bytes_model["note"]
+        kernel_ms = sum(v["ms_per_step"] for v in br.values())
+        out["roofline"] = {"bound": "hbm", "kernel": f"whole step (largest class: {top})",
+                           "achieved": bytes_model["total"] / (kernel_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                           "frac": bytes_model["total"] / (kernel_ms * 1e-3) / 1e9 / 8000.0,
+                           "traffic": _train_traffic_from_profile(batch),
+                           "timing": f"sum of HIP-event launch durations over {n_t} eager steps = {kernel_ms:.2f} ms/step"}
+    return out
+
+
+def train_bytes_model(batch):
+    """Bytes the bf16 training step moves BY DESIGN, in units u = one bf16 (M,128) tensor,
+    M = batch * 480 tokens; fp32 (M,128) = 2u.  Kept next to the kernels' launch list: update both together."""
+    u = batch * 480 * 128 * 2
+    units = TRAIN_UNITS_PER_BLOCK * 4
+    return {"total": units * u, "note": f"{TRAIN_UNITS_PER_BLOCK} u per block x 4 blocks, u = {u / 1e6:.1f} MB "
+                                        f"(one bf16 (M,128) tensor); tails < 1 %"}
+
+
+TRAIN_UNITS_PER_BLOCK = 88   # round-1 kernel list: forward 32 u + backward 56 u (DESIGN.md 4.3)
+
+
+def _train_traffic_from_profile(batch):
+    """HBM bytes per step from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (None if absent)."""
+    f = os.path.join(REPO, "profiles", "train_traffic.json")
+    try:
+        d = json.load(open(f))
+        return d.get("hbm_bytes_per_step") if d.get("per_gpu_batch") == batch else None
+    except (OSError, ValueError):
+        return None
 
 
 def alt_math_run(model, vae, args, dev, text):
@@ -174,6 +311,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2],
                     help="sampler lanes: 0 = the library's default (two half-batch chains on two streams from B >= 128), 1, 2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the training leg reported as `train`")
+    ap.add_argument("--train-batch", type=int, default=1152, help="per-GPU batch of the training leg")
+    ap.add_argument("--train-steps", type=int, default=30)
     ap.add_argument("--no-alt-math", action="store_true", help="skip the extra bf16x3 measurement reported as alt_math")
     ap.add_argument("--math", default="f32", choices=["f32", "bf16x3"],
                     help="matrix arithmetic: f32 MFMA (headline) or fp32-accurate split-bf16 products (include/t2s.h)")
@@ -181,17 +321,17 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     from t2ms_amd import dist as tdist
     from t2ms_amd import synth
+    local_rank = tdist.local_device_index()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     from t2ms_amd.sampler import Sampler
     dist = tdist.init("nccl", dev)      # RCCL; None when single-process
 
@@ -229,23 +369,30 @@ def main():
                    "global_batch": B * world, "diffusion_steps": args.diffusion_steps, "parallelism": f"batch-shard x{world}",
                    "sampler_lanes": lanes_used},
     }
+    train = None
+    if not args.no_train:
+        train = train_leg(dev, dist, rank, world, batch=args.train_batch, steps=args.train_steps)
     if rank == 0:
         # roofline of the dominant kernel (fused attention; 48 % of all FLOPs), same shapes as the workload
         kt = time_kernels_in_situ(model, dev, lat.clone(), text)
         t_attn = kt["attn_us"] * 1e-6
         flop_attn = FLOP_ATTN_PER_SEQ_BLOCK * 2 * B
         achieved = flop_attn / t_attn / 1e12
-        traffic = None
-        tfile = os.path.join(REPO, "profiles", "attn_traffic.json")
-        if os.path.exists(tfile) and B == 256:     # the PMC passes were taken at the headline shape
+        # HBM traffic / matrix-busy share of that kernel: NOT measured by this run (PMC counters need rocprofv3
+        # passes of their own); read from the committed summary of those passes, which names its source revision
+        pmc = {}
+        pfile = os.path.join(REPO, "profiles", "attn_pmc.json")
+        if os.path.exists(pfile) and B == 256:     # the PMC passes were taken at the headline shape
             try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                pmc = json.load(open(pfile))
             except (OSError, ValueError):
-                traffic = None
+                pmc = {}
+        traffic = pmc.get("hbm_bytes_per_launch")
         out["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_persistent_kernel", "achieved": achieved,
                            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                            "traffic": traffic, "hbm_gbps": (traffic / t_attn / 1e9) if traffic else None,
-                           "mfma_busy_frac_pmc": 0.79, "pmc_source": "profiles/r01_v7_pmc_mfma_utilisation.md",
+                           "pmc": {"mfma_busy_frac": pmc.get("mfma_busy_frac"), "source": pmc.get("source"),
+                                   "measured_by_this_run": False} if pmc else None,
                            "avg_launch_us": t_attn * 1e6,
                            "flop_per_launch": flop_attn, "launches_timed": kt["attn_calls"],
                            "timing": "HIP events on the launch stream around every attention launch of "
@@ -266,6 +413,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, args.diffusion_steps, args.cfg_scale, args.length)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if train is not None:
+            out["train"] = train
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

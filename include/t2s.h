@@ -131,6 +131,11 @@ int t2s_dit_forward_cfg(t2s_dit* h, const float* x, const float* temb, const flo
  * row-chain launches, other ms, other launches} in out6 and disarms it. */
 int t2s_dit_timing_begin(t2s_dit* h);
 int t2s_dit_timing_end(t2s_dit* h, double* out6);
+/* The same with the launches of the training step (t2s_dit_train_forward / _backward) in classes 3..8: out holds
+ * n_classes pairs {ms, launches}: 0 attention, 1 row chain, 2 other (inference forward); 3 streaming GEMMs / fused row
+ * kernels, 4 attention forward, 5 attention backward, 6 weight gradients, 7 gate / LayerNorm elementwise kernels,
+ * 8 everything else of the step (packs, patchify, final layer, adaLN linear).  n_classes <= 9. */
+int t2s_dit_timing_end_ex(t2s_dit* h, double* out, int n_classes);
 
 /* Test tap: copy out the residual stream (S,480,128) the last forward left in the
  * workspace (post block 3, before the final LayerNorm).  Used by tests to bisect. */
@@ -342,6 +347,10 @@ int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, const float* no
  * drain.  Bitwise the same result.  lanes: 0 = automatic (two when batch >= 128 and a multiple of 64; env
  * T2S_SAMPLER_LANES=1|2 overrides), 1, 2.  trace0 runs always use one lane. */
 int t2s_sampler_set_lanes(t2s_sampler* s, int lanes);
+/* Move the sampler to another shard position: global index of its first series (the Philox key of row r is
+ * row0 + r).  Takes effect at the next t2s_sampler_run; the captured hipGraphs are kept (the kernels read the
+ * value from device memory next to the step counter).  infer.py:66 loops over batches with one sampler. */
+int t2s_sampler_set_row0(t2s_sampler* s, uint32_t row0);
 
 /* ------------------------------------------------------------------------ *
  * Evaluation metrics: evaluation.py:166-206 (calculate_mse, calculate_wape), :21-45 (calculate_mrr)

@@ -66,6 +66,9 @@ def infer(args):
     device = torch.device(args.device)
     rank, local_rank, world = tdist.env_world()
     dist = tdist.init("nccl", device)
+    # ONE seed for the whole job: it seeds the loader shuffle (every rank must walk the same batches to take ITS rows
+    # of each) and keys the Philox noise.  A per-rank time-based default would silently mis-pair series across ranks.
+    args.seed = tdist.broadcast_int(dist, args.seed)
     backbone = {"flowmatching": "flowmatching", "ddpm": "ddpm"}.get(args.backbone)
     if backbone is None:
         raise ValueError("No backbone found")
@@ -89,8 +92,7 @@ def infer(args):
             if sampler is None or sampler.batch != hi - lo or sampler.length != L:
                 sampler = Sampler(model, vae.decoder, backbone, args.total_step, args.cfg_scale, hi - lo, L,
                                   device, use_graph=True, seed=args.seed, row0=0)
-            sampler.row0 = n_series + lo          # global row index of this shard's first series
-            sampler._create()
+            sampler.set_row0(n_series + lo)       # global row index of this shard's first series; the graph is kept
             want_trace = bool(args.trace) and batch == 0 and rank == 0
             lat, series, tr = sampler.run(embedding[lo:hi].contiguous(), decode=True, trace=want_trace)
             if want_trace:
@@ -162,7 +164,7 @@ def main(argv=None):
     args.mix_train = False
     if not torch.cuda.is_available():
         sys.exit("infer.py: no GPU visible -- this build runs the HIP path only (no CPU fallback)")
-    _, local_rank, _ = tdist.env_world()
+    local_rank = tdist.local_device_index()
     torch.cuda.set_device(local_rank)
     args.device = f"cuda:{local_rank}"
     if args.seed is None:

@@ -135,21 +135,39 @@ def modulate(x: Tensor, shift: Tensor, scale: Tensor) -> Tensor:
     return x * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1)
 
 
+_ATTENTION_IMPL = "explicit"
+
+
+def set_attention_impl(impl: str) -> None:
+    """Which of timm 1.0.11 Attention.forward's two branches timm_attention follows: "explicit" (the non-fused
+    branch, the default here: every intermediate is inspectable) or "sdpa" (F.scaled_dot_product_attention, the branch
+    timm takes when `fused_attn` is available, i.e. what the reference executes; bench.py times this one as the CPU
+    baseline).  The two agree to fp32 rounding (tests/test_oracle_golden.py)."""
+    global _ATTENTION_IMPL
+    if impl not in ("explicit", "sdpa"):
+        raise ValueError(impl)
+    _ATTENTION_IMPL = impl
+
+
 def timm_attention(x: Tensor, w_qkv: Tensor, b_qkv: Tensor, w_proj: Tensor, b_proj: Tensor,
                    num_heads: int = N_HEADS) -> Tensor:
     """timm 1.0.11 vision_transformer.Attention.forward (restated; unpinned).
 
     Call site transformer.py:104,116: Attention(128, num_heads=4, qkv_bias=True);
-    q_norm/k_norm are Identity, dropouts are 0.  Uses the explicit (non-fused)
-    form: softmax((q*scale) @ k^T) @ v.
+    q_norm/k_norm are Identity, dropouts are 0.  Default: the explicit (non-fused)
+    form softmax((q*scale) @ k^T) @ v; see set_attention_impl for the fused branch.
     """
     B, N, C = x.shape
     hd = C // num_heads
     qkv = F.linear(x, w_qkv, b_qkv).reshape(B, N, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv.unbind(0)
-    q = q * (hd ** -0.5)
-    attn = (q @ k.transpose(-2, -1)).softmax(dim=-1)
-    o = (attn @ v).transpose(1, 2).reshape(B, N, C)
+    if _ATTENTION_IMPL == "sdpa":
+        o = F.scaled_dot_product_attention(q, k, v)
+    else:
+        q = q * (hd ** -0.5)
+        attn = (q @ k.transpose(-2, -1)).softmax(dim=-1)
+        o = attn @ v
+    o = o.transpose(1, 2).reshape(B, N, C)
     return F.linear(o, w_proj, b_proj)
 
 

@@ -81,6 +81,7 @@ SYMBOLS = {
     "t2s_dit_read_stream": (_I, [_VP, _VP, _I, _VP]),
     "t2s_dit_timing_begin": (_I, [_VP]),
     "t2s_dit_timing_end": (_I, [_VP, C.POINTER(C.c_double)]),
+    "t2s_dit_timing_end_ex": (_I, [_VP, C.POINTER(C.c_double), _I]),
     "t2s_dit_set_train_dtype": (_I, [_VP, _I]),
     "t2s_dit_set_math": (_I, [_VP, _I]),
     "t2s_eval_mse_wape": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP]),
@@ -109,6 +110,7 @@ SYMBOLS = {
     "t2s_sampler_destroy": (None, [_VP]),
     "t2s_sampler_run": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "t2s_sampler_set_lanes": (_I, [_VP, _I]),
+    "t2s_sampler_set_row0": (_I, [_VP, _U32]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -233,19 +233,6 @@ int upload_weights(t2s_dit* h, const t2s_dit_weights* w, hipStream_t st) {
     return T2S_OK;
 }
 
-enum { TC_ATTN = 0, TC_ROWS = 1, TC_OTHER = 2 };
-struct TimeScope {   // records an event pair around one launch when timing is on
-    t2s_dit* h; hipStream_t st; bool on;
-    TimeScope(t2s_dit* h_, int cls, hipStream_t st_) : h(h_), st(st_), on(h_->timing) {
-        if (!on) return;
-        hipEvent_t a, b;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
-        h->ev_pool.push_back(a); h->ev_pool.push_back(b); h->ev_class.push_back(cls);
-        (void)hipEventRecord(a, st);
-    }
-    ~TimeScope() { if (on) (void)hipEventRecord(h->ev_pool.back(), st); }
-};
-
 // One DiT forward over S sequences (sequence s reads latent row s % B).
 // ws_seq0: first workspace slot (in sequences) this pass may use -- the sampler runs two half batches as independent
 // lanes on two streams, each in its own slice of the workspace (slots [ws_seq0, ws_seq0 + S))
@@ -520,16 +507,19 @@ int t2s_dit_timing_begin(t2s_dit* h) {
     return T2S_OK;
 }
 
-int t2s_dit_timing_end(t2s_dit* h, double* out6) {
-    T2S_REQUIRE(h && out6, "t2s_dit_timing_end: NULL argument");
+int t2s_dit_timing_end(t2s_dit* h, double* out6) { return t2s_dit_timing_end_ex(h, out6, 3); }
+
+int t2s_dit_timing_end_ex(t2s_dit* h, double* out, int n_classes) {
+    T2S_REQUIRE(h && out && n_classes > 0 && n_classes <= t2s::TC_COUNT, "t2s_dit_timing_end_ex: bad argument (n_classes=%d)", n_classes);
     h->timing = false;
-    for (int i = 0; i < 6; ++i) out6[i] = 0.0;
+    for (int i = 0; i < 2 * n_classes; ++i) out[i] = 0.0;
     for (size_t i = 0; i < h->ev_class.size(); ++i) {
         T2S_HIP_CHECK(hipEventSynchronize(h->ev_pool[2 * i + 1]));
         float ms = 0.f;
         T2S_HIP_CHECK(hipEventElapsedTime(&ms, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]));
-        out6[2 * h->ev_class[i]] += ms;
-        out6[2 * h->ev_class[i] + 1] += 1.0;
+        if (h->ev_class[i] >= n_classes) continue;
+        out[2 * h->ev_class[i]] += ms;
+        out[2 * h->ev_class[i] + 1] += 1.0;
     }
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     h->ev_pool.clear();

@@ -30,3 +30,20 @@ struct t2s_dit {
     std::vector<int> ev_class;   // class of interval i = [ev_pool[2i], ev_pool[2i+1]]
 };
 
+
+namespace t2s {
+// launch classes of the in-situ timing (t2s_dit_timing_begin / _end[_ex]): inference forward 0-2, training step 3-8
+enum { TC_ATTN = 0, TC_ROWS = 1, TC_OTHER = 2, TC_TR_GEMM = 3, TC_TR_ATTN_FWD = 4, TC_TR_ATTN_BWD = 5, TC_TR_WGRAD = 6,
+       TC_TR_ELEM = 7, TC_TR_TAIL = 8, TC_COUNT = 9 };
+struct TimeScope {   // records an event pair around the launches issued in its scope when timing is on
+    t2s_dit* h; hipStream_t st; bool on;
+    TimeScope(t2s_dit* h_, int cls, hipStream_t st_) : h(h_), st(st_), on(h_->timing) {
+        if (!on) return;
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+        h->ev_pool.push_back(a); h->ev_pool.push_back(b); h->ev_class.push_back(cls);
+        (void)hipEventRecord(a, st);
+    }
+    ~TimeScope() { if (on) (void)hipEventRecord(h->ev_pool.back(), st); }
+};
+}  // namespace t2s

@@ -74,7 +74,8 @@ struct StepArgs {
     const float* noise;   // injected draws: (steps,noise_rows,1920) indexed by step (this shard's first row), or
                           // (B,1920) if step_ptr NULL
     const float* coef;    // DEVICE (T,3)
-    const int* step_ptr;  // device loop index j, or NULL (then t_index / stream_id are immediate)
+    const int* step_ptr;  // device {loop index j, global row of the first series}, or NULL (then t_index / stream_id /
+                          // row0 are immediate)
     int steps;            // T (t = steps-1-j when step_ptr != NULL)
     int t_index;
     float cfg;
@@ -90,10 +91,11 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const StepArgs a) {
     constexpr int QPR = LAT / 4;
     if (idx >= a.B * QPR) return;
     int t = a.t_index;
-    uint32_t sid = a.stream_id;
+    uint32_t sid = a.stream_id, row0 = a.row0;
     const float* noise = a.noise;
     if (a.step_ptr) {
-        const int j = *a.step_ptr;
+        const int j = a.step_ptr[0];
+        row0 = (uint32_t)a.step_ptr[1];   // read on the device so a captured graph serves every shard position
         t = a.steps - 1 - j;
         sid = (uint32_t)j;
         if (noise) noise += (size_t)j * a.noise_rows * LAT;
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const StepArgs a) {
         z = reinterpret_cast<const f32x4*>(noise)[idx];
     } else {
         const int row = idx / QPR, quad = idx - row * QPR;
-        z = normal4(a.seed, sid, a.row0 + (uint32_t)row, (uint32_t)quad);
+        z = normal4(a.seed, sid, row0 + (uint32_t)row, (uint32_t)quad);
     }
     const f32x4 mean = c0 * (x - c1 * pred);
     reinterpret_cast<f32x4*>(a.x)[idx] = mean + c2 * z;
@@ -218,8 +220,16 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, c
     }
 }
 
-__global__ void set_step_kernel(int* step, int value, int delta) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *step = delta ? *step + delta : value;
+// step[0] = loop index, step[1] = global row index of the lane's first series (Philox key)
+__global__ void set_step_kernel(int* step, int value, int delta, uint32_t row0) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (delta) {
+            step[0] += delta;
+        } else {
+            step[0] = value;
+            step[1] = (int)row0;
+        }
+    }
 }
 
 }  // namespace t2s
@@ -348,7 +358,7 @@ int enqueue_step(t2s_sampler* s, float* x, const float* text, const float* noise
         rf_step_kernel<<<(n4 + 255) / 256, 256, 0, st>>>(xl, eu, ec, c.cfg_scale, 1.0f / (float)c.steps, n4);
     }
     T2S_LAUNCH_CHECK();
-    set_step_kernel<<<1, 64, 0, st>>>(step, 0, 1);
+    set_step_kernel<<<1, 64, 0, st>>>(step, 0, 1, 0u);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }
@@ -427,6 +437,12 @@ extern "C" int t2s_sampler_set_lanes(t2s_sampler* s, int lanes) {
     return T2S_OK;
 }
 
+extern "C" int t2s_sampler_set_row0(t2s_sampler* s, uint32_t row0) {
+    T2S_REQUIRE(s, "t2s_sampler_set_row0: NULL sampler");
+    s->cfg.row0 = row0;   // uploaded next to the step counters at the start of every run: no re-capture
+    return T2S_OK;
+}
+
 extern "C" void t2s_sampler_destroy(t2s_sampler* s) {
     if (!s) return;
     drop_graph(s);
@@ -494,7 +510,7 @@ extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, cons
         T2S_HIP_CHECK(hipStreamWaitEvent(s->side, s->ev_fork, 0));
     }
     for (int l = 0; l < lanes; ++l) {
-        set_step_kernel<<<1, 64, 0, lst[l]>>>(s->step + 16 * l, 0, 0);
+        set_step_kernel<<<1, 64, 0, lst[l]>>>(s->step + 16 * l, 0, 0, c.row0 + (uint32_t)r0[l]);
         T2S_LAUNCH_CHECK();
     }
     for (int j = 0; j < c.steps; ++j) {

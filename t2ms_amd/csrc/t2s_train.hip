@@ -846,60 +846,100 @@ int t2s_dit_train_forward(t2s_dit* h, const t2s_dit_weights* w, const float* x, 
             pk(b.fc1_w, ws->fc1_f16[i], ws->fc1_t16[i], 2 * D, D);
             pk(b.fc2_w, ws->fc2_f16[i], ws->fc2_t16[i], D, 2 * D);
         }
+        { TimeScope ts(h, TC_TR_TAIL, st);
         pack16_multi_kernel<<<dim3((3 * D * D + 255) / 256, np), 256, 0, st>>>(pt);
         T2S_LAUNCH_CHECK();
+        }
     }
     T2S_HIP_CHECK(hipMemcpyAsync(ws->lat, x, (size_t)S * LAT * sizeof(float), hipMemcpyDeviceToDevice, st));
+    { TimeScope ts(h, TC_TR_TAIL, st);
     cond_rows_kernel<<<(S * D + 255) / 256, 256, 0, st>>>(ws->c, temb, temb_rows, text, S);
     T2S_LAUNCH_CHECK();
+    }
+    { TimeScope ts(h, TC_TR_TAIL, st);
     silu_kernel<<<(S * D + 255) / 256, 256, 0, st>>>(ws->c, ws->silu_c, S * D);
     T2S_LAUNCH_CHECK();
+    }
+    { TimeScope ts(h, TC_TR_TAIL, st);
     if ((rc = gemm<128, 3, PRO_PLAIN, EPI_BIAS>(ws->silu_c, h->ada_p, h->ada_b, ws->mod, S, MODROW, st))) return rc;
+    }
+    { TimeScope ts(h, TC_TR_TAIL, st);
     patchify_rows_kernel<<<(S * NTOK * 32 + 255) / 256, 256, 0, st>>>(x, ws->x_in[0], S, h->conv_w, h->conv_b, h->patch_w,
                                                                       h->patch_b, h->pos);
     T2S_LAUNCH_CHECK();
+    }
     for (int i = 0; i < NBLK && bf; ++i) {
         const int base = i * MODW;
         // a1 = mod(LN1(x_in)) -> bf16; q,k,v = a1 Wqkv^T + b -> bf16 heads
+        { TimeScope ts(h, TC_TR_GEMM, st);
         if ((rc = bgemm<128, 384, BPRO_LN, BEPI_QKV>(ws->x_in[i], ws->qkv_f16[i], h->qkv_b[i], nullptr, M, 3 * D, st, ws->mod,
                                                  base + 0 * D, base + 1 * D, ws->a1h[i], nullptr, ws->qh[i], ws->kh[i], ws->vh[i])))
             return rc;
+        }
+        { TimeScope ts(h, TC_TR_ATTN_FWD, st);
         if ((rc = attn16_train_fwd(ws->qh[i], ws->kh[i], ws->vh[i], ws->oh[i], ws->lse[i], S * NH, st))) return rc;
+        }
         // p = o Wp^T + b; x_mid = x_in + g1 * p.  (Fusing the gate/residual into the GEMM epilogue was measured
         // slower: the lane-per-token epilogue touches the fp32 stream in 32-byte pieces, 346 vs 82 + 123 us.)
+        { TimeScope ts(h, TC_TR_GEMM, st);
         if ((rc = bgemm<128, 128, BPRO_BF16, BEPI_BF16>(ws->oh[i], ws->proj_f16[i], h->proj_b[i], ws->ph[i], M, D, st))) return rc;
+        }
+        { TimeScope ts(h, TC_TR_ELEM, st);
         gate_res_kernel<<<(M * 32 + 255) / 256, 256, 0, st>>>(ws->x_in[i], ws->ph[i], ws->mod, base + 2 * D, ws->x_mid[i], M);
         T2S_LAUNCH_CHECK();
+        }
         // a2 = mod(LN2(x_mid)); u = a2 W1^T + b1; g = gelu(u) (saved for the fc2 weight gradient); f = g W2^T + b2
+        { TimeScope ts(h, TC_TR_GEMM, st);
         if ((rc = bgemm<128, 256, BPRO_LN, BEPI_BF16>(ws->x_mid[i], ws->fc1_f16[i], h->fc1_b[i], ws->uh[i], M, 2 * D, st, ws->mod,
                                                   base + 3 * D, base + 4 * D, ws->a2h[i])))
             return rc;
+        }
+        { TimeScope ts(h, TC_TR_GEMM, st);
         if ((rc = bgemm<256, 128, BPRO_GELU, BEPI_BF16>(ws->uh[i], ws->fc2_f16[i], h->fc2_b[i], ws->fh[i], M, D, st, nullptr, 0, 0,
                                                          ws->gh[i])))
             return rc;
+        }
+        { TimeScope ts(h, TC_TR_ELEM, st);
         gate_res_kernel<<<(M * 32 + 255) / 256, 256, 0, st>>>(ws->x_mid[i], ws->fh[i], ws->mod, base + 5 * D, ws->x_in[i + 1], M);
         T2S_LAUNCH_CHECK();
+        }
     }
     for (int i = 0; i < NBLK && !bf; ++i) {
         const int base = i * MODW;
         // a1 = mod(LN1(x_in)); q,k,v = a1 Wqkv^T + b
+        { TimeScope ts(h, TC_TR_GEMM, st);
         if ((rc = gemm<128, 3, PRO_LNMOD, EPI_QKV>(ws->x_in[i], h->qkv_p[i], h->qkv_b[i], nullptr, M, 3 * D, st, ws->mod,
                                                     base + 0 * D, base + 1 * D, ws->a1[i], nullptr, ws->q[i], ws->k[i], ws->v[i])))
             return rc;
+        }
+        { TimeScope ts(h, TC_TR_ATTN_FWD, st);
         if ((rc = attn_plain_train_fwd(ws->q[i], ws->k[i], ws->v[i], ws->o[i], ws->lse[i], S * NH, st))) return rc;
+        }
+        { TimeScope ts(h, TC_TR_GEMM, st);
         if ((rc = gemm<128, 1, PRO_PLAIN, EPI_BIAS>(ws->o[i], h->proj_p[i], h->proj_b[i], ws->p[i], M, D, st))) return rc;
+        }
+        { TimeScope ts(h, TC_TR_ELEM, st);
         gate_res_kernel<<<(M * 32 + 255) / 256, 256, 0, st>>>(ws->x_in[i], ws->p[i], ws->mod, base + 2 * D, ws->x_mid[i], M);
         T2S_LAUNCH_CHECK();
+        }
         // a2 = mod(LN2(x_mid)); u = a2 W1^T + b1; f = gelu(u) W2^T + b2
+        { TimeScope ts(h, TC_TR_GEMM, st);
         if ((rc = gemm<128, 2, PRO_LNMOD, EPI_BIAS>(ws->x_mid[i], h->fc1_p[i], h->fc1_b[i], ws->u[i], M, 2 * D, st, ws->mod,
                                                      base + 3 * D, base + 4 * D, ws->a2[i])))
             return rc;
+        }
+        { TimeScope ts(h, TC_TR_GEMM, st);
         if ((rc = gemm<256, 1, PRO_GELU, EPI_BIAS>(ws->u[i], ws->fc2_f[i], h->fc2_b[i], ws->f[i], M, D, st))) return rc;
+        }
+        { TimeScope ts(h, TC_TR_ELEM, st);
         gate_res_kernel<<<(M * 32 + 255) / 256, 256, 0, st>>>(ws->x_mid[i], ws->f[i], ws->mod, base + 5 * D, ws->x_in[i + 1], M);
         T2S_LAUNCH_CHECK();
+        }
     }
+    { TimeScope ts(h, TC_TR_TAIL, st);
     final_rows_kernel<<<(M * 32 + 255) / 256, 256, 0, st>>>(ws->x_in[NBLK], S, h->ln_w, h->ln_b, h->out_w, h->out_b, out);
     T2S_LAUNCH_CHECK();
+    }
     return T2S_OK;
 }
 
@@ -932,9 +972,11 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
         i = k;
     }
     // ---- final layer
+    { TimeScope ts(h, TC_TR_TAIL, st);
     final_bwd_kernel<<<(M + TAIL_ROWS - 1) / TAIL_ROWS, 256, 0, st>>>(ws->x_in[NBLK], dout, h->ln_w, h->ln_b, h->out_w, ws->dx, g->ln_w,
                                                     g->ln_b, g->out_w, g->out_b, M);
     T2S_LAUNCH_CHECK();
+    }
     const bool bf = ws->dtype == T2S_TRAIN_BF16;
     for (int i = NBLK - 1; i >= 0 && bf; --i) {
         const int base = i * MODW;
@@ -942,76 +984,132 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
         // ---- MLP branch: x_out = x_mid + g2 * f.  t1 = df = g2 * dx and dgate2 come from the previous block's
         // LN1 backward (merged gate backward) except for the last block
         if (i == NBLK - 1) {
+            { TimeScope ts(h, TC_TR_ELEM, st);
             gate_bwd_kernel<<<S, 256, 0, st>>>(ws->dx, ws->fh[i], ws->mod, base + 5 * D, ws->t1h, ws->dmod);
             T2S_LAUNCH_CHECK();
+            }
         }
+        { TimeScope ts(h, TC_TR_WGRAD, st);
         if ((rc = launch_wgrad16(ws->t1h, ws->gh[i], b.fc2_w, b.fc2_b, M, D, 2 * D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
+        }
         // du = (df W2) * gelu'(u)
+        { TimeScope ts(h, TC_TR_GEMM, st);
         if ((rc = bgemm<128, 256, BPRO_BF16, BEPI_GELUBWD>(ws->t1h, ws->fc2_t16[i], nullptr, ws->t2h, M, 2 * D, st, nullptr, 0, 0,
                                                             nullptr, ws->uh[i])))
             return rc;
+        }
+        { TimeScope ts(h, TC_TR_WGRAD, st);
         if ((rc = launch_wgrad16(ws->t2h, ws->a2h[i], b.fc1_w, b.fc1_b, M, 2 * D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
+        }
         // da2 = du W1 -> t4
+        { TimeScope ts(h, TC_TR_GEMM, st);
         if ((rc = bgemm<256, 128, BPRO_BF16, BEPI_BF16>(ws->t2h, ws->fc1_t16[i], nullptr, ws->t4h, M, D, st))) return rc;
+        }
         // LN2 backward into dx, merged with the attention branch's gate backward: t1 = dp = g1 * dx, dgate1
+        { TimeScope ts(h, TC_TR_ELEM, st);
         ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t4h, ws->x_mid[i], ws->mod, base + 3 * D, base + 4 * D, ws->dx, ws->dmod,
                                              ws->ph[i], base + 2 * D, ws->t1h);
         T2S_LAUNCH_CHECK();
+        }
         // ---- attention branch: x_mid = x_in + g1 * p
+        { TimeScope ts(h, TC_TR_WGRAD, st);
         if ((rc = launch_wgrad16(ws->t1h, ws->oh[i], b.proj_w, b.proj_b, M, D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
+        }
+        { TimeScope ts(h, TC_TR_GEMM, st);
         if ((rc = bgemm<128, 128, BPRO_BF16, BEPI_BF16>(ws->t1h, ws->proj_t16[i], nullptr, ws->t4h, M, D, st))) return rc;   // do
+        }
+        { TimeScope ts(h, TC_TR_ATTN_BWD, st);
         if ((rc = attn16_bwd(ws->qh[i], ws->kh[i], ws->vh[i], ws->oh[i], ws->t4h, ws->lse[i], ws->dsum, ws->t3h, S * NH, st)))
             return rc;
+        }
+        { TimeScope ts(h, TC_TR_WGRAD, st);
         if ((rc = launch_wgrad16(ws->t3h, ws->a1h[i], b.qkv_w, b.qkv_b, M, 3 * D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
+        }
         // da1 = dqkv Wqkv -> t4
+        { TimeScope ts(h, TC_TR_GEMM, st);
         if ((rc = bgemm<384, 128, BPRO_BF16, BEPI_BF16>(ws->t3h, ws->qkv_t16[i], nullptr, ws->t4h, M, D, st))) return rc;
+        }
         // LN1 backward into dx, merged with the gate backward of block i-1's MLP branch
+        { TimeScope ts(h, TC_TR_ELEM, st);
         ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t4h, ws->x_in[i], ws->mod, base + 0 * D, base + 1 * D, ws->dx, ws->dmod,
                                              i > 0 ? ws->fh[i - 1] : (const __bf16*)nullptr, (i - 1) * MODW + 5 * D, ws->t1h);
         T2S_LAUNCH_CHECK();
+        }
     }
     for (int i = NBLK - 1; i >= 0 && !bf; --i) {
         const int base = i * MODW;
         const t2s_dit_block_grads& b = g->blk[i];
         // ---- MLP branch: x_out = x_mid + g2 * f
+        { TimeScope ts(h, TC_TR_ELEM, st);
         gate_bwd_kernel<<<S, 256, 0, st>>>(ws->dx, ws->f[i], ws->mod, base + 5 * D, ws->t1, ws->dmod);      // t1 = df
         T2S_LAUNCH_CHECK();
+        }
+        { TimeScope ts(h, TC_TR_ELEM, st);
         gelu_kernel<<<((size_t)M * 64 + 255) / 256, 256, 0, st>>>(ws->u[i], ws->t2a, (size_t)M * 64);        // t2a = gelu(u)
         T2S_LAUNCH_CHECK();
+        }
+        { TimeScope ts(h, TC_TR_WGRAD, st);
         if ((rc = wgrad(ws, ws->t1, ws->t2a, b.fc2_w, b.fc2_b, M, D, 2 * D, st))) return rc;
+        }
         // du = (df W2) * gelu'(u)      (dgrad = row GEMM on W2^T: out 256 <- in 128)
+        { TimeScope ts(h, TC_TR_GEMM, st);
         if ((rc = gemm<128, 2, PRO_PLAIN, EPI_GELUBWD>(ws->t1, ws->fc2_t[i], nullptr, ws->t2b, M, 2 * D, st, nullptr, 0, 0,
                                                         nullptr, ws->u[i])))
             return rc;
+        }
+        { TimeScope ts(h, TC_TR_WGRAD, st);
         if ((rc = wgrad(ws, ws->t2b, ws->a2[i], b.fc1_w, b.fc1_b, M, 2 * D, D, st))) return rc;
+        }
         // da2 = du W1 (out 128 <- in 256)
+        { TimeScope ts(h, TC_TR_GEMM, st);
         if ((rc = gemm<256, 1, PRO_PLAIN, EPI_BIAS>(ws->t2b, ws->fc1_t[i], nullptr, ws->t1, M, D, st))) return rc;
+        }
+        { TimeScope ts(h, TC_TR_ELEM, st);
         ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t1, ws->x_mid[i], ws->mod, base + 3 * D, base + 4 * D, ws->dx, ws->dmod,
                                              (const float*)nullptr, 0, (float*)nullptr);
         T2S_LAUNCH_CHECK();
+        }
         // ---- attention branch: x_mid = x_in + g1 * p
+        { TimeScope ts(h, TC_TR_ELEM, st);
         gate_bwd_kernel<<<S, 256, 0, st>>>(ws->dx, ws->p[i], ws->mod, base + 2 * D, ws->t1, ws->dmod);       // t1 = dp
         T2S_LAUNCH_CHECK();
+        }
+        { TimeScope ts(h, TC_TR_WGRAD, st);
         if ((rc = wgrad(ws, ws->t1, ws->o[i], b.proj_w, b.proj_b, M, D, D, st))) return rc;
+        }
+        { TimeScope ts(h, TC_TR_GEMM, st);
         if ((rc = gemm<128, 1, PRO_PLAIN, EPI_BIAS>(ws->t1, ws->proj_t[i], nullptr, ws->t4, M, D, st))) return rc;   // do
+        }
+        { TimeScope ts(h, TC_TR_ATTN_BWD, st);
         if ((rc = attn_bwd(ws->q[i], ws->k[i], ws->v[i], ws->o[i], ws->t4, ws->lse[i], ws->dsum, ws->t3, S * NH, st))) return rc;
+        }
+        { TimeScope ts(h, TC_TR_WGRAD, st);
         if ((rc = wgrad(ws, ws->t3, ws->a1[i], b.qkv_w, b.qkv_b, M, 3 * D, D, st))) return rc;
+        }
         // da1 = dqkv Wqkv (out 128 <- in 384)
+        { TimeScope ts(h, TC_TR_GEMM, st);
         if ((rc = gemm<384, 1, PRO_PLAIN, EPI_BIAS>(ws->t3, ws->qkv_t[i], nullptr, ws->t1, M, D, st))) return rc;
+        }
+        { TimeScope ts(h, TC_TR_ELEM, st);
         ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t1, ws->x_in[i], ws->mod, base + 0 * D, base + 1 * D, ws->dx, ws->dmod,
                                              (const float*)nullptr, 0, (float*)nullptr);
         T2S_LAUNCH_CHECK();
+        }
     }
     // ---- patchify
+    { TimeScope ts(h, TC_TR_TAIL, st);
     patchify_bwd_kernel<<<(M + TAIL_ROWS - 1) / TAIL_ROWS, 256, 0, st>>>(ws->dx, ws->lat, S, h->conv_w, h->conv_b, h->patch_w, g->patch_w,
                                                        g->patch_b, g->conv_w, g->conv_b, M);
     T2S_LAUNCH_CHECK();
+    }
     // ---- adaLN linear: mod = silu(c) W_ada^T + b_ada  (per block rows [768 i, 768 i + 768) of the (3072,128) stack)
     for (int i = 0; i < NBLK; ++i) {
         // dmod block slice is strided (row stride MODROW): copy to a dense (S,768) temp first
         T2S_HIP_CHECK(hipMemcpy2DAsync(ws->t1, MODW * sizeof(float), ws->dmod + i * MODW, MODROW * sizeof(float),
                                        MODW * sizeof(float), S, hipMemcpyDeviceToDevice, st));
+        { TimeScope ts(h, TC_TR_WGRAD, st);
         if ((rc = wgrad(ws, ws->t1, ws->silu_c, g->blk[i].ada_w, g->blk[i].ada_b, S, MODW, D, st))) return rc;
+        }
     }
     return T2S_OK;
 }

@@ -10,6 +10,7 @@ the network, and there is no CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 import math
 import weakref
 
@@ -140,10 +141,16 @@ def _freqs_on(device) -> torch.Tensor:
     return _FREQS[key]
 
 
+_HANDLE_IDS = itertools.count(1)
+
+
 class _DitHandle:
-    """Owns one t2s_dit (packed weights + workspace) for one module on one device."""
+    """Owns one t2s_dit (packed weights + workspace) for one module on one device.  `uid` identifies THIS handle
+    for the life of the process: a re-created handle often gets the freed one's address back, so users that cache
+    state bound to a handle (Sampler's captured hipGraph, a pending backward) compare uids, never pointers."""
 
     def __init__(self, weights: L.DitWeights, keep, max_seqs: int):
+        self.uid = next(_HANDLE_IDS)
         self.ptr = C.c_void_p()
         self.keep = keep
         self.max_seqs = max_seqs
@@ -254,6 +261,11 @@ class Transformer(nn.Module):
                         "t2s_dit_set_math")
             self.__dict__["_t2s_math_applied"] = math
         return h.ptr
+
+    def t2s_handle_id(self):
+        """uid of the current t2s_dit handle (None before the first use); changes whenever t2s_handle() rebuilds it."""
+        h = self.__dict__.get("_t2s_h")
+        return None if h is None else h.uid
 
     def set_math(self, math: str):
         """Matrix arithmetic of the (no-grad) forward / the sampler: "f32" (default, f32 MFMA) or "bf16x3"

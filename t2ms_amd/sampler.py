@@ -33,6 +33,18 @@ def loop_t_values(backbone: str, steps: int) -> torch.Tensor:
     raise ValueError("No backbone found")
 
 
+def philox_normal(n_rows: int, row_elems: int, seed: int, stream_id: int, row0: int, device) -> torch.Tensor:
+    """(n_rows, row_elems) N(0,1) draws of the library's Philox stream: element e of GLOBAL row row0 + r uses counter
+    (e/4, row0 + r, stream_id), key = seed -- the same values however the rows are sharded over GPUs."""
+    device = torch.device(device)
+    out = torch.empty(n_rows, row_elems, device=device, dtype=torch.float32)
+    if n_rows:
+        with torch.cuda.device(device):
+            L.check(L.lib().t2s_philox_normal(L.dev_ptr(out), int(seed), int(stream_id) & 0xFFFFFFFF, int(row0), n_rows,
+                                              row_elems, L.stream_ptr(device)), "t2s_philox_normal")
+    return out
+
+
 class Sampler:
     def __init__(self, model, decoder, backbone: str, steps: int, cfg_scale: float, batch: int, length: int,
                  device, use_graph: bool = True, seed: int = 2025, row0: int = 0, lanes: int = 0):
@@ -67,7 +79,7 @@ class Sampler:
         cfg.t_values = tvals.data_ptr()
         with torch.cuda.device(self.device):
             dit = model.t2s_handle(self.device, 2 * self.batch)
-            self._dit_ptr = dit.value
+            self._dit_uid = model.t2s_handle_id()
             vae = decoder._handle(self.device) if decoder is not None else None
             torch.cuda.synchronize(self.device)
             self.ptr = C.c_void_p()
@@ -75,6 +87,12 @@ class Sampler:
             L.check(L.lib().t2s_sampler_set_lanes(self.ptr, self.lanes), "t2s_sampler_set_lanes")
         self._fin = weakref.finalize(self, L.lib().t2s_sampler_destroy, self.ptr)
         self._keep = (tvals, coef)
+
+    def set_row0(self, row0: int):
+        """Global index of this shard's first series for the NEXT run (the Philox key of row r is row0 + r);
+        the captured hipGraph is kept (t2s_sampler_set_row0)."""
+        self.row0 = int(row0)
+        L.check(L.lib().t2s_sampler_set_row0(self.ptr, self.row0), "t2s_sampler_set_row0")
 
     def draw_xT(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x_T ~ N(0,1) from the Philox stream (perf mode), (batch,64,30)."""
@@ -114,8 +132,9 @@ class Sampler:
         tr = torch.empty(self.steps, self.length, device=dev, dtype=torch.float32) if trace else None
         with torch.cuda.device(dev):
             # weights may have changed since the last run: refresh the packed copy on the caller's stream
-            if self.model.t2s_handle(dev, 2 * self.batch).value != self._dit_ptr:
-                self._create()  # the model re-created its handle (capacity grew / device moved)
+            self.model.t2s_handle(dev, 2 * self.batch)
+            if self.model.t2s_handle_id() != self._dit_uid:
+                self._create()  # the model re-created its handle (capacity grew / device moved): drop the graph
             cur = torch.cuda.current_stream(dev)
             self.stream.wait_stream(cur)
             L.check(L.lib().t2s_sampler_run(self.ptr, L.dev_ptr(self._x), L.dev_ptr(self._text), L.dev_ptr(noise),
@@ -130,6 +149,8 @@ class Sampler:
         Requires one prior run() (buffers + text in place).  Returns (latent, series) views."""
         dev = self.device
         with torch.cuda.device(dev):
+            if self.model.t2s_handle_id() != self._dit_uid:
+                self._create()
             self.draw_xT(self._x)
             cur = torch.cuda.current_stream(dev)
             self.stream.wait_stream(cur)

@@ -61,6 +61,49 @@ _GRAD_TOP = ("conv_w", "conv_b", "patch_w", "patch_b", None, "ln_w", "ln_b", "ou
 _GRAD_BLK = ("qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ada_w", "ada_b")
 
 
+BUCKET = N_GRAD + 8   # the flat gradient bucket; slot N_GRAD carries the (weighted) loss through the same all-reduce
+
+
+def _trainable(model):
+    """The 48 tensors that receive a gradient, in bucket order (= _dit_tensors() minus pos_embed)."""
+    ts = model._dit_tensors()
+    return [t for i, t in enumerate(ts) if i != 4]
+
+
+def _make_bucket(model, dev):
+    """A flat fp32 bucket + one view per gradient tensor + the t2s_dit_grads struct pointing into it."""
+    flat = torch.zeros(BUCKET, device=dev, dtype=torch.float32)
+    g = L.DitGrads()
+    views, off = [], 0
+    ts = _trainable(model)
+    for name, t in zip([n for n in _GRAD_TOP if n is not None], ts[:8]):
+        n = t.numel()
+        v = flat[off:off + n].view(t.shape)
+        setattr(g, name, v.data_ptr())
+        views.append(v)
+        off += n
+    for i in range(4):
+        for j, name in enumerate(_GRAD_BLK):
+            t = ts[8 + 10 * i + j]
+            n = t.numel()
+            v = flat[off:off + n].view(t.shape)
+            setattr(g.blk[i], name, v.data_ptr())
+            views.append(v)
+            off += n
+    assert off == N_GRAD, off
+    return dict(flat=flat, views=views, struct=g)
+
+
+def grad_bucket(model, dev):
+    """The model's PERSISTENT gradient bucket on `dev`: every backward writes here, p.grad aliases its views, the
+    DDP all-reduce sends it as one message, and the fused AdamW's pointer table stays valid from step to step."""
+    b = model.__dict__.get("_t2s_bucket")
+    if b is None or b["flat"].device != dev:
+        b = _make_bucket(model, dev)
+        model.__dict__["_t2s_bucket"] = b
+    return b
+
+
 class _DitTrainFn(torch.autograd.Function):
     """pred = Transformer(input, t, text) with a hand-written backward (train.py:123-125)."""
 
@@ -77,46 +120,36 @@ class _DitTrainFn(torch.autograd.Function):
             L.check(L.lib().t2s_dit_train_forward(h, C.byref(w), L.dev_ptr(x, "input"), L.dev_ptr(temb), B,
                                                   L.dev_ptr(text, "text_input"), L.dev_ptr(out), B,
                                                   L.stream_ptr(dev)), "t2s_dit_train_forward")
-        ctx.model, ctx.B, ctx.keep = model, B, keep
-        ctx.param_shapes = [tuple(p.shape) for p in params]
+        # the saved activations live in the model's ONE handle: a later grad-mode forward overwrites them
+        gen = model.__dict__.get("_t2s_fwd_gen", 0) + 1
+        model.__dict__["_t2s_fwd_gen"] = gen
+        ctx.model, ctx.B, ctx.keep, ctx.gen, ctx.handle_id = model, B, keep, gen, model.t2s_handle_id()
         return out
 
     @staticmethod
     def backward(ctx, dout):
         model, B = ctx.model, ctx.B
         dev = dout.device
-        flat = torch.empty(N_GRAD, device=dev, dtype=torch.float32)
-        model.__dict__["_t2s_flat_grad"] = flat           # one bucket: what the DDP all-reduce sends
-        g = L.DitGrads()
-        grads, off = [], 0
-        names = list(_GRAD_TOP) + [None] * 0
-        for name, shp in zip(names, ctx.param_shapes[:9]):
-            if name is None:
-                grads.append(None)
-                continue
-            n = 1
-            for s in shp:
-                n *= s
-            view = flat[off:off + n].view(shp)
-            setattr(g, name, view.data_ptr())
-            grads.append(view)
-            off += n
-        for i in range(4):
-            for j, name in enumerate(_GRAD_BLK):
-                shp = ctx.param_shapes[9 + 10 * i + j]
-                n = 1
-                for s in shp:
-                    n *= s
-                view = flat[off:off + n].view(shp)
-                setattr(g.blk[i], name, view.data_ptr())
-                grads.append(view)
-                off += n
-        assert off == N_GRAD, off
+        if model.__dict__.get("_t2s_fwd_gen") != ctx.gen or model.t2s_handle_id() != ctx.handle_id:
+            raise L.T2SError("Transformer backward: another grad-mode forward ran on this model (or its handle was "
+                             "rebuilt) since the forward being differentiated -- the saved activations are gone. "
+                             "Run forward -> backward pairs one at a time (wrap extra forwards in torch.no_grad()).")
+        bucket = grad_bucket(model, dev)
+        ts = _trainable(model)
+        if any(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(ts[:1], bucket["views"][:1])):
+            # gradients of an earlier backward still live in the persistent bucket (accumulation, or
+            # zero_grad(set_to_none=False)): write this pass elsewhere so autograd can add the two
+            bucket = _make_bucket(model, dev)
+        model.__dict__["_t2s_flat_grad"] = bucket["flat"]
         d = L.as_f32(dout)
         with torch.cuda.device(dev):
             h = model.t2s_handle(dev, B)
-            L.check(L.lib().t2s_dit_train_backward(h, L.dev_ptr(d, "grad_output"), C.byref(g), B,
+            L.check(L.lib().t2s_dit_train_backward(h, L.dev_ptr(d, "grad_output"), C.byref(bucket["struct"]), B,
                                                    L.stream_ptr(dev)), "t2s_dit_train_backward")
+        # fresh view objects: AccumulateGrad adopts a returned gradient in place of copying it only when nothing
+        # else references the tensor object -- p.grad must ALIAS the bucket (all-reduce, AdamW pointer table)
+        views = [v.view_as(v) for v in bucket["views"]]
+        grads = views[:4] + [None] + views[4:]      # pos_embed (index 4 of _dit_tensors) gets none
         return (None, None, None, None) + tuple(grads)
 
 
@@ -211,13 +244,33 @@ class T2SAdamW(torch.optim.Optimizer):
 
 
 # ---------------------------------------------------------------------------- data parallel
-def allreduce_gradients(model, dist) -> Optional[torch.Tensor]:
-    """Average the DiT gradients over ranks with ONE all-reduce of the flat 3.7 MB bucket the backward
-    filled (latency-bound, a single bucket beats stock DDP's many).  No-op when
-    `dist` is None."""
-    flat = model.__dict__.get("_t2s_flat_grad")
-    if dist is None or flat is None:
-        return flat
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat.div_(dist.get_world_size())
-    return flat
+def allreduce_gradients(model, dist, n_local: Optional[int] = None, n_global: Optional[int] = None,
+                        loss: Optional[torch.Tensor] = None):
+    """Combine the DiT gradients of all ranks with ONE all-reduce of the flat 3.7 MB bucket (SURVEY.md 8e:
+    latency-bound, a single bucket beats stock DDP's many).  Rank r's gradient of ITS mean loss over n_local rows is
+    weighted n_local / n_global, so the sum is the gradient of the mean over the global batch even when shards are
+    ragged (default weights: 1 / world).  A rank whose shard is empty (p.grad is None after zero_grad) contributes a
+    zero bucket -- every rank must call this every step.  `loss` rides in the bucket's spare slot.  Returns
+    (flat bucket, global mean loss or None).  No-op when `dist` is None."""
+    ts = _trainable(model)
+    if dist is None:
+        return model.__dict__.get("_t2s_flat_grad"), loss
+    dev = ts[0].device
+    bucket = grad_bucket(model, dev)
+    flat, views = bucket["flat"], bucket["views"]
+    if all(p.grad is None for p in ts):
+        flat.zero_()
+    for p, v in zip(ts, views):
+        if p.grad is None:
+            p.grad = v
+        elif p.grad.data_ptr() != v.data_ptr():       # autograd cloned / accumulated elsewhere: move it into the bucket
+            v.copy_(p.grad)
+            p.grad = v
+    world = dist.get_world_size()
+    w = (float(n_local) / float(n_global)) if (n_local is not None and n_global) else 1.0 / world
+    flat[N_GRAD] = loss.detach() if loss is not None else 0.0
+    flat.mul_(w)
+    from . import dist as tdist
+    tdist.all_reduce_sum(dist, flat)
+    model.__dict__["_t2s_flat_grad"] = flat
+    return flat, (flat[N_GRAD].clone() if loss is not None or n_local == 0 else None)

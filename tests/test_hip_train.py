@@ -256,3 +256,60 @@ def test_bf16_attention_forward_and_stale_reference_branch(dev):
     # P is rounded to bf16 before P.V and O is stored as bf16: ~2^-8 relative
     assert float((o - ref).abs().max()) < 3e-2 and _rel(o, ref) < 6e-3
     assert float((lsed.cpu().double() - lse_ref).abs().max()) < 2e-3
+
+
+def test_bf16_full_batch_properties(dev):
+    """BASELINE configs[3] per-GPU shape (B=1152, bf16): size-independent properties instead of an oracle run --
+    the forward rows equal the SAME rows in a 4-row batch bitwise (rows are independent end to end, tile position in
+    the batch does not change a row's arithmetic), every gradient is finite, and the block weight / bias gradients
+    are bit-reproducible from run to run (fixed reduction order; include/t2s.h t2s_dit_train_backward)."""
+    from t2ms_amd.train import _trainable, mse_loss
+    B = 1152
+    x = synth.make_latents(5, B).to(dev)
+    text = synth.make_text_embeddings(5, B).to(dev)
+    t = (torch.arange(B) % 100).to(dev)
+    target = synth.make_latents(6, B).to(dev)
+    m = _model(dev).set_train_dtype("bf16")
+    rows = [0, 1, 575, 1151]
+    with torch.enable_grad():
+        small = m(input=x[rows].contiguous(), t=t[rows].contiguous(), text_input=text[rows].contiguous()).detach().clone()
+        runs = []
+        for _ in range(2):
+            m.zero_grad()
+            pred = m(input=x, t=t, text_input=text)
+            loss = mse_loss(pred, target)
+            loss.backward()
+            torch.cuda.synchronize()
+            runs.append((pred.detach().clone(), float(loss), [p.grad.detach().clone() for p in _trainable(m)]))
+    assert torch.equal(runs[0][0][rows], small), "a row's forward depends on the batch it sits in"
+    assert torch.equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
+    names = ["conv_w", "conv_b", "patch_w", "patch_b", "ln_w", "ln_b", "out_w", "out_b"] + \
+            [f"blk{i}.{n}" for i in range(4) for n in ("qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w",
+                                                        "fc2_b", "ada_w", "ada_b")]
+    for name, g0, g1 in zip(names, runs[0][2], runs[1][2]):
+        assert torch.isfinite(g0).all() and float(g0.abs().max()) > 0, name
+        if name.startswith("blk"):
+            assert torch.equal(g0, g1), f"{name}: gradient differs between two identical runs"
+        else:                                   # atomically flushed tail gradients: last bits may vary
+            assert float((g0 - g1).abs().max()) <= 1e-5 * float(g0.abs().max()), name
+
+
+def test_backward_fails_loudly_after_a_second_grad_forward(dev):
+    """The saved activations live in the model's one handle: a second grad-mode forward before the backward of the
+    first must raise instead of returning the gradients of the wrong pass."""
+    from t2ms_amd._lib import T2SError
+    from t2ms_amd.train import mse_loss
+    m = _model(dev)
+    x = synth.make_latents(1, 2).to(dev)
+    t = torch.tensor([3, 4], device=dev)
+    p1 = m(input=x, t=t, text_input=None)
+    p2 = m(input=x * 2, t=t, text_input=None)
+    with pytest.raises(T2SError, match="another grad-mode forward"):
+        mse_loss(p1, x).backward()
+    m.zero_grad()
+    mse_loss(p2, x).backward()                # the most recent forward is still differentiable
+    assert m.layers[0].attn.qkv.weight.grad is not None
+    # accumulation over two forward/backward pairs adds up (the persistent bucket is not overwritten in place)
+    g1 = m.layers[0].attn.qkv.weight.grad.clone()
+    mse_loss(m(input=x * 2, t=t, text_input=None), x).backward()
+    torch.testing.assert_close(m.layers[0].attn.qkv.weight.grad, 2 * g1, rtol=1e-5, atol=1e-8)

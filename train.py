@@ -49,35 +49,50 @@ def _load_vae(args, device):
     return vae.float().to(device).eval()
 
 
-def train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world, latents=None, idx=None):
-    """One optimisation step on this rank's slice of the batch (train.py:103-127 / 60-87)."""
-    lo, hi = tdist.shard_rows(x_1.shape[0], rank, world)
-    if hi == lo:
-        return None
-    emb = emb[lo:hi].float().to(device)
-    if latents is not None and idx is not None:
-        z = latents[idx[lo:hi].to(device)]                                         # pre-encoded rows (latent cache)
-    else:
-        with torch.no_grad():
-            z, _ = model.encoder(x_1[lo:hi].float().to(device).contiguous())      # frozen LA-VAE (train.py:31-33,106)
-    n = z.shape[0]
-    if args.backbone == "flowmatching":
-        t = torch.round(torch.rand(n, device=device) * args.total_step) / args.total_step
-        x_t, x_0 = backbone.create_flow(z, t)
-        target = z - x_0
-    elif args.backbone == "ddpm":
-        t = torch.floor(torch.rand(n).to(device) * args.total_step).long()
-        target = torch.randn_like(z)
-        x_t, _ = backbone.q_sample(z, t, target)
-    else:
-        raise ValueError(f"Unsupported backbone type: {args.backbone}")
+def train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world, latents=None, idx=None, step_no=0):
+    """One optimisation step on this rank's slice of the batch (train.py:103-127 / 60-87).
+
+    Every rank runs every step -- also with an EMPTY slice (a length group smaller than the world size): it then
+    contributes a zero bucket, because the gradient all-reduce is a collective.  All random draws are functions of
+    (seed, step, GLOBAL row): t and the CFG coin come from the CPU generator (identically seeded on every rank, and
+    always drawn for the whole batch so the generators stay in lock-step whatever the shard sizes), the Gaussian
+    targets from the library's Philox stream keyed by the global row.  The step is therefore the same computation for
+    any number of GPUs (up to the summation order of the all-reduce), and the gradient is that of the mean loss over
+    the GLOBAL batch: rank r's bucket is weighted n_r / n."""
+    from t2ms_amd.sampler import philox_normal
+    n_global = x_1.shape[0]
+    lo, hi = tdist.shard_rows(n_global, rank, world)
+    n = hi - lo
+    u = torch.rand(n_global)                                   # CPU generator: same on every rank
+    drop_text = bool(torch.rand(1) < 0.3)                      # classifier-free guidance coin (train.py:120-122)
     opt.zero_grad()
-    if bool(torch.rand(1) < 0.3):            # classifier-free guidance: drop the text for the whole batch
-        emb = None
-    pred = model(input=x_t, t=t, text_input=emb)
-    loss = backbone.loss(pred, target)
-    loss.backward()
-    allreduce_gradients(model, dist)
+    loss = None
+    if n > 0:
+        emb = emb[lo:hi].float().to(device)
+        if latents is not None and idx is not None:
+            z = latents[idx[lo:hi].to(device)]                                         # pre-encoded rows (latent cache)
+        else:
+            with torch.no_grad():
+                z, _ = model.encoder(x_1[lo:hi].float().to(device).contiguous())      # frozen LA-VAE (train.py:31-33,106)
+        noise = philox_normal(n, z[0].numel(), args.seed ^ 0x7261696E, step_no, lo, device).view_as(z)
+        if args.backbone == "flowmatching":
+            t = (torch.round(u * args.total_step) / args.total_step)[lo:hi].to(device)
+            x_t, x_0 = backbone.create_flow(z, t, x_0=noise)
+            target = z - x_0
+        elif args.backbone == "ddpm":
+            t = torch.floor(u * args.total_step).long()[lo:hi].to(device)
+            target = noise
+            x_t, _ = backbone.q_sample(z, t, target)
+        else:
+            raise ValueError(f"Unsupported backbone type: {args.backbone}")
+        pred = model(input=x_t, t=t, text_input=None if drop_text else emb)
+        loss = backbone.loss(pred, target)
+        loss.backward()
+    elif args.backbone not in ("flowmatching", "ddpm"):
+        raise ValueError(f"Unsupported backbone type: {args.backbone}")
+    if dist is not None:
+        _, loss = allreduce_gradients(model, dist, n_local=n, n_global=n_global,
+                                      loss=loss if loss is not None else torch.zeros((), device=device))
     opt.step()
     return loss
 
@@ -86,11 +101,11 @@ def train(args):
     device = torch.device(args.device)
     rank, _, world = tdist.env_world()
     dist = tdist.init("nccl", device)
+    args.seed = tdist.broadcast_int(dist, args.seed)
     if rank == 0:
         print(f"Training config::\tepoch: {args.epochs}\tsave_path: {args.save_path}\tdevice: {args.device}\tGPUs: {world}")
         os.makedirs(args.save_path, exist_ok=True)
-    torch.manual_seed(args.seed)              # identical shuffles / CFG coin on every rank (CPU generator)
-    torch.cuda.manual_seed(args.seed + 7919 * rank)   # ...but independent t / noise draws per rank (device generator)
+    torch.manual_seed(args.seed)              # identical shuffles / t / CFG coin on every rank (CPU generator)
     dataset, dataloader = loader_provider(args, period="train")
     model = {"DiT": Transformer}.get(args.denoiser)
     if model is None:
@@ -115,7 +130,10 @@ def train(args):
         raise ValueError("training the LA-VAE encoder jointly is outside the accelerated path (frozen codec)")
     if rank == 0:
         print(f"Total learnable parameters: {sum(p.numel() for p in model.parameters() if p.requires_grad)}")
-    opt = T2SAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.0)
+    # every parameter, as the reference builds it (train.py:37): the optimizer state_dict then indexes the same 67
+    # tensors (pos_embed first, the frozen encoder last) and checkpoints interchange; tensors without a gradient
+    # (frozen, or the never-used unpatch.*) are skipped by step() and carry no state, as in torch.optim.AdamW
+    opt = T2SAdamW(model.parameters(), lr=1e-4, weight_decay=0.0)
     sched = lr_scheduler.OneCycleLR(opt, max_lr=1e-4, total_steps=max(1, len(dataloader) * args.epochs))
     loss_list, start_epoch = [], 0
     if args.checkpoint_path:
@@ -131,6 +149,7 @@ def train(args):
             print("latent cache: " + ", ".join(f"L={L}: {tuple(z.shape)}" for L, z in sorted(cache.items())))
     model.train()
     t0, seen = time.time(), 0
+    step_no = len(loss_list)                  # global optimisation-step counter (keys the noise stream; survives resume)
     for epoch in range(start_epoch, args.epochs):
         for batch, data in enumerate(dataloader):
             groups = data if args.mix_train else [data]
@@ -138,9 +157,8 @@ def train(args):
                 x_1, emb = group[1], group[2]
                 idx = group[3] if len(group) > 3 else None
                 loss = train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world,
-                                  cache.get(int(x_1.shape[1])) if cache else None, idx)
-                if loss is None:
-                    continue
+                                  cache.get(int(x_1.shape[1])) if cache else None, idx, step_no)
+                step_no += 1
                 seen += x_1.shape[0]
                 loss_list.append(loss.item())
                 if batch % 100 == 0 and rank == 0:
@@ -183,7 +201,7 @@ def get_args(argv=None):
         args.mix_train = False
     if not torch.cuda.is_available():
         sys.exit("train.py: no GPU visible -- this build runs the HIP path only (no CPU fallback)")
-    _, local_rank, _ = tdist.env_world()
+    local_rank = tdist.local_device_index()
     torch.cuda.set_device(local_rank)
     args.device = f"cuda:{local_rank}"
     if args.mix_train:
