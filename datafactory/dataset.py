@@ -36,10 +36,14 @@ def split_indices(size: int, ratio: float = 0.99, seed: int = 123):
 
 def minmax_scale_columns(a: np.ndarray) -> np.ndarray:
     """sklearn MinMaxScaler().fit_transform semantics (feature_range (0,1), constant columns -> 0)."""
-    lo, hi = a.min(axis=0), a.max(axis=0)
+    # in sklearn's own operation order (scale_ = 1 / range, min_ = 0 - data_min * scale_, X * scale_ + min_), so the
+    # result equals the reference's to the bit rather than to a few ulp of (a - lo) / span
+    a = np.asarray(a, dtype=np.float64)
+    lo, hi = np.nanmin(a, axis=0), np.nanmax(a, axis=0)
     span = hi - lo
-    span[span == 0.0] = 1.0
-    return (a - lo) / span
+    span[span < 10 * np.finfo(span.dtype).eps] = 1.0
+    scale = 1.0 / span
+    return a * scale + (0.0 - lo * scale)
 
 
 class _LatentCacheMixin:

@@ -471,3 +471,96 @@ def eval_mrr(ori, gen, threshold=0.5):
                 break
         scores[i] = 1.0 / rank if rank is not None else 0.0
     return float(np.mean(scores))
+
+
+def eval_crps(ori, gen):
+    """calculate_crps (evaluation.py:51-83): ori (N, L, S), gen (N, L, S, G).  Per sample / series / run: a Gaussian
+    N(mean, std) is fitted to the generated series over TIME (population std, +1e-8 when 0), its CDF at the observed
+    values is compared with the step function 1[obs >= mean], squared and averaged over time; then the mean over
+    runs, series, samples."""
+    import numpy as np
+    from scipy.stats import norm
+    ori, gen = np.asarray(ori), np.asarray(gen)
+    vals = []
+    for i in range(ori.shape[0]):
+        total = 0.0
+        for j in range(ori.shape[2]):
+            per_run = []
+            for k in range(gen.shape[3]):
+                g = gen[i, :, j, k]
+                mean, std = g.mean(), g.std()
+                if std == 0:
+                    std += 1e-8
+                obs = ori[i, :, j]
+                step = np.where(obs < mean, 0, 1)
+                per_run.append(np.mean((step - norm.cdf(obs, loc=mean, scale=std)) ** 2))
+            total += np.mean(per_run)
+        vals.append(total / ori.shape[2])
+    return float(np.asarray(vals).mean())
+
+
+def eval_ed(ori, gen):
+    """calculate_ed (evaluation.py:137-150): mean over samples of the per-series Euclidean distance over time."""
+    import numpy as np
+    ori, gen = np.asarray(ori), np.asarray(gen)
+    d = np.linalg.norm(ori - gen, axis=1)          # (N, S)
+    return float(d.mean(axis=1).mean())
+
+
+def eval_dtw(ori, gen):
+    """calculate_dtw (evaluation.py:152-163) = dtaidistance 2.3 dtw_ndim.distance(s1, s2) per sample, averaged:
+    sqrt of the minimal-cost warping path with squared-Euclidean point costs between the (L, S) sequences, no window,
+    no penalty (third-party, absent here: restated from its published definition -- UNPINNED)."""
+    import numpy as np
+    ori, gen = np.asarray(ori, dtype=np.float64), np.asarray(gen, dtype=np.float64)
+    out = []
+    for a, b in zip(ori, gen):
+        n, m = a.shape[0], b.shape[0]
+        cost = ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1)
+        acc = np.full((n + 1, m + 1), np.inf)
+        acc[0, 0] = 0.0
+        for i in range(1, n + 1):
+            for j in range(1, m + 1):
+                acc[i, j] = cost[i - 1, j - 1] + min(acc[i - 1, j], acc[i, j - 1], acc[i - 1, j - 1])
+        out.append(np.sqrt(acc[n, m]))
+    return float(np.mean(out))
+
+
+def eval_fid(act1, act2):
+    """calculate_fid (evaluation.py:127-135): |mu1 - mu2|^2 + tr(S1 + S2 - 2 sqrtm(S1 S2)) (real part)."""
+    import numpy as np
+    from scipy.linalg import sqrtm
+    act1, act2 = np.asarray(act1), np.asarray(act2)
+    mu1, s1 = act1.mean(axis=0), np.cov(act1, rowvar=False)
+    mu2, s2 = act2.mean(axis=0), np.cov(act2, rowvar=False)
+    covmean = sqrtm(s1.dot(s2))
+    if np.iscomplexobj(covmean):
+        covmean = covmean.real
+    return float(np.sum((mu1 - mu2) ** 2.0) + np.trace(s1 + s2 - 2.0 * covmean))
+
+
+def ts2vec_encode(sd: SD, x: Tensor) -> Tuple[Tensor, Tensor]:
+    """TSEncoder.forward in eval mode with mask 'all_true' (evaluate/ts2vec.py:366-399) and the 'full_series' pooling
+    of TS2Vec.encode (:236-245): x (B, T, C_in) -> (per-step representation (B, T, C_out), max over time (B, C_out)).
+    Time steps holding a NaN are zeroed before AND after input_fc (:367-368,388-389); the encoder is depth+1 ConvBlocks
+    (:421-434: residual [1x1 projector when the widths differ or in the final block] + conv(gelu(conv(gelu(x)))), k=3,
+    dilation 2^i, 'same' padding); dropout is the identity in eval mode."""
+    x = x.clone()
+    ok = ~x.isnan().any(dim=-1)
+    x[~ok] = 0
+    h = F.linear(x, sd["input_fc.weight"], sd["input_fc.bias"])
+    h[~ok] = 0
+    h = h.transpose(1, 2)
+    i = 0
+    while f"feature_extractor.net.{i}.conv1.conv.weight" in sd:
+        p = f"feature_extractor.net.{i}."
+        d = 2 ** i
+        res = h
+        if p + "projector.weight" in sd:
+            res = F.conv1d(h, sd[p + "projector.weight"], sd[p + "projector.bias"])
+        y = F.conv1d(F.gelu(h), sd[p + "conv1.conv.weight"], sd[p + "conv1.conv.bias"], padding=d, dilation=d)
+        y = F.conv1d(F.gelu(y), sd[p + "conv2.conv.weight"], sd[p + "conv2.conv.bias"], padding=d, dilation=d)
+        h = y + res
+        i += 1
+    rep = h.transpose(1, 2)
+    return rep, rep.max(dim=1).values

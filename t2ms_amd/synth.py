@@ -153,3 +153,29 @@ def make_series(seed: int, batch: int, length: int) -> torch.Tensor:
     """MinMax-scaled series stand-in: U[0,1], (batch, length) (dataset.py:81-82)."""
     rs = np.random.RandomState((seed + 11) % (2 ** 32))
     return torch.from_numpy(rs.uniform(0, 1, size=(batch, length)).astype(np.float32))
+
+
+def make_ts2vec_state_dict(seed: int = 2025, input_dims: int = 1, output_dims: int = 100, hidden: int = 64,
+                           depth: int = 10) -> Dict[str, torch.Tensor]:
+    """Seeded weights under the state-dict keys of evaluate/ts2vec.py TSEncoder (:352-364: input_fc, then
+    DilatedConvEncoder = depth blocks hidden->hidden + a final block hidden->output_dims with a 1x1 projector, :421-449).
+    N(0, 1/fan_in) weights, small biases: activations stay O(1) through the 11 residual blocks."""
+    rs = np.random.RandomState(seed)
+
+    def w(*shape):
+        fan_in = int(np.prod(shape[1:]))
+        return torch.from_numpy((rs.randn(*shape) / np.sqrt(fan_in)).astype(np.float32))
+
+    def b(n):
+        return torch.from_numpy((0.05 * rs.randn(n)).astype(np.float32))
+
+    sd = {"input_fc.weight": w(hidden, input_dims), "input_fc.bias": b(hidden)}
+    chans = [hidden] * depth + [output_dims]
+    for i, co in enumerate(chans):
+        ci = chans[i - 1] if i > 0 else hidden
+        p = f"feature_extractor.net.{i}."
+        sd[p + "conv1.conv.weight"], sd[p + "conv1.conv.bias"] = w(co, ci, 3), b(co)
+        sd[p + "conv2.conv.weight"], sd[p + "conv2.conv.bias"] = w(co, co, 3), b(co)
+        if ci != co or i == len(chans) - 1:
+            sd[p + "projector.weight"], sd[p + "projector.bias"] = w(co, ci, 1), b(co)
+    return sd

@@ -86,12 +86,22 @@ def main():
     from t2ms_amd import synth  # seeds -> weights/inputs (shared with the tests)
 
     _install_timm_stub()
+    # The repo's own `model/` (the drop-in mirrors) is a REGULAR package and shadows the reference's namespace package
+    # `model` under any sys.path order: take the repo off the path now that t2ms_amd.synth is imported, and assert
+    # below that what got imported IS the reference.
+    sys.path[:] = [p for p in sys.path if os.path.abspath(p or ".") != REPO]
+    for k in [k for k in sys.modules if k.split(".")[0] == "model"]:
+        del sys.modules[k]
+    os.chdir(HERE)
     sys.path.insert(0, REF)
     from model.backbone.DDPM import DDPM
     from model.backbone.rectified_flow import RectifiedFlow
     from model.denoiser.transformer import Transformer, TimeEmbedding, get_sinusoidal_positional_embeddings
     from model.denoiser.mlp import MLP
     from model.pretrained.vqvae import vqvae
+    for mod in ("model.backbone.DDPM", "model.backbone.rectified_flow", "model.denoiser.transformer", "model.denoiser.mlp",
+                "model.pretrained.vqvae"):
+        assert sys.modules[mod].__file__.startswith(REF + os.sep), (mod, sys.modules[mod].__file__)
 
     def save(name, **arrs):
         arrs = {k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()}

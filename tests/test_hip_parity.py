@@ -653,3 +653,48 @@ def test_two_lane_sampler_is_bitwise_one_lane(dev, vae, math):
     # bad lane counts are refused with the library's error code, not clamped
     assert L.lib().t2s_sampler_set_lanes(s.ptr, 3) != 0 and L.lib().t2s_sampler_set_lanes(s.ptr, -1) != 0
     assert L.lib().t2s_sampler_set_lanes(s.ptr, 2) == 0
+
+
+# ---------------------------------------------------------------- 1000-step chain at the headline schedule
+@pytest.mark.parametrize("math,lanes", [("f32", 1), ("f32", 2), ("bf16x3", 1)])
+def test_chain_1000_steps_reference(dev, vae, math, lanes):
+    """north_star: "outputs matching the reference CPU path within fp32 1e-4 on fixed seeds" for the 1000-step run.
+    infer.py:76-88 at --total_step 1000, cfg 9.0, B=2 through the REFERENCE (tests/golden/chain1000.npz, injected
+    draws regenerated from their seeds) against the fused sampler: hipGraph replayed 1000 times, one and two lanes,
+    f32 MFMA and the fp32-accurate bf16x3 arithmetic.  Tolerance 1e-4 relative to max|x| (1.2e3 at the end: an
+    untrained model does not cancel the schedule's growth), series 1e-4 relative to max|series|."""
+    from model.denoiser.transformer import Transformer
+    from t2ms_amd.sampler import Sampler
+    from _chain1000 import chain1000_inputs, check_chain1000
+    xT, text, noises = chain1000_inputs()
+    m = Transformer()
+    m.load_state_dict(synth.make_dit_state_dict(31337, gain=0.7), strict=True)
+    m = m.to(dev).eval().set_math(math)
+    s = Sampler(m, vae.decoder, "ddpm", 1000, 9.0, 2, 96, dev, use_graph=True, lanes=lanes)
+    lat, series, _ = s.run(text, x_T=xT, noise=noises)
+    check_chain1000(lat.cpu().numpy(), series.cpu().numpy(), {})
+
+
+def test_chain_1000_steps_stepwise_taps(dev, vae):
+    """The same chain through the mirrored CLASSES (Transformer.forward x 2, torch CFG glue, DDPM.p_sample), checked
+    against the reference after loop indices 0, 1, 9, 99, 499, 998, 999: 1e-4 relative to the state's size there."""
+    from model.backbone.DDPM import DDPM
+    from model.denoiser.transformer import Transformer
+    from _chain1000 import CHAIN_TAPS, chain1000_inputs, check_chain1000
+    xT, text, noises = chain1000_inputs()
+    m = Transformer()
+    m.load_state_dict(synth.make_dit_state_dict(31337, gain=0.7), strict=True)
+    m = m.to(dev).eval()
+    ddpm = DDPM(1000, dev)
+    x, textd, nz = xT.to(dev), text.to(dev), noises.to(dev)
+    taps = {}
+    with torch.no_grad():
+        for j in range(1000):
+            t = torch.full((2,), 999 - j, dtype=torch.long, device=dev)
+            u = m(input=x, t=t, text_input=None)
+            c = m(input=x, t=t, text_input=textd)
+            x = ddpm.p_sample(x, u + 9.0 * (c - u), t, eps=nz[j])
+            if j in CHAIN_TAPS:
+                taps[j] = x.cpu().numpy()
+        series, _ = vae.decoder(x, length=96)
+    check_chain1000(x.cpu().numpy(), series.cpu().numpy(), taps)
