@@ -83,12 +83,6 @@ constexpr int NKB = NTOK / 32;                          // 15 key blocks / query
 // re-references (m_ref starts at -inf, so its common-path sum is +inf).
 constexpr float SM_BIG = 1.152921504606847e18f;   // 2^60
 
-#if defined(T2S_EXP) && (T2S_EXP & 32)
-__device__ unsigned long long t2s_dbg[8 * 2 * 4096 * 4];  // 2 regions x (4096 WGs x 4 waves) x 8 words
-#define STAMP(i) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); seg[i] += _t - tprev; tprev = _t; }
-#else
-#define STAMP(i)
-#endif
 
 struct TileState {
     f32x16 negm;   // -m_ref in all 16 registers (C operand of the first QK MFMA)
@@ -171,11 +165,6 @@ __device__ __forceinline__ void attn_packed_body(f32x4* ring, const f32x4* qg, c
 #pragma unroll
     for (int g = 0; g < 4; ++g) kf[g] = ring[g * 64 + lane];
 
-#if defined(T2S_EXP) && (T2S_EXP & 32)
-    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
-    unsigned long long tprev = __builtin_amdgcn_s_memtime();
-    const unsigned long long tstart = tprev;
-#endif
 #pragma unroll 1
     for (int jb = 0; jb < NKB; ++jb) {
         const f32x4* slot = ring + (jb & (ATT_SLOTS - 1)) * ATT_SLOT_F4 + lane;
@@ -193,7 +182,6 @@ __device__ __forceinline__ void attn_packed_body(f32x4* ring, const f32x4* qg, c
                 sta = mfma32(kf[g][e], qa[g][e], sta);
                 if (NT == 2) stb = mfma32(kf[g][e], qb[g][e], stb);
             }
-        STAMP(0)
         float psa = exp_sum(sta);
         float psb = (NT == 2) ? exp_sum(stb) : 0.f;
         const bool stale = !(psa < SM_BIG) || !(psb < SM_BIG);
@@ -203,20 +191,14 @@ __device__ __forceinline__ void attn_packed_body(f32x4* ring, const f32x4* qg, c
         }
         ta.l_lane += psa;
         tb.l_lane += psb;
-        STAMP(1)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int e = 0; e < 4; ++e) oa = mfma32(vf[g][e], sta[4 * g + e], oa);      // PV_A
-        STAMP(2)
         // ---- make block jb+1 visible, keep the DMA two blocks ahead, fetch its K fragments ----
-#if !defined(T2S_EXP) || !(T2S_EXP & 8)
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        STAMP(3)
         __builtin_amdgcn_s_barrier();
-        STAMP(4)
         issue_clamped(jb + 4);   // slot (jb+4)&3 == jb&3: every wave read K(jb), V(jb) before this barrier
-#endif
         {
             const f32x4* nslot = ring + ((jb + 1) & (ATT_SLOTS - 1)) * ATT_SLOT_F4 + lane;
 #pragma unroll
@@ -228,17 +210,8 @@ __device__ __forceinline__ void attn_packed_body(f32x4* ring, const f32x4* qg, c
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ob = mfma32(vf[g][e], stb[4 * g + e], ob);  // PV_B
         }
-        STAMP(5)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the trailing (unused) DMAs
-#if defined(T2S_EXP) && (T2S_EXP & 32)
-    if (lane == 0 && blockIdx.x < 4096) {
-        unsigned long long* d = t2s_dbg + (size_t)(blockIdx.x * 4 + wave) * 8;
-        for (int i = 0; i < 6; ++i) d[i] = seg[i];
-        d[6] = tprev - tstart;
-        d[7] = tstart;
-    }
-#endif
 
     // ---- normalise and store O[query][d]: lane (query i, half) holds d = 8g + 4*half + e ----
     const int seq = bh / NH, head = bh % NH;
@@ -265,9 +238,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_packed_kernel(const float* __
                                                                  const float* __restrict__ vT,
                                                                  float* __restrict__ o, int BH) {
     extern __shared__ __attribute__((aligned(16))) f32x4 ring[];
-#if defined(T2S_EXP) && (T2S_EXP & 32)
-    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
-#endif
     // The two workgroups of a (sequence, head) stream the same K/V: give them ids r and r+8 of a
     // 16-id group so that (round-robin XCD placement) they share an L2.  Speed only.
     const int grp = blockIdx.x >> 4, rr = blockIdx.x & 15;
@@ -298,15 +268,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_packed_kernel(const float* __
         attn_packed_body<2>(ring, qg, kg, vg, og, bh, t0, lane, wave);
     else
         attn_packed_body<1>(ring, qg, kg, vg, og, bh, t0, lane, wave);
-#if defined(T2S_EXP) && (T2S_EXP & 32)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0 && blockIdx.x < 4096) {
-        unsigned long long* d = t2s_dbg + (size_t)(4096 * 4 + blockIdx.x * 4 + wave) * 8;
-        d[0] = t_entry;
-        d[1] = __builtin_amdgcn_s_memtime();
-        d[2] = __builtin_amdgcn_s_getreg(0x1804 | (7 << 11));  // HW_ID low bits: wave, simd, ...
-    }
-#endif
 }
 
 // ------------------------------------------------------------------ persistent variant
@@ -463,20 +424,10 @@ __global__ __launch_bounds__(PERSIST_THREADS, 2) void attn_fwd_persistent_kernel
     const f32x4* kg = reinterpret_cast<const f32x4*>(k);
     const f32x4* vg = reinterpret_cast<const f32x4*>(vT);
     f32x4* og = reinterpret_cast<f32x4*>(o);
-#if defined(T2S_EXP) && (T2S_EXP & 32)
-    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-#endif
     if (wave < 7)
         attn_persistent_body<2>(ring, qg, kg, vg, og, BH, lane, wave);
     else
         attn_persistent_body<1>(ring, qg, kg, vg, og, BH, lane, wave);   // tiles 14 only (15 is void)
-#if defined(T2S_EXP) && (T2S_EXP & 32)
-    if (lane == 0 && blockIdx.x < 512 && wave < 4) {
-        unsigned long long* d = t2s_dbg + (size_t)(blockIdx.x * 4 + wave) * 8;
-        d[0] = __builtin_amdgcn_s_memtime() - c0;
-        d[1] = __builtin_amdgcn_s_memrealtime() - r0;
-    }
-#endif
 }
 
 int launch_attn_packed(const float* q, const float* k, const float* vT, float* o, int BH, hipStream_t st) {
@@ -585,11 +536,6 @@ extern "C" int t2s_attn_fwd(const float* q, const float* k, const float* v, floa
     return T2S_OK;
 }
 
-#if defined(T2S_EXP) && (T2S_EXP & 32)
-extern "C" int t2s_debug_read(unsigned long long* host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(t2s::t2s_dbg), (size_t)n * 8);
-}
-#endif
 
 extern "C" int t2s_attn_fwd_packed(const float* q, const float* k, const float* vT, float* o, int n_seq,
                                    void* stream) {

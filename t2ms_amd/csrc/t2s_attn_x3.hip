@@ -32,19 +32,6 @@ __device__ __forceinline__ float pair_sum(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-#if defined(T2S_EXP) && (T2S_EXP & 512)
-__device__ unsigned long long t2s_x3_dbg[8 * 8 * 256];   // per (workgroup < 256, wave): 8 words
-#define X3_STAMP(i) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); seg[i] += _t - tprev; tprev = _t; }
-#else
-#define X3_STAMP(i)
-#endif
-
-// Timing ablations (results INVALID; tools/exp_x3_ablate.sh): -DT2S_ABL=<bits>  1: no exponentials / split (P planes
-// are reinterpreted score registers), 2: no per-block barrier, 4: K / V^T fragments read from LDS once per head only,
-// 8: no DMA inside the loop, 16: no MFMAs
-#ifndef T2S_ABL
-#define T2S_ABL 0
-#endif
 
 struct TileState {
     f32x16 negm;   // -m_ref in all 16 registers (C operand of the first QK MFMA)
@@ -186,11 +173,6 @@ __device__ __forceinline__ void attn_x3_body(bf16x8* ring, const f32x4* qall, co
     Split3 kf[2];
     load_k(kf, 0);
 
-#if defined(T2S_EXP) && (T2S_EXP & 512)
-    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long tstart = __builtin_amdgcn_s_memtime();
-    unsigned long long tprev = tstart;
-#endif
 #pragma unroll 1
     for (; bh < BH; bh += stride) {
         f32x16 oa, ob;
@@ -206,32 +188,15 @@ __device__ __forceinline__ void attn_x3_body(bf16x8* ring, const f32x4* qall, co
 #pragma unroll 1
         for (int jb = 0; jb < NKB; ++jb, ++gb) {
             // ---- QK^T (MFMA)
-            f32x16 sta = ta.negm;
+            f32x16 sta = scores_from(kf, qa, ta.negm);
             f32x16 stb = tb.negm;
-            if (!(T2S_ABL & 16)) {
-                sta = scores_from(kf, qa, ta.negm);
-                if (NT == 2) stb = scores_from(kf, qb, tb.negm);
-            }
-            X3_STAMP(0)
+            if (NT == 2) stb = scores_from(kf, qb, tb.negm);
             if (STAG) {
                 wait_but(1);
-                X3_STAMP(1)
-                if (!(T2S_ABL & 2)) __builtin_amdgcn_s_barrier();
-                if (!(T2S_ABL & 8)) issue_block(bh, jb + 3, gb + 3);
-                X3_STAMP(4)
+                __builtin_amdgcn_s_barrier();
+                issue_block(bh, jb + 3, gb + 3);
             }
             const bf16x8* slot = ring + (gb & (X3_SLOTS - 1)) * X3_SLOT_UNITS + lane;
-#if T2S_ABL & 4
-            Split3 vf[2] = {kf[1], kf[0]};
-            if (jb == 0) {
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    vf[s].h = slot[(6 + 0 + s) * 64];
-                    vf[s].m = slot[(6 + 2 + s) * 64];
-                    vf[s].l = slot[(6 + 4 + s) * 64];
-                }
-            }
-#else
             Split3 vf[2];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -239,24 +204,6 @@ __device__ __forceinline__ void attn_x3_body(bf16x8* ring, const f32x4* qall, co
                 vf[s].m = slot[(6 + 2 + s) * 64];
                 vf[s].l = slot[(6 + 4 + s) * 64];
             }
-#endif
-#if T2S_ABL & 1
-            // no VALU: the score registers, reinterpreted, stand in for the P planes
-            Split3 pa0, pa1, pb0, pb1;
-            {
-                typedef float f32x4v __attribute__((ext_vector_type(4)));
-                auto cast = [&](const f32x16& c, int o) -> bf16x8 {
-                    const f32x4v v = {c[o], c[o + 1], c[o + 2], c[o + 3]};
-                    return __builtin_bit_cast(bf16x8, v);
-                };
-                pa0.h = cast(sta, 0); pa0.m = cast(sta, 4); pa0.l = cast(sta, 8);
-                pa1.h = cast(sta, 12); pa1.m = cast(sta, 0); pa1.l = cast(sta, 4);
-                pb0.h = cast(stb, 0); pb0.m = cast(stb, 4); pb0.l = cast(stb, 8);
-                pb1.h = cast(stb, 12); pb1.m = cast(stb, 0); pb1.l = cast(stb, 4);
-            }
-            X3_STAMP(2)
-            X3_STAMP(3)
-#else
             // ---- softmax + split of P^T (VALU)
             float psa = exp_sum(sta);
             float psb = (NT == 2) ? exp_sum(stb) : 0.f;
@@ -267,32 +214,22 @@ __device__ __forceinline__ void attn_x3_body(bf16x8* ring, const f32x4* qall, co
             }
             ta.l_lane += psa;
             tb.l_lane += psb;
-            X3_STAMP(2)
             const Split3 pa0 = split3_acc(sta, 0), pa1 = split3_acc(sta, 1);
             Split3 pb0 = pa0, pb1 = pa1;
             if (NT == 2) { pb0 = split3_acc(stb, 0); pb1 = split3_acc(stb, 1); }
-            X3_STAMP(3)
-#endif
             if (!STAG) {
                 wait_but(1);
-                X3_STAMP(1)
-                if (!(T2S_ABL & 2)) __builtin_amdgcn_s_barrier();
-                if (!(T2S_ABL & 8)) issue_block(bh, jb + 3, gb + 3);
-                X3_STAMP(4)
+                __builtin_amdgcn_s_barrier();
+                issue_block(bh, jb + 3, gb + 3);
             }
             // K fragments of the next block (landed: barrier above), read behind the PV MFMAs
-            if (!(T2S_ABL & 4) || jb == NKB - 1) load_k(kf, gb + 1);
+            load_k(kf, gb + 1);
             // ---- PV (MFMA): O^T += V^T P^T
-            if (!(T2S_ABL & 16)) {
-                oa = mfma_x3(vf[0], pa0, oa);
-                oa = mfma_x3(vf[1], pa1, oa);
-                if (NT == 2) {
-                    ob = mfma_x3(vf[0], pb0, ob);
-                    ob = mfma_x3(vf[1], pb1, ob);
-                }
-            } else {
-                oa[0] += (float)pa0.h[0] + (float)pa1.l[1] + (float)vf[0].h[0] + (float)vf[1].l[0];
-                ob[0] += (float)pb0.h[0] + (float)pb1.l[1];
+            oa = mfma_x3(vf[0], pa0, oa);
+            oa = mfma_x3(vf[1], pa1, oa);
+            if (NT == 2) {
+                ob = mfma_x3(vf[0], pb0, ob);
+                ob = mfma_x3(vf[1], pb1, ob);
             }
             // prefetch the next head's Q fragments (a whole block old by the next counted wait)
             if (jb == NKB - 4 && bh + stride < BH) {
@@ -303,7 +240,6 @@ __device__ __forceinline__ void attn_x3_body(bf16x8* ring, const f32x4* qall, co
                     if (NT == 2) qnb[g] = qg[((t0 + 1) * 4 + g) * 64 + lane];
                 }
             }
-            X3_STAMP(5)
         }
         // ---- normalise and store O of this head; swap in the prefetched Q ----
         const int seq = bh / NH, head = bh % NH;
@@ -325,16 +261,8 @@ __device__ __forceinline__ void attn_x3_body(bf16x8* ring, const f32x4* qall, co
         }
         load_q(qna, qa);
         if (NT == 2) load_q(qnb, qb);
-        X3_STAMP(6)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the trailing (unused) DMAs
-#if defined(T2S_EXP) && (T2S_EXP & 512)
-    if (lane == 0 && blockIdx.x < 256) {
-        unsigned long long* d = t2s_x3_dbg + (size_t)(blockIdx.x * 8 + wave) * 8;
-        for (int i = 0; i < 7; ++i) d[i] = seg[i];
-        d[7] = __builtin_amdgcn_s_memtime() - tstart;
-    }
-#endif
 }
 
 // k3 / vT3: split planes (BH*15 tiles x 6 KiB each); q, o: fp32 fragment-major as in t2s_attn_fwd_packed
@@ -472,8 +400,3 @@ extern "C" int t2s_attn_fwd_x3(const float* q, const float* k, const float* v, f
     return rc;
 }
 
-#if defined(T2S_EXP) && (T2S_EXP & 512)
-extern "C" int t2s_debug_read_x3(unsigned long long* host, int n) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(t2s::t2s_x3_dbg), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
-}
-#endif

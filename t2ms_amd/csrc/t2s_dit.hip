@@ -527,11 +527,6 @@ int t2s_dit_timing_end_ex(t2s_dit* h, double* out, int n_classes) {
     return T2S_OK;
 }
 
-#if defined(T2S_EXP) && (T2S_EXP & 64)
-int t2s_debug_read_rows(unsigned long long* host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(t2s::t2s_rows_dbg), (size_t)n * 8);
-}
-#endif
 
 int t2s_dit_read_stream(const t2s_dit* h, float* out, int S, void* stream) {
     T2S_REQUIRE(h && out && S > 0 && S <= h->max_seqs, "t2s_dit_read_stream: bad argument");

@@ -112,12 +112,6 @@ __device__ __forceinline__ void ln_modulate(const f32x16 (&x)[4], f32x16 (&y)[4]
         }
 }
 
-#if defined(T2S_EXP) && (T2S_EXP & 64)
-__device__ unsigned long long t2s_rows_dbg[8 * 8192];
-#define ROWS_STAMP(i) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); if (DO_MLP && DO_QKV) stamp[i] = _t; }
-#else
-#define ROWS_STAMP(i)
-#endif
 
 // NW = waves per workgroup: 4 (two workgroups per CU; the default) or 8 (one; each wave then issues half the
 // weight DMA pieces and the weights cross L2 -> LDS once per 256 tokens).  Measured: 8 is slower, 510 vs 480 us
@@ -129,10 +123,6 @@ constexpr int ROWS_NW = T2S_ROWS_NW;
 template <bool DO_MLP, bool DO_QKV>
 __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(const RowArgs a) {
     extern __shared__ __attribute__((aligned(16))) f32x4 wring[];  // [2][1024]
-#if defined(T2S_EXP) && (T2S_EXP & 64)
-    unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    ROWS_STAMP(0)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: scalar addressing
     const int half = lane >> 5;
@@ -213,7 +203,6 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
                 for (int e = 0; e < 4; ++e) bop[G >> 2][4 * (G & 3) + e] = t[e];
             }
             __syncthreads();  // chunk 0 landed (vmcnt(0) + barrier)
-            ROWS_STAMP(1)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 fill(ci + 1);
@@ -238,7 +227,6 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
                 ++ci;
             }
         }
-        ROWS_STAMP(2)
         // ---------------- x += gate_mlp * (fc2(gelu(fc1(mod(LN(x))))) + b2) ----------------
         f32x4* xw = reinterpret_cast<f32x4*>(a.x) + (size_t)tile * 16 * 64 + lane;
         {
@@ -260,7 +248,6 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-            ROWS_STAMP(3)
 #pragma unroll 1
             for (int c = 0; c < 8; ++c) {  // 32 hidden units per chunk; ci = 4 + 2c (even) here
                 fill(ci + 1);
@@ -376,17 +363,13 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
             }
         }
     }
-    ROWS_STAMP(4)
     if constexpr (DO_QKV) {
         f32x16 xm[4];
         ln_modulate(x, xm, cm + 768, cm + 768 + D, half, 1e-6f);
-        ROWS_STAMP(5)
         const int tile_in_seq = tile - seq * (NTOK / 32);
 #pragma unroll 1
         for (int t = 0; t < 12; ++t) {  // output tile t = which*4 + head
-#if !defined(T2S_EXP) || !(T2S_EXP & 2)
             if (ci + 1 < N_CHUNKS) fill(ci + 1);
-#endif
             const f32x4* wb = wring + (ci & 1) * ROWS_CHUNK_F4 + lane;
             const int which = t >> 2, head = t & 3;
             float* base = which == 0 ? a.q : (which == 1 ? a.k : a.v);
@@ -407,11 +390,7 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc = mfma32(w[e], xm[G >> 2][4 * (G & 3) + e], acc);
                 }
-#if defined(T2S_EXP) && (T2S_EXP & 1)
-                if (active && acc[0] == 1234.5f) {
-#else
                 if (active) {
-#endif
                     {
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
@@ -432,11 +411,7 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc = mfma32(xm[G >> 2][4 * (G & 3) + e], w[e], acc);
                 }
-#if defined(T2S_EXP) && (T2S_EXP & 1)
-                if (active && acc[0] == 1234.5f) {
-#else
                 if (active) {
-#endif
                     {
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
@@ -448,7 +423,6 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
                     }
                 }
             }
-#if !defined(T2S_EXP) || !(T2S_EXP & 2)
             // Counted wait + raw barrier: only the chunk's 4 DMA pieces must have landed; the 4
             // q/k/v stores issued after them (the youngest VM ops) stay in flight across the
             // barrier.  (__syncthreads() would drain them: vmcnt(0).)  Tail waves store nothing.
@@ -457,19 +431,9 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-#endif
             ++ci;
         }
     }
-    ROWS_STAMP(6)
-#if defined(T2S_EXP) && (T2S_EXP & 64)
-    if (DO_MLP && DO_QKV && lane == 0 && blockIdx.x < 2048) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stamp[7] = __builtin_amdgcn_s_memtime();
-        unsigned long long* d = t2s_rows_dbg + (size_t)(blockIdx.x * ROWS_NW + wave) * 8;
-        for (int i = 0; i < 8; ++i) d[i] = stamp[i];
-    }
-#endif
 }
 
 template <bool DO_MLP, bool DO_QKV>

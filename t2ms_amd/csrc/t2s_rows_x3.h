@@ -97,10 +97,6 @@ __device__ __forceinline__ Split3 ldw3(const bf16x8* wb, int pc) {
 template <bool DO_MLP, bool DO_QKV>
 __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const RowArgsX3 a) {
     extern __shared__ __attribute__((aligned(16))) bf16x8 wring3[];  // [2][X3_CHUNK_UNITS]
-#if defined(T2S_EXP) && (T2S_EXP & 64)
-    unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    ROWS_STAMP(0)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
@@ -125,9 +121,6 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
     };
     // each wave DMAs pieces {wave, wave+4, ..., wave+20} of the chunk
     auto fill = [&](int ci) T2S_X3_KERNEL {
-#if defined(T2S_EXP) && (T2S_EXP & 4096)
-        if (ci > 1) return;     // timing experiment: no weight DMA after the first two chunks (results are garbage)
-#endif
         const bf16x8* src = chunk_src(ci) + lane;
         bf16x8* dst = wring3 + (ci & 1) * X3_CHUNK_UNITS;
 #pragma unroll
@@ -186,7 +179,6 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
                 aop[ks] = split3(v);
             }
             wg_sync();  // chunk 0 landed (vmcnt(0) + barrier)
-            ROWS_STAMP(1)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 fill(ci + 1);
@@ -207,7 +199,6 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
                 ++ci;
             }
         }
-        ROWS_STAMP(2)
         // ---------------- x += gate_mlp * (fc2(gelu(fc1(mod(LN(x))))) + b2) ----------------
         f32x4* xw = reinterpret_cast<f32x4*>(a.x) + (size_t)tile * 16 * 64 + lane;
         {
@@ -235,7 +226,6 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
             X3_PRIO(0)
-            ROWS_STAMP(3)
 #pragma unroll 1
             for (int c = 0; c < 8; ++c) {  // 32 hidden units per chunk; ci = 4 + 2c (even) here
                 fill(ci + 1);
@@ -346,7 +336,6 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
             }
         }
     }
-    ROWS_STAMP(4)
     if constexpr (DO_QKV) {
         Split3 xmp[8];      // LayerNorm + modulate output as resident planes
         X3_PRIO(2)
@@ -358,7 +347,6 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
         }
         const int tile_in_seq = tile - seq * (NTOK / 32);
         X3_PRIO(0)
-        ROWS_STAMP(5)
 #pragma unroll 1
         for (int t = 0; t < 12; ++t) {  // output tile t = which*4 + head
             if (ci + 1 < N_CHUNKS) fill(ci + 1);
@@ -427,15 +415,6 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
             ++ci;
         }
     }
-    ROWS_STAMP(6)
-#if defined(T2S_EXP) && (T2S_EXP & 64)
-    if (DO_MLP && DO_QKV && lane == 0 && blockIdx.x < 2048) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stamp[7] = __builtin_amdgcn_s_memtime();
-        unsigned long long* d = t2s_rows_dbg + (size_t)(blockIdx.x * 4 + wave) * 8;
-        for (int i = 0; i < 8; ++i) d[i] = stamp[i];
-    }
-#endif
 }
 
 template <bool DO_MLP, bool DO_QKV>

@@ -16,7 +16,7 @@
 // instruction hides behind the matrix pipe (tools/ubench_valu.hip: 8 MFMA | 48 x v_pk_add_f32: 214 ns together vs
 // 112 / 108 alone; v_fma_f32: 135 vs 114 / 105).  The bf16x3 kernels live on that overlap, so they are compiled
 // without packed fp32 (T2S_X3_KERNEL on the __global__ function; the inlined helpers follow the kernel).
-#if defined(__HIP_DEVICE_COMPILE__) && !(defined(T2S_EXP) && (T2S_EXP & 2048))
+#if defined(__HIP_DEVICE_COMPILE__)
 #define T2S_X3_KERNEL __attribute__((target("no-packed-fp32-ops")))
 #else
 #define T2S_X3_KERNEL
