@@ -260,7 +260,7 @@ def train_bytes_model(batch):
                                         f"(one bf16 (M,128) tensor); tails < 1 %"}
 
 
-TRAIN_UNITS_PER_BLOCK = 88   # round-1 kernel list: forward 32 u + backward 56 u
+TRAIN_UNITS_PER_BLOCK = 83   # forward 27 u (gate / residual adds fused into the consuming GEMM, gelu(u) not saved) + backward 56 u
 
 
 def _train_traffic_from_profile(batch):

@@ -78,7 +78,7 @@ static __global__ void pack16_kernel(const float* __restrict__ W, __bf16* __rest
 }
 
 // ------------------------------------------------------------------------------------------ bgemm
-enum { BPRO_BF16 = 0, BPRO_LN = 1, BPRO_GELU = 2 };
+enum { BPRO_BF16 = 0, BPRO_LN = 1, BPRO_GELU = 2, BPRO_LN_RES = 3 };
 enum { BEPI_BF16 = 0, BEPI_QKV = 1, BEPI_GELUBWD = 2 };
 
 struct BGemmArgs {
@@ -93,6 +93,9 @@ struct BGemmArgs {
     int scale_off;
     __bf16* save_A;       // optional (M,K): the prologue-transformed rows (saved for the weight gradient)
     const __bf16* aux;    // BEPI_GELUBWD: pre-activation u (M,N); out = acc * gelu'(u)
+    const __bf16* res;    // BPRO_LN_RES: the branch output (M,128) whose gated residual add produces this layer's input:
+    int gate_off;         //   x = A + mod[seq][gate_off + c] * res; x is written to x_out (fp32 (M,128)) and then
+    float* x_out;         //   LayerNorm-modulated like BPRO_LN -- the stand-alone gate/residual kernel fused away
     __bf16* q;            // BEPI_QKV destinations, each (S*4, 480, 32)
     __bf16* k;
     __bf16* v;
@@ -110,7 +113,7 @@ constexpr int BG_STAGE_BYTES = 32 * BG_STAGE_STRIDE;     // per wave
 template <int K, int N, int PRO, int EPI>
 __global__ __launch_bounds__(BG_THREADS) void bgemm_kernel(const BGemmArgs a) {
     constexpr int KS = K / 16, NT = N / 32;
-    static_assert(PRO != BPRO_LN || K == 128, "LayerNorm prologue is over d_model = 128");
+    static_assert((PRO != BPRO_LN && PRO != BPRO_LN_RES) || K == 128, "LayerNorm prologue is over d_model = 128");
     extern __shared__ __attribute__((aligned(16))) char wl[];
     bf16x8* wlds = reinterpret_cast<bf16x8*>(wl);
     float* blds = reinterpret_cast<float*>(wl + (size_t)N * K * 2);
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_kernel(const BGemmArgs a) {
 
         // ---- B operand: this lane's token, k = 16s + 8h + 0..7
         bf16x8 xf[KS];
-        if constexpr (PRO == BPRO_LN) {
+        if constexpr (PRO == BPRO_LN || PRO == BPRO_LN_RES) {
             const float* xr = reinterpret_cast<const float*>(a.A) + row * K + 8 * h;
             f32x4 v[KS][2];
             float s = 0.f;
@@ -142,8 +145,37 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_kernel(const BGemmArgs a) {
             for (int t = 0; t < KS; ++t) {
                 v[t][0] = *reinterpret_cast<const f32x4*>(xr + 16 * t);
                 v[t][1] = *reinterpret_cast<const f32x4*>(xr + 16 * t + 4);
-                s += ((v[t][0].x + v[t][0].y) + (v[t][0].z + v[t][0].w)) + ((v[t][1].x + v[t][1].y) + (v[t][1].z + v[t][1].w));
             }
+            if constexpr (PRO == BPRO_LN_RES) {
+                // x = x_prev + gate * branch (the expression of gate_res_kernel, same operation order), written back as
+                // whole 128-byte lines through the wave's staging tile: 32 features (two k-steps) of the 32 rows per pass
+                const __bf16* rr = a.res + row * K + 8 * h;
+                const float* grow = a.mod + (size_t)seq * MODROW + a.gate_off + 8 * h;
+                float* xo = a.x_out + (size_t)tile * 32 * K;
+#pragma unroll
+                for (int t = 0; t < KS; ++t) {
+                    const f32x8 b = unpack8(*reinterpret_cast<const bf16x8*>(rr + 16 * t));
+                    const f32x4 g0 = *reinterpret_cast<const f32x4*>(grow + 16 * t);
+                    const f32x4 g1 = *reinterpret_cast<const f32x4*>(grow + 16 * t + 4);
+                    const f32x4 b0 = {b[0], b[1], b[2], b[3]}, b1 = {b[4], b[5], b[6], b[7]};
+                    v[t][0] = v[t][0] + g0 * b0;
+                    v[t][1] = v[t][1] + g1 * b1;
+                    char* sp = stage + i * BG_STAGE_STRIDE + (t & 1) * 64 + 32 * h;
+                    *reinterpret_cast<f32x4*>(sp) = v[t][0];
+                    *reinterpret_cast<f32x4*>(sp + 16) = v[t][1];
+                    if (t & 1) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int r = 8 * u + (lane >> 3), c16 = lane & 7;
+                            *reinterpret_cast<f32x4*>(xo + (size_t)r * K + (t >> 1) * 32 + c16 * 4) =
+                                *reinterpret_cast<const f32x4*>(stage + r * BG_STAGE_STRIDE + c16 * 16);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < KS; ++t)
+                s += ((v[t][0].x + v[t][0].y) + (v[t][0].z + v[t][0].w)) + ((v[t][1].x + v[t][1].y) + (v[t][1].z + v[t][1].w));
             s += xhalf(s);
             const float mean = s * (1.0f / 128.0f);
             float ss = 0.f;
@@ -274,6 +306,9 @@ inline int launch_bgemm(const BGemmArgs& a, hipStream_t st) {
 // [128 z, +128).  MFMA: D[n][k] = sum_row A[n][row] B[row][k]: both operands are read column-wise
 // out of row-major LDS tiles (64 rows per pass, row stride 320 B: four consecutive rows land in
 // disjoint bank quarters, so the transposed reads are conflict-free).
+// XGELU: the X operand is gelu(X) (the fc2 weight gradient needs gelu(u); applying it to the fetched chunks here
+// costs VALU time the HBM-bound kernel has to spare and saves writing + re-reading a (M,256) tensor per block).
+template <bool XGELU>
 static __global__ __launch_bounds__(256) void wgrad16_kernel(const __bf16* __restrict__ dY, const __bf16* __restrict__ X,
                                                       float* __restrict__ part, float* __restrict__ bpart, int M, int N,
                                                       int K, int rows_per_wg) {
@@ -329,7 +364,14 @@ static __global__ __launch_bounds__(256) void wgrad16_kernel(const __bf16* __res
             const int idx = tid + 256 * u, rr = idx >> 4, c = idx & 15;
             const bool in = rs + rr < r1;
             *reinterpret_cast<bf16x8*>(ys + rr * STR + c * 16) = in ? py[u] : zero8;
-            *reinterpret_cast<bf16x8*>(xs + rr * STR + c * 16) = in ? px[u] : zero8;
+            bf16x8 xv = px[u];
+            if constexpr (XGELU) {
+                f32x8 g = unpack8(xv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = gelu_tanh(g[e]);
+                xv = __builtin_convertvector(g, bf16x8);
+            }
+            *reinterpret_cast<bf16x8*>(xs + rr * STR + c * 16) = in ? xv : zero8;
         }
         __syncthreads();
         if (rs + SLAB < r1) fetch(rs + SLAB);
@@ -412,6 +454,7 @@ inline size_t wgrad16_scratch_floats(int M, int n_cu) {      // worst case over 
     return worst;
 }
 
+template <bool XGELU = false>
 inline int launch_wgrad16(const __bf16* dY, const __bf16* X, float* dW, float* db, int M, int N, int K, float* scratch,
                           size_t scratch_floats, int n_cu, hipStream_t st) {
     if (N % 128 != 0 || K % 128 != 0 || M <= 0) {
@@ -428,7 +471,7 @@ inline int launch_wgrad16(const __bf16* dY, const __bf16* X, float* dW, float* d
     }
     float* part = scratch;
     float* bpart = scratch + part_floats;
-    wgrad16_kernel<<<dim3(gx, gy, gz), 256, 0, st>>>(dY, X, part, bpart, M, N, K, rows_per_wg);
+    wgrad16_kernel<XGELU><<<dim3(gx, gy, gz), 256, 0, st>>>(dY, X, part, bpart, M, N, K, rows_per_wg);
     T2S_LAUNCH_CHECK();
     wgrad16_reduce_kernel<<<dim3(65, gy * gz), 256, 0, st>>>(part, bpart, dW, db, gx, gy, gz, K);
     T2S_LAUNCH_CHECK();

@@ -59,8 +59,11 @@ struct t2s_train_ws {
     bf16x8 *qkv_f16[NBLK], *proj_f16[NBLK], *fc1_f16[NBLK], *fc2_f16[NBLK];
     bf16x8 *qkv_t16[NBLK], *proj_t16[NBLK], *fc1_t16[NBLK], *fc2_t16[NBLK];
     __bf16* act16 = nullptr;
-    __bf16 *a1h[NBLK], *qh[NBLK], *kh[NBLK], *vh[NBLK], *oh[NBLK], *ph[NBLK], *a2h[NBLK], *uh[NBLK], *gh[NBLK], *fh[NBLK];
-    __bf16 *t1h = nullptr, *t2h = nullptr, *t3h = nullptr, *t4h = nullptr;   // (M,128) (M,256) (M,384) (M,128)
+    __bf16 *a1h[NBLK], *qh[NBLK], *kh[NBLK], *vh[NBLK], *oh[NBLK], *ph[NBLK], *a2h[NBLK], *uh[NBLK], *fh[NBLK];
+    __bf16* t4h = nullptr;                                   // (M,128): da2 / do / da1 on the main stream
+    __bf16 *dfh[2], *duh[2], *dph[2], *dqkvh[2];             // weight-gradient operands, double-buffered by block parity
+    hipStream_t side = nullptr;                              // the weight gradients' stream (t2s_dit_train_backward)
+    hipEvent_t ev_op = nullptr, ev_side3[NBLK], ev_side4[NBLK];
     float* wg_scratch = nullptr;   // partial weight-gradient tiles (wgrad16 stage 1 -> stage 2)
     size_t wg_scratch_floats = 0;
     int n_cu = 0;
@@ -701,20 +704,33 @@ int ensure_ws(t2s_dit* h, int S) {
     if (bf) {
         size_t hoff = 0;
         auto htake = [&](size_t n) { size_t o = hoff; hoff += r64(n); return o; };
-        size_t h_a1[NBLK], h_q[NBLK], h_k[NBLK], h_v[NBLK], h_o[NBLK], h_p[NBLK], h_a2[NBLK], h_u[NBLK], h_g[NBLK], h_f[NBLK];
+        size_t h_a1[NBLK], h_q[NBLK], h_k[NBLK], h_v[NBLK], h_o[NBLK], h_p[NBLK], h_a2[NBLK], h_u[NBLK], h_f[NBLK];
         for (int i = 0; i < NBLK; ++i) {
             h_a1[i] = htake(M * D); h_q[i] = htake(M * D); h_k[i] = htake(M * D); h_v[i] = htake(M * D); h_o[i] = htake(M * D);
-            h_p[i] = htake(M * D); h_a2[i] = htake(M * D); h_u[i] = htake(M * 2 * D); h_g[i] = htake(M * 2 * D);
-            h_f[i] = htake(M * D);
+            h_p[i] = htake(M * D); h_a2[i] = htake(M * D); h_u[i] = htake(M * 2 * D); h_f[i] = htake(M * D);
         }
-        const size_t h_t1 = htake(M * D), h_t2 = htake(M * 2 * D), h_t3 = htake(M * 3 * D), h_t4 = htake(M * D);
+        size_t h_df[2], h_du[2], h_dp[2], h_dqkv[2];
+        for (int p = 0; p < 2; ++p) { h_df[p] = htake(M * D); h_du[p] = htake(M * 2 * D); h_dp[p] = htake(M * D); h_dqkv[p] = htake(M * 3 * D); }
+        const size_t h_t4 = htake(M * D);
         if (hipMalloc(&w->act16, hoff * sizeof(__bf16)) != hipSuccess) return fail("bf16 activations", hoff * 2 / 1e6);
         __bf16* H = w->act16;
         for (int i = 0; i < NBLK; ++i) {
             w->a1h[i] = H + h_a1[i]; w->qh[i] = H + h_q[i]; w->kh[i] = H + h_k[i]; w->vh[i] = H + h_v[i]; w->oh[i] = H + h_o[i];
-            w->ph[i] = H + h_p[i]; w->a2h[i] = H + h_a2[i]; w->uh[i] = H + h_u[i]; w->gh[i] = H + h_g[i]; w->fh[i] = H + h_f[i];
+            w->ph[i] = H + h_p[i]; w->a2h[i] = H + h_a2[i]; w->uh[i] = H + h_u[i]; w->fh[i] = H + h_f[i];
         }
-        w->t1h = H + h_t1; w->t2h = H + h_t2; w->t3h = H + h_t3; w->t4h = H + h_t4;
+        for (int p = 0; p < 2; ++p) { w->dfh[p] = H + h_df[p]; w->duh[p] = H + h_du[p]; w->dph[p] = H + h_dp[p]; w->dqkvh[p] = H + h_dqkv[p]; }
+        w->t4h = H + h_t4;
+        bool ok = hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&w->ev_op, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < NBLK && ok; ++i)
+            ok = hipEventCreateWithFlags(&w->ev_side3[i], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&w->ev_side4[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            h->train = w;            // train_free releases whatever was created
+            t2s::train_free(h);
+            set_error("t2s train: side stream / event creation failed");
+            return T2S_E_HIP;
+        }
     }
     h->train = w;
     return T2S_OK;
@@ -742,10 +758,12 @@ __global__ void pack16_multi_kernel(const Pack16Table t) {
 template <int K, int N, int PRO, int EPI>
 int bgemm(const void* A, const bf16x8* Wp, const float* bias, __bf16* out, int M, int n_out, hipStream_t st,
           const float* mod = nullptr, int shift_off = 0, int scale_off = 0, __bf16* save_A = nullptr,
-          const __bf16* aux = nullptr, __bf16* q = nullptr, __bf16* k = nullptr, __bf16* v = nullptr) {
+          const __bf16* aux = nullptr, __bf16* q = nullptr, __bf16* k = nullptr, __bf16* v = nullptr,
+          const __bf16* res = nullptr, int gate_off = 0, float* x_out = nullptr) {
     BGemmArgs a{};
     a.A = A; a.Wp = Wp; a.bias = bias; a.out = out; a.M = M; a.N = n_out; a.mod = mod; a.shift_off = shift_off;
     a.scale_off = scale_off; a.save_A = save_A; a.aux = aux; a.q = q; a.k = k; a.v = v;
+    a.res = res; a.gate_off = gate_off; a.x_out = x_out;
     return launch_bgemm<K, N, PRO, EPI>(a, st);
 }
 
@@ -793,6 +811,12 @@ void train_free(t2s_dit* h) {
     if (w->warena16) (void)hipFree(w->warena16);
     if (w->act) (void)hipFree(w->act);
     if (w->act16) (void)hipFree(w->act16);
+    if (w->side) { (void)hipStreamSynchronize(w->side); (void)hipStreamDestroy(w->side); }
+    if (w->ev_op) (void)hipEventDestroy(w->ev_op);
+    for (int i = 0; i < NBLK; ++i) {
+        if (w->ev_side3[i]) (void)hipEventDestroy(w->ev_side3[i]);
+        if (w->ev_side4[i]) (void)hipEventDestroy(w->ev_side4[i]);
+    }
     delete w;
     h->train = nullptr;
 }
@@ -870,38 +894,41 @@ int t2s_dit_train_forward(t2s_dit* h, const t2s_dit_weights* w, const float* x, 
     }
     for (int i = 0; i < NBLK && bf; ++i) {
         const int base = i * MODW;
-        // a1 = mod(LN1(x_in)) -> bf16; q,k,v = a1 Wqkv^T + b -> bf16 heads
+        // The gate / residual adds have no kernel of their own: the GEMM that consumes a residual-stream tensor forms it
+        // in its prologue (x = x_prev + gate * branch), writes it out for the backward pass and LayerNorm-modulates it.
+        // a1 = mod(LN1(x_in)) -> bf16; q,k,v = a1 Wqkv^T + b -> bf16 heads; for i > 0, x_in[i] = x_mid[i-1] + g2 f[i-1]
         { TimeScope ts(h, TC_TR_GEMM, st);
-        if ((rc = bgemm<128, 384, BPRO_LN, BEPI_QKV>(ws->x_in[i], ws->qkv_f16[i], h->qkv_b[i], nullptr, M, 3 * D, st, ws->mod,
-                                                 base + 0 * D, base + 1 * D, ws->a1h[i], nullptr, ws->qh[i], ws->kh[i], ws->vh[i])))
-            return rc;
+        if (i == 0)
+            rc = bgemm<128, 384, BPRO_LN, BEPI_QKV>(ws->x_in[i], ws->qkv_f16[i], h->qkv_b[i], nullptr, M, 3 * D, st, ws->mod,
+                                                   base + 0 * D, base + 1 * D, ws->a1h[i], nullptr, ws->qh[i], ws->kh[i], ws->vh[i]);
+        else
+            rc = bgemm<128, 384, BPRO_LN_RES, BEPI_QKV>(ws->x_mid[i - 1], ws->qkv_f16[i], h->qkv_b[i], nullptr, M, 3 * D, st, ws->mod,
+                                                       base + 0 * D, base + 1 * D, ws->a1h[i], nullptr, ws->qh[i], ws->kh[i], ws->vh[i],
+                                                       ws->fh[i - 1], (i - 1) * MODW + 5 * D, ws->x_in[i]);
+        if (rc) return rc;
         }
         { TimeScope ts(h, TC_TR_ATTN_FWD, st);
         if ((rc = attn16_train_fwd(ws->qh[i], ws->kh[i], ws->vh[i], ws->oh[i], ws->lse[i], S * NH, st))) return rc;
         }
-        // p = o Wp^T + b; x_mid = x_in + g1 * p.  (Fusing the gate/residual into the GEMM epilogue was measured
-        // slower: the lane-per-token epilogue touches the fp32 stream in 32-byte pieces, 346 vs 82 + 123 us.)
+        // p = o Wp^T + b
         { TimeScope ts(h, TC_TR_GEMM, st);
         if ((rc = bgemm<128, 128, BPRO_BF16, BEPI_BF16>(ws->oh[i], ws->proj_f16[i], h->proj_b[i], ws->ph[i], M, D, st))) return rc;
         }
-        { TimeScope ts(h, TC_TR_ELEM, st);
-        gate_res_kernel<<<(M * 32 + 255) / 256, 256, 0, st>>>(ws->x_in[i], ws->ph[i], ws->mod, base + 2 * D, ws->x_mid[i], M);
-        T2S_LAUNCH_CHECK();
-        }
-        // a2 = mod(LN2(x_mid)); u = a2 W1^T + b1; g = gelu(u) (saved for the fc2 weight gradient); f = g W2^T + b2
+        // x_mid = x_in + g1 * p; a2 = mod(LN2(x_mid)); u = a2 W1^T + b1
         { TimeScope ts(h, TC_TR_GEMM, st);
-        if ((rc = bgemm<128, 256, BPRO_LN, BEPI_BF16>(ws->x_mid[i], ws->fc1_f16[i], h->fc1_b[i], ws->uh[i], M, 2 * D, st, ws->mod,
-                                                  base + 3 * D, base + 4 * D, ws->a2h[i])))
+        if ((rc = bgemm<128, 256, BPRO_LN_RES, BEPI_BF16>(ws->x_in[i], ws->fc1_f16[i], h->fc1_b[i], ws->uh[i], M, 2 * D, st, ws->mod,
+                                                      base + 3 * D, base + 4 * D, ws->a2h[i], nullptr, nullptr, nullptr, nullptr,
+                                                      ws->ph[i], base + 2 * D, ws->x_mid[i])))
             return rc;
         }
+        // f = gelu(u) W2^T + b2   (gelu(u) is not saved: the fc2 weight gradient re-applies it to u)
         { TimeScope ts(h, TC_TR_GEMM, st);
-        if ((rc = bgemm<256, 128, BPRO_GELU, BEPI_BF16>(ws->uh[i], ws->fc2_f16[i], h->fc2_b[i], ws->fh[i], M, D, st, nullptr, 0, 0,
-                                                         ws->gh[i])))
-            return rc;
+        if ((rc = bgemm<256, 128, BPRO_GELU, BEPI_BF16>(ws->uh[i], ws->fc2_f16[i], h->fc2_b[i], ws->fh[i], M, D, st))) return rc;
         }
-        { TimeScope ts(h, TC_TR_ELEM, st);
-        gate_res_kernel<<<(M * 32 + 255) / 256, 256, 0, st>>>(ws->x_mid[i], ws->fh[i], ws->mod, base + 5 * D, ws->x_in[i + 1], M);
-        T2S_LAUNCH_CHECK();
+        if (i == NBLK - 1) {   // the final layer reads the stream itself: x_in[NBLK] = x_mid + g2 * f
+            TimeScope ts(h, TC_TR_ELEM, st);
+            gate_res_kernel<<<(M * 32 + 255) / 256, 256, 0, st>>>(ws->x_mid[i], ws->fh[i], ws->mod, base + 5 * D, ws->x_in[i + 1], M);
+            T2S_LAUNCH_CHECK();
         }
     }
     for (int i = 0; i < NBLK && !bf; ++i) {
@@ -978,63 +1005,91 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
     T2S_LAUNCH_CHECK();
     }
     const bool bf = ws->dtype == T2S_TRAIN_BF16;
+    // bf16 mode: the four weight gradients of a block run on a SIDE stream.  They are off the critical path (their
+    // results are only needed at the end) and HBM-bound, while the attention backward on the main stream is VALU-bound
+    // and leaves more than half of the HBM bandwidth idle: issued next to it they cost (almost) no wall time.
+    // The gradient operands (df, du, dp, dqkv) are double-buffered by block parity; events order the two streams:
+    //   main records ev_op after producing an operand, side waits on it before the weight gradient that reads it;
+    //   side records ev_side3[i] after the first three gradients of block i and ev_side4[i] after the qkv one;
+    //   main waits on them before it overwrites the buffers of the same parity (two blocks later), and joins at the end.
+    hipStream_t sd = bf ? ws->side : nullptr;
+    auto hand_to_side = [&]() -> int {        // everything queued on main so far happens-before what side does next
+        T2S_HIP_CHECK(hipEventRecord(ws->ev_op, st));
+        T2S_HIP_CHECK(hipStreamWaitEvent(sd, ws->ev_op, 0));
+        return T2S_OK;
+    };
     for (int i = NBLK - 1; i >= 0 && bf; --i) {
-        const int base = i * MODW;
+        const int base = i * MODW, par = i & 1;
         const t2s_dit_block_grads& b = g->blk[i];
-        // ---- MLP branch: x_out = x_mid + g2 * f.  t1 = df = g2 * dx and dgate2 come from the previous block's
+        __bf16 *df = ws->dfh[par], *du = ws->duh[par], *dp = ws->dph[par], *dqkv = ws->dqkvh[par];
+        // buffers of this parity were last read by the side stream for block i + 2
+        if (i + 2 < NBLK) T2S_HIP_CHECK(hipStreamWaitEvent(st, ws->ev_side3[i + 2], 0));
+        // ---- MLP branch: x_out = x_mid + g2 * f.  df = g2 * dx and dgate2 come from the previous block's
         // LN1 backward (merged gate backward) except for the last block
         if (i == NBLK - 1) {
             { TimeScope ts(h, TC_TR_ELEM, st);
-            gate_bwd_kernel<<<S, 256, 0, st>>>(ws->dx, ws->fh[i], ws->mod, base + 5 * D, ws->t1h, ws->dmod);
+            gate_bwd_kernel<<<S, 256, 0, st>>>(ws->dx, ws->fh[i], ws->mod, base + 5 * D, df, ws->dmod);
             T2S_LAUNCH_CHECK();
             }
         }
-        { TimeScope ts(h, TC_TR_WGRAD, st);
-        if ((rc = launch_wgrad16(ws->t1h, ws->gh[i], b.fc2_w, b.fc2_b, M, D, 2 * D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
+        if ((rc = hand_to_side())) return rc;
+        { TimeScope ts(h, TC_TR_WGRAD, sd);     // dW2 = df^T gelu(u): gelu applied to the fetched u chunks
+        if ((rc = launch_wgrad16<true>(df, ws->uh[i], b.fc2_w, b.fc2_b, M, D, 2 * D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, sd))) return rc;
         }
         // du = (df W2) * gelu'(u)
         { TimeScope ts(h, TC_TR_GEMM, st);
-        if ((rc = bgemm<128, 256, BPRO_BF16, BEPI_GELUBWD>(ws->t1h, ws->fc2_t16[i], nullptr, ws->t2h, M, 2 * D, st, nullptr, 0, 0,
+        if ((rc = bgemm<128, 256, BPRO_BF16, BEPI_GELUBWD>(df, ws->fc2_t16[i], nullptr, du, M, 2 * D, st, nullptr, 0, 0,
                                                             nullptr, ws->uh[i])))
             return rc;
         }
-        { TimeScope ts(h, TC_TR_WGRAD, st);
-        if ((rc = launch_wgrad16(ws->t2h, ws->a2h[i], b.fc1_w, b.fc1_b, M, 2 * D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
+        if ((rc = hand_to_side())) return rc;
+        { TimeScope ts(h, TC_TR_WGRAD, sd);
+        if ((rc = launch_wgrad16(du, ws->a2h[i], b.fc1_w, b.fc1_b, M, 2 * D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, sd))) return rc;
         }
         // da2 = du W1 -> t4
         { TimeScope ts(h, TC_TR_GEMM, st);
-        if ((rc = bgemm<256, 128, BPRO_BF16, BEPI_BF16>(ws->t2h, ws->fc1_t16[i], nullptr, ws->t4h, M, D, st))) return rc;
+        if ((rc = bgemm<256, 128, BPRO_BF16, BEPI_BF16>(du, ws->fc1_t16[i], nullptr, ws->t4h, M, D, st))) return rc;
         }
-        // LN2 backward into dx, merged with the attention branch's gate backward: t1 = dp = g1 * dx, dgate1
+        // LN2 backward into dx, merged with the attention branch's gate backward: dp = g1 * dx, dgate1
         { TimeScope ts(h, TC_TR_ELEM, st);
         ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t4h, ws->x_mid[i], ws->mod, base + 3 * D, base + 4 * D, ws->dx, ws->dmod,
-                                             ws->ph[i], base + 2 * D, ws->t1h);
+                                             ws->ph[i], base + 2 * D, dp);
         T2S_LAUNCH_CHECK();
         }
         // ---- attention branch: x_mid = x_in + g1 * p
-        { TimeScope ts(h, TC_TR_WGRAD, st);
-        if ((rc = launch_wgrad16(ws->t1h, ws->oh[i], b.proj_w, b.proj_b, M, D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
+        if ((rc = hand_to_side())) return rc;
+        { TimeScope ts(h, TC_TR_WGRAD, sd);
+        if ((rc = launch_wgrad16(dp, ws->oh[i], b.proj_w, b.proj_b, M, D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, sd))) return rc;
         }
+        T2S_HIP_CHECK(hipEventRecord(ws->ev_side3[i], sd));
         { TimeScope ts(h, TC_TR_GEMM, st);
-        if ((rc = bgemm<128, 128, BPRO_BF16, BEPI_BF16>(ws->t1h, ws->proj_t16[i], nullptr, ws->t4h, M, D, st))) return rc;   // do
+        if ((rc = bgemm<128, 128, BPRO_BF16, BEPI_BF16>(dp, ws->proj_t16[i], nullptr, ws->t4h, M, D, st))) return rc;   // do
         }
+        if (i + 2 < NBLK) T2S_HIP_CHECK(hipStreamWaitEvent(st, ws->ev_side4[i + 2], 0));   // dqkv of this parity is free again
         { TimeScope ts(h, TC_TR_ATTN_BWD, st);
-        if ((rc = attn16_bwd(ws->qh[i], ws->kh[i], ws->vh[i], ws->oh[i], ws->t4h, ws->lse[i], ws->dsum, ws->t3h, S * NH, st)))
+        if ((rc = attn16_bwd(ws->qh[i], ws->kh[i], ws->vh[i], ws->oh[i], ws->t4h, ws->lse[i], ws->dsum, dqkv, S * NH, st)))
             return rc;
         }
-        { TimeScope ts(h, TC_TR_WGRAD, st);
-        if ((rc = launch_wgrad16(ws->t3h, ws->a1h[i], b.qkv_w, b.qkv_b, M, 3 * D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
+        if ((rc = hand_to_side())) return rc;
+        { TimeScope ts(h, TC_TR_WGRAD, sd);
+        if ((rc = launch_wgrad16(dqkv, ws->a1h[i], b.qkv_w, b.qkv_b, M, 3 * D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, sd))) return rc;
         }
+        T2S_HIP_CHECK(hipEventRecord(ws->ev_side4[i], sd));
         // da1 = dqkv Wqkv -> t4
         { TimeScope ts(h, TC_TR_GEMM, st);
-        if ((rc = bgemm<384, 128, BPRO_BF16, BEPI_BF16>(ws->t3h, ws->qkv_t16[i], nullptr, ws->t4h, M, D, st))) return rc;
+        if ((rc = bgemm<384, 128, BPRO_BF16, BEPI_BF16>(dqkv, ws->qkv_t16[i], nullptr, ws->t4h, M, D, st))) return rc;
         }
-        // LN1 backward into dx, merged with the gate backward of block i-1's MLP branch
+        // LN1 backward into dx, merged with the gate backward of block i-1's MLP branch (its df has the other parity)
         { TimeScope ts(h, TC_TR_ELEM, st);
         ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t4h, ws->x_in[i], ws->mod, base + 0 * D, base + 1 * D, ws->dx, ws->dmod,
-                                             i > 0 ? ws->fh[i - 1] : (const __bf16*)nullptr, (i - 1) * MODW + 5 * D, ws->t1h);
+                                             i > 0 ? ws->fh[i - 1] : (const __bf16*)nullptr, (i - 1) * MODW + 5 * D,
+                                             ws->dfh[par ^ 1]);
         T2S_LAUNCH_CHECK();
         }
+    }
+    if (bf) {   // join: the tail below reuses the weight-gradient scratch on the main stream
+        T2S_HIP_CHECK(hipEventRecord(ws->ev_op, sd));
+        T2S_HIP_CHECK(hipStreamWaitEvent(st, ws->ev_op, 0));
     }
     for (int i = NBLK - 1; i >= 0 && !bf; --i) {
         const int base = i * MODW;
