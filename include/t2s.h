@@ -238,6 +238,12 @@ int t2s_ddpm_step(float* x, const float* eps_u, const float* eps_c, const float*
  * out of place. */
 int t2s_ddpm_p_sample(const float* xt, const float* eps_hat, const int32_t* t, const float* noise,
                       const float* coef, float* out, int B, void* stream);
+/* The same two class methods on latents of another size, rows of `row_elems` floats (a multiple of 4): the MLP denoiser
+ * of BASELINE configs[0] runs on the (B,64,L/4) pre-interpolation latent, not on (B,64,30). */
+int t2s_ddpm_p_sample_n(const float* xt, const float* eps_hat, const int32_t* t, const float* noise,
+                        const float* coef, float* out, int B, int row_elems, void* stream);
+int t2s_ddpm_q_sample_n(const float* x0, const float* eps, const int32_t* t, const float* sqrt_ab,
+                        const float* sqrt_1mab, float* out, int B, int row_elems, void* stream);
 /* DDPM.loss / RectifiedFlow.loss = F.mse_loss(a, b) (DDPM.py:37-38, rectified_flow.py:13-16):
  * mean over n elements into out[0]; fixed summation order (deterministic). */
 int t2s_mse(const float* a, const float* b, float* out, uint64_t n, void* stream);
@@ -300,6 +306,10 @@ void t2s_vae_destroy(t2s_vae* h);
  * L in {4..128}, L % 4 == 0.  (The host mirror applies torch.squeeze's shape rule.) */
 int t2s_vae_decode(t2s_vae* h, const float* z, float* recon, float* after, int B, int L,
                    void* stream);
+/* Decoder.forward on a latent of another width: z (B,64,latent_w), latent_w <= 32 (F.interpolate at vqvae.py:98 accepts any;
+ * BASELINE configs[0] decodes the (B,64,L/4) latent of the MLP denoiser, for which the interpolation is the identity). */
+int t2s_vae_decode_w(t2s_vae* h, const float* z, float* recon, float* after, int B, int L, int latent_w,
+                     void* stream);
 /* Encoder.forward, vqvae.py:57-71: x (B,L) -> z (B,64,30), before (B,64,L/4) (may be NULL). */
 int t2s_vae_encode(t2s_vae* h, const float* x, float* z, float* before, int B, int L,
                    void* stream);
@@ -371,6 +381,40 @@ int t2s_eval_mse_wape(const float* ori, const float* gen, float* per_sample, flo
  * index; out[0] = mean score. */
 int t2s_eval_mrr(const float* ori, const float* gen, float* sims, float* score, float* out, int n, int len,
                  int runs, float threshold, void* stream);
+
+/* ED: evaluation.py:137-150 (calculate_ed).  ori, gen: (n, L, n_series); per_sample (n): mean over series of the
+ * Euclidean distance over time; out[0] = mean over samples. */
+int t2s_eval_ed(const float* ori, const float* gen, float* per_sample, float* out, int n, int L, int n_series,
+                void* stream);
+/* CRPS: evaluation.py:51-83 (calculate_crps) over the repeated generations evaluation.py:298-314 stacks.
+ * ori (n, L, n_series); gen (runs, n, L, n_series) run-major; per_sample (n); out[0] = mean. */
+int t2s_eval_crps(const float* ori, const float* gen, float* per_sample, float* out, int n, int L, int n_series,
+                  int runs, void* stream);
+/* DTW: evaluation.py:152-163 (calculate_dtw = dtaidistance 2.3 dtw_ndim.distance, no window, no penalty): sqrt of the
+ * minimal warping-path cost with squared-Euclidean point costs between the (L, n_series) sequences of each sample.
+ * per_sample (n); out[0] = mean.  L <= 4096. */
+int t2s_eval_dtw(const float* ori, const float* gen, float* per_sample, float* out, int n, int L, int n_series,
+                 void* stream);
+
+/* TS2Vec encoder of the C-FID metric: evaluate/ts2vec.py:352-399 (TSEncoder.forward, eval mode, mask 'all_true') followed
+ * by the 'full_series' pooling of TS2Vec.encode (:236-245).  Device pointers to the state-dict tensors:
+ * input_fc.{weight (hidden,input_dims),bias}; block i in [0,depth]: feature_extractor.net.i.conv{1,2}.conv.{weight
+ * (co,ci,3),bias} with dilation 2^i (blocks 0..depth-1: hidden -> hidden, block depth: hidden -> output_dims with the 1x1
+ * projector feature_extractor.net.depth.projector.{weight (output_dims,hidden,1),bias}). */
+#define T2S_TS2VEC_MAX_BLOCKS 16
+typedef struct t2s_ts2vec_weights {
+    int input_dims, hidden, output_dims, depth;
+    const float *fc_w, *fc_b;
+    const float* conv1_w[T2S_TS2VEC_MAX_BLOCKS];
+    const float* conv1_b[T2S_TS2VEC_MAX_BLOCKS];
+    const float* conv2_w[T2S_TS2VEC_MAX_BLOCKS];
+    const float* conv2_b[T2S_TS2VEC_MAX_BLOCKS];
+    const float *proj_w, *proj_b;
+} t2s_ts2vec_weights;
+/* x (B, T, input_dims) -> rep (B, T, output_dims) per-step representations (may be NULL) and full (B, output_dims) =
+ * their maximum over time.  Time steps of x holding a NaN are zeroed as the reference does.  3 * max(hidden,
+ * output_dims) * T * 4 bytes must fit in 160 KB of LDS (T <= 128 at the evaluation's 64 / 100 channels). */
+int t2s_ts2vec_encode(const t2s_ts2vec_weights* w, const float* x, float* rep, float* full, int B, int T, void* stream);
 
 #ifdef __cplusplus
 }

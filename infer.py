@@ -46,12 +46,19 @@ def _load_models(args, device):
         vae = torch.load(f"results/saved_pretrained_models/dataset{root}_epoch2000/final_model.pth",
                          map_location=torch.device("cpu"), weights_only=False)     # infer.py:39
     vae = vae.float().to(device).eval()
+    if args.denoiser == "MLP":
+        # BASELINE configs[0] (plumbing): torch mirror of the MLP denoiser on the (B,64,L/4) latent, L = 24
+        from model.denoiser.mlp import MLP
+        model = MLP()
+        if args.random_init:
+            model.load_state_dict(synth.make_mlp_state_dict(args.seed), strict=True)
+        else:
+            model.load_state_dict(torch.load(args.checkpoint_path, map_location="cpu")["model"], strict=False)
+        model.encoder = vae.encoder
+        return model.to(device).eval(), vae
     if args.denoiser != "DiT":
-        raise ValueError("No denoiser found" if args.denoiser != "MLP" else
-                         "the MLP denoiser (config-1 plumbing) is served by t2ms_amd.model.denoiser.mlp; "
-                         "the fused sampler drives the DiT")
+        raise ValueError("No denoiser found")
     model = Transformer().to(device)
-    model.set_math(getattr(args, "math", "f32"))
     model.encoder = vae.encoder                                                     # infer.py:47
     if args.random_init:
         sd = synth.make_dit_state_dict(args.seed)
@@ -60,6 +67,32 @@ def _load_models(args, device):
     else:
         model.load_state_dict(torch.load(args.checkpoint_path, map_location="cpu")["model"])   # infer.py:48
     return model.to(device).eval(), vae
+
+
+def sample_mlp_config1(model, vae, backbone, x_1, embedding, args, device, row0):
+    """The loop of infer.py:76-95 for `--denoiser MLP`, in the runnable form SURVEY.md 8(d) config 1 prescribes: the
+    reference's MLP needs a 6-wide latent (mlp.py:55,67) while its encoder emits 30 (vqvae.py:70), so the diffusion
+    state is the PRE-interpolation latent `before` (B,64,L/4), L = 24, and the decoder's 6 -> 6 interpolation is the
+    identity.  The MLP is a torch module (plumbing); the encoder, the DDPM update and the decoder are
+    the HIP kernels; x_T and the per-step draws come from the library's Philox stream keyed by the global row."""
+    from t2ms_amd.sampler import XT_STREAM, philox_normal
+    if backbone != "ddpm":
+        raise ValueError("config 1 (MLP denoiser) is wired for --backbone ddpm")
+    z_enc, before = model.encoder(x_1.contiguous())
+    B, C, W = before.shape
+    if W != 6:
+        raise ValueError(f"the MLP denoiser needs the 6-wide latent of L = 24 series (mlp.py:67), got L/4 = {W}")
+    from model.backbone.DDPM import DDPM as _DDPM
+    ddpm = _DDPM(args.total_step, device)
+    x_t = philox_normal(B, C * W, args.seed, XT_STREAM, row0, device).view(B, C, W)
+    for j in range(args.total_step):
+        t = torch.full((B,), args.total_step - 1 - j, dtype=torch.long, device=device)
+        u = model(x_t, t, None)
+        c = model(x_t, t, embedding)
+        pred = u + args.cfg_scale * (c - u)                                               # infer.py:87
+        x_t = ddpm.p_sample(x_t, pred, t, eps=philox_normal(B, C * W, args.seed, j, row0, device).view(B, C, W))
+    series, _ = vae.decoder(x_t, length=x_1.shape[-1])
+    return x_t, series.reshape(B, -1), z_enc
 
 
 def infer(args):
@@ -79,6 +112,8 @@ def infer(args):
     torch.manual_seed(args.seed)          # identical loader shuffle on every rank
     dataset, dataloader = loader_provider(args, period="test")
     model, vae = _load_models(args, device)
+    if args.denoiser == "DiT":
+        model.set_math(getattr(args, "math", "f32"))
 
     x1_all, xt_all, lat_dec_all, lat_enc_all, trace = [], [], [], [], None
     sampler, t_start, n_series = None, time.time(), 0
@@ -88,6 +123,21 @@ def infer(args):
             lo, hi = tdist.shard_rows(B, rank, world)
             x_1 = x_1.float().to(device)
             embedding = embedding.float().to(device)
+            if args.denoiser == "MLP":
+                lat, series, z_enc = sample_mlp_config1(model, vae, backbone, x_1[lo:hi], embedding[lo:hi], args, device,
+                                                        n_series + lo)
+                lat = torch.nn.functional.pad(lat, (0, 30 - lat.shape[2]))      # the .npy layout is (N,64,30): zero-padded
+                series = tdist.gather_rows(dist, series, B, rank, world)
+                lat = tdist.gather_rows(dist, lat, B, rank, world)
+                z_enc = tdist.gather_rows(dist, z_enc, B, rank, world)
+                n_series += B
+                if rank == 0:
+                    print(f"Generating {batch}th Batch TS...  ({n_series / (time.time() - t_start):.1f} series/s)")
+                    x1_all.append(x_1.cpu().numpy().squeeze())
+                    xt_all.append(series.cpu().numpy().squeeze())
+                    lat_dec_all.append(lat.cpu().numpy().squeeze())
+                    lat_enc_all.append(z_enc.cpu().numpy().squeeze())
+                continue
             z_enc, _ = model.encoder(x_1[lo:hi].contiguous())                      # infer.py:73-74
             if sampler is None or sampler.batch != hi - lo or sampler.length != L:
                 sampler = Sampler(model, vae.decoder, backbone, args.total_step, args.cfg_scale, hi - lo, L,

@@ -58,6 +58,17 @@ class VaeWeights(C.Structure):
                 ("enc_stack", VaeStackWeights), ("enc_prevq_w", C.c_void_p), ("enc_prevq_b", C.c_void_p)]
 
 
+TS2VEC_MAX_BLOCKS = 16
+
+
+class Ts2vecWeights(C.Structure):
+    _fields_ = [("input_dims", C.c_int), ("hidden", C.c_int), ("output_dims", C.c_int), ("depth", C.c_int),
+                ("fc_w", C.c_void_p), ("fc_b", C.c_void_p),
+                ("conv1_w", C.c_void_p * TS2VEC_MAX_BLOCKS), ("conv1_b", C.c_void_p * TS2VEC_MAX_BLOCKS),
+                ("conv2_w", C.c_void_p * TS2VEC_MAX_BLOCKS), ("conv2_b", C.c_void_p * TS2VEC_MAX_BLOCKS),
+                ("proj_w", C.c_void_p), ("proj_b", C.c_void_p)]
+
+
 class SampleConfig(C.Structure):
     _fields_ = [("mode", C.c_int), ("steps", C.c_int), ("cfg_scale", C.c_float), ("batch", C.c_int),
                 ("length", C.c_int), ("use_graph", C.c_int), ("seed", C.c_uint64), ("row0", C.c_uint32),
@@ -86,6 +97,10 @@ SYMBOLS = {
     "t2s_dit_set_math": (_I, [_VP, _I]),
     "t2s_eval_mse_wape": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP]),
     "t2s_eval_mrr": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _F, _VP]),
+    "t2s_eval_ed": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
+    "t2s_eval_crps": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
+    "t2s_eval_dtw": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
+    "t2s_ts2vec_encode": (_I, [C.POINTER(Ts2vecWeights), _VP, _VP, _VP, _I, _I, _VP]),
     "t2s_attn_fwd_x3": (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_attn_fwd_bf16": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_dit_train_forward": (_I, [_VP, C.POINTER(DitWeights), _VP, _VP, _I, _VP, _VP, _I, _VP]),
@@ -97,6 +112,9 @@ SYMBOLS = {
     "t2s_attn_fwd_packed": (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_ddpm_step": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _F, _U64, _U32, _U32, _I, _VP]),
     "t2s_ddpm_p_sample": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
+    "t2s_ddpm_p_sample_n": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP]),
+    "t2s_ddpm_q_sample_n": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP]),
+    "t2s_vae_decode_w": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
     "t2s_mse": (_I, [_VP, _VP, _VP, _U64, _VP]),
     "t2s_rf_step": (_I, [_VP, _VP, _VP, _F, _F, _I, _VP]),
     "t2s_ddpm_q_sample": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),

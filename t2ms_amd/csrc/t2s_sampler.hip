@@ -133,9 +133,9 @@ __global__ __launch_bounds__(256) void rf_step_kernel(float* __restrict__ x, con
 
 __global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ eps,
                                                        const int32_t* __restrict__ t, const float* __restrict__ sab,
-                                                       const float* __restrict__ s1m, float* __restrict__ out, int B) {
+                                                       const float* __restrict__ s1m, float* __restrict__ out, int B,
+                                                       int QPR) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    constexpr int QPR = LAT / 4;
     if (idx >= B * QPR) return;
     const int tt = t[idx / QPR];
     const f32x4 a = reinterpret_cast<const f32x4*>(x0)[idx];
@@ -157,9 +157,9 @@ __global__ __launch_bounds__(256) void create_flow_kernel(const float* __restric
 // DDPM.p_sample with a per-row timestep (the class API allows t to differ per row), out of place
 __global__ __launch_bounds__(256) void p_sample_rows_kernel(const float* __restrict__ xt, const float* __restrict__ eh,
                                                             const int32_t* __restrict__ t, const float* __restrict__ noise,
-                                                            const float* __restrict__ coef, float* __restrict__ out, int B) {
+                                                            const float* __restrict__ coef, float* __restrict__ out, int B,
+                                                            int QPR) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    constexpr int QPR = LAT / 4;
     if (idx >= B * QPR) return;
     const int tt = t[idx / QPR];
     const float c0 = coef[tt * 3 + 0], c1 = coef[tt * 3 + 1], c2 = coef[tt * 3 + 2];
@@ -271,22 +271,34 @@ extern "C" int t2s_rf_step(float* x, const float* v_u, const float* v_c, float c
     return T2S_OK;
 }
 
+extern "C" int t2s_ddpm_q_sample_n(const float* x0, const float* eps, const int32_t* t, const float* sqrt_ab,
+                                   const float* sqrt_1mab, float* out, int B, int row_elems, void* stream) {
+    T2S_REQUIRE(x0 && eps && t && sqrt_ab && sqrt_1mab && out && B > 0, "t2s_ddpm_q_sample: bad argument");
+    T2S_REQUIRE(row_elems > 0 && row_elems % 4 == 0, "t2s_ddpm_q_sample: row_elems=%d must be a positive multiple of 4", row_elems);
+    const int total = B * (row_elems / 4);
+    q_sample_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(x0, eps, t, sqrt_ab, sqrt_1mab, out, B, row_elems / 4);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
 extern "C" int t2s_ddpm_q_sample(const float* x0, const float* eps, const int32_t* t, const float* sqrt_ab,
                                  const float* sqrt_1mab, float* out, int B, void* stream) {
-    T2S_REQUIRE(x0 && eps && t && sqrt_ab && sqrt_1mab && out && B > 0, "t2s_ddpm_q_sample: bad argument");
-    const int total = B * (LAT / 4);
-    q_sample_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(x0, eps, t, sqrt_ab, sqrt_1mab, out, B);
+    return t2s_ddpm_q_sample_n(x0, eps, t, sqrt_ab, sqrt_1mab, out, B, LAT, stream);
+}
+
+extern "C" int t2s_ddpm_p_sample_n(const float* xt, const float* eps_hat, const int32_t* t, const float* noise,
+                                   const float* coef, float* out, int B, int row_elems, void* stream) {
+    T2S_REQUIRE(xt && eps_hat && t && noise && coef && out && B > 0, "t2s_ddpm_p_sample: bad argument");
+    T2S_REQUIRE(row_elems > 0 && row_elems % 4 == 0, "t2s_ddpm_p_sample: row_elems=%d must be a positive multiple of 4", row_elems);
+    const int total = B * (row_elems / 4);
+    p_sample_rows_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(xt, eps_hat, t, noise, coef, out, B, row_elems / 4);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }
 
 extern "C" int t2s_ddpm_p_sample(const float* xt, const float* eps_hat, const int32_t* t, const float* noise,
                                  const float* coef, float* out, int B, void* stream) {
-    T2S_REQUIRE(xt && eps_hat && t && noise && coef && out && B > 0, "t2s_ddpm_p_sample: bad argument");
-    const int total = B * (LAT / 4);
-    p_sample_rows_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(xt, eps_hat, t, noise, coef, out, B);
-    T2S_LAUNCH_CHECK();
-    return T2S_OK;
+    return t2s_ddpm_p_sample_n(xt, eps_hat, t, noise, coef, out, B, LAT, stream);
 }
 
 extern "C" int t2s_mse(const float* a, const float* b, float* out, uint64_t n, void* stream) {

@@ -60,10 +60,7 @@ struct t2s_train_ws {
     bf16x8 *qkv_t16[NBLK], *proj_t16[NBLK], *fc1_t16[NBLK], *fc2_t16[NBLK];
     __bf16* act16 = nullptr;
     __bf16 *a1h[NBLK], *qh[NBLK], *kh[NBLK], *vh[NBLK], *oh[NBLK], *ph[NBLK], *a2h[NBLK], *uh[NBLK], *fh[NBLK];
-    __bf16* t4h = nullptr;                                   // (M,128): da2 / do / da1 on the main stream
-    __bf16 *dfh[2], *duh[2], *dph[2], *dqkvh[2];             // weight-gradient operands, double-buffered by block parity
-    hipStream_t side = nullptr;                              // the weight gradients' stream (t2s_dit_train_backward)
-    hipEvent_t ev_op = nullptr, ev_side3[NBLK], ev_side4[NBLK];
+    __bf16 *t1h = nullptr, *t2h = nullptr, *t3h = nullptr, *t4h = nullptr;   // (M,128) (M,256) (M,384) (M,128)
     float* wg_scratch = nullptr;   // partial weight-gradient tiles (wgrad16 stage 1 -> stage 2)
     size_t wg_scratch_floats = 0;
     int n_cu = 0;
@@ -709,28 +706,14 @@ int ensure_ws(t2s_dit* h, int S) {
             h_a1[i] = htake(M * D); h_q[i] = htake(M * D); h_k[i] = htake(M * D); h_v[i] = htake(M * D); h_o[i] = htake(M * D);
             h_p[i] = htake(M * D); h_a2[i] = htake(M * D); h_u[i] = htake(M * 2 * D); h_f[i] = htake(M * D);
         }
-        size_t h_df[2], h_du[2], h_dp[2], h_dqkv[2];
-        for (int p = 0; p < 2; ++p) { h_df[p] = htake(M * D); h_du[p] = htake(M * 2 * D); h_dp[p] = htake(M * D); h_dqkv[p] = htake(M * 3 * D); }
-        const size_t h_t4 = htake(M * D);
+        const size_t h_t1 = htake(M * D), h_t2 = htake(M * 2 * D), h_t3 = htake(M * 3 * D), h_t4 = htake(M * D);
         if (hipMalloc(&w->act16, hoff * sizeof(__bf16)) != hipSuccess) return fail("bf16 activations", hoff * 2 / 1e6);
         __bf16* H = w->act16;
         for (int i = 0; i < NBLK; ++i) {
             w->a1h[i] = H + h_a1[i]; w->qh[i] = H + h_q[i]; w->kh[i] = H + h_k[i]; w->vh[i] = H + h_v[i]; w->oh[i] = H + h_o[i];
             w->ph[i] = H + h_p[i]; w->a2h[i] = H + h_a2[i]; w->uh[i] = H + h_u[i]; w->fh[i] = H + h_f[i];
         }
-        for (int p = 0; p < 2; ++p) { w->dfh[p] = H + h_df[p]; w->duh[p] = H + h_du[p]; w->dph[p] = H + h_dp[p]; w->dqkvh[p] = H + h_dqkv[p]; }
-        w->t4h = H + h_t4;
-        bool ok = hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking) == hipSuccess &&
-                  hipEventCreateWithFlags(&w->ev_op, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; i < NBLK && ok; ++i)
-            ok = hipEventCreateWithFlags(&w->ev_side3[i], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&w->ev_side4[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) {
-            h->train = w;            // train_free releases whatever was created
-            t2s::train_free(h);
-            set_error("t2s train: side stream / event creation failed");
-            return T2S_E_HIP;
-        }
+        w->t1h = H + h_t1; w->t2h = H + h_t2; w->t3h = H + h_t3; w->t4h = H + h_t4;
     }
     h->train = w;
     return T2S_OK;
@@ -811,12 +794,6 @@ void train_free(t2s_dit* h) {
     if (w->warena16) (void)hipFree(w->warena16);
     if (w->act) (void)hipFree(w->act);
     if (w->act16) (void)hipFree(w->act16);
-    if (w->side) { (void)hipStreamSynchronize(w->side); (void)hipStreamDestroy(w->side); }
-    if (w->ev_op) (void)hipEventDestroy(w->ev_op);
-    for (int i = 0; i < NBLK; ++i) {
-        if (w->ev_side3[i]) (void)hipEventDestroy(w->ev_side3[i]);
-        if (w->ev_side4[i]) (void)hipEventDestroy(w->ev_side4[i]);
-    }
     delete w;
     h->train = nullptr;
 }
@@ -1005,91 +982,67 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
     T2S_LAUNCH_CHECK();
     }
     const bool bf = ws->dtype == T2S_TRAIN_BF16;
-    // bf16 mode: the four weight gradients of a block run on a SIDE stream.  They are off the critical path (their
-    // results are only needed at the end) and HBM-bound, while the attention backward on the main stream is VALU-bound
-    // and leaves more than half of the HBM bandwidth idle: issued next to it they cost (almost) no wall time.
-    // The gradient operands (df, du, dp, dqkv) are double-buffered by block parity; events order the two streams:
-    //   main records ev_op after producing an operand, side waits on it before the weight gradient that reads it;
-    //   side records ev_side3[i] after the first three gradients of block i and ev_side4[i] after the qkv one;
-    //   main waits on them before it overwrites the buffers of the same parity (two blocks later), and joins at the end.
-    hipStream_t sd = bf ? ws->side : nullptr;
-    auto hand_to_side = [&]() -> int {        // everything queued on main so far happens-before what side does next
-        T2S_HIP_CHECK(hipEventRecord(ws->ev_op, st));
-        T2S_HIP_CHECK(hipStreamWaitEvent(sd, ws->ev_op, 0));
-        return T2S_OK;
-    };
+    // (Measured and dropped in round 2: the four weight gradients of a block on a side stream.  Issued as soon as their
+    // operands exist they only share the HBM bandwidth with the GEMM / LayerNorm kernels they run beside (13.42 ms per step,
+    // the same as in order); issued beside the VALU-bound attention backward they slow it by more than they take alone
+    // (attention backward 3.0 -> 4.4 ms per step, 14.1 ms per step): the attention workgroups fill the CUs.)
     for (int i = NBLK - 1; i >= 0 && bf; --i) {
-        const int base = i * MODW, par = i & 1;
+        const int base = i * MODW;
         const t2s_dit_block_grads& b = g->blk[i];
-        __bf16 *df = ws->dfh[par], *du = ws->duh[par], *dp = ws->dph[par], *dqkv = ws->dqkvh[par];
-        // buffers of this parity were last read by the side stream for block i + 2
-        if (i + 2 < NBLK) T2S_HIP_CHECK(hipStreamWaitEvent(st, ws->ev_side3[i + 2], 0));
-        // ---- MLP branch: x_out = x_mid + g2 * f.  df = g2 * dx and dgate2 come from the previous block's
+        // ---- MLP branch: x_out = x_mid + g2 * f.  t1 = df = g2 * dx and dgate2 come from the previous block's
         // LN1 backward (merged gate backward) except for the last block
         if (i == NBLK - 1) {
             { TimeScope ts(h, TC_TR_ELEM, st);
-            gate_bwd_kernel<<<S, 256, 0, st>>>(ws->dx, ws->fh[i], ws->mod, base + 5 * D, df, ws->dmod);
+            gate_bwd_kernel<<<S, 256, 0, st>>>(ws->dx, ws->fh[i], ws->mod, base + 5 * D, ws->t1h, ws->dmod);
             T2S_LAUNCH_CHECK();
             }
         }
-        if ((rc = hand_to_side())) return rc;
-        { TimeScope ts(h, TC_TR_WGRAD, sd);     // dW2 = df^T gelu(u): gelu applied to the fetched u chunks
-        if ((rc = launch_wgrad16<true>(df, ws->uh[i], b.fc2_w, b.fc2_b, M, D, 2 * D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, sd))) return rc;
+        { TimeScope ts(h, TC_TR_WGRAD, st);     // dW2 = df^T gelu(u): gelu applied to the fetched u chunks (not saved)
+        if ((rc = launch_wgrad16<true>(ws->t1h, ws->uh[i], b.fc2_w, b.fc2_b, M, D, 2 * D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
         }
         // du = (df W2) * gelu'(u)
         { TimeScope ts(h, TC_TR_GEMM, st);
-        if ((rc = bgemm<128, 256, BPRO_BF16, BEPI_GELUBWD>(df, ws->fc2_t16[i], nullptr, du, M, 2 * D, st, nullptr, 0, 0,
+        if ((rc = bgemm<128, 256, BPRO_BF16, BEPI_GELUBWD>(ws->t1h, ws->fc2_t16[i], nullptr, ws->t2h, M, 2 * D, st, nullptr, 0, 0,
                                                             nullptr, ws->uh[i])))
             return rc;
         }
-        if ((rc = hand_to_side())) return rc;
-        { TimeScope ts(h, TC_TR_WGRAD, sd);
-        if ((rc = launch_wgrad16(du, ws->a2h[i], b.fc1_w, b.fc1_b, M, 2 * D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, sd))) return rc;
+        { TimeScope ts(h, TC_TR_WGRAD, st);
+        if ((rc = launch_wgrad16(ws->t2h, ws->a2h[i], b.fc1_w, b.fc1_b, M, 2 * D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
         }
         // da2 = du W1 -> t4
         { TimeScope ts(h, TC_TR_GEMM, st);
-        if ((rc = bgemm<256, 128, BPRO_BF16, BEPI_BF16>(du, ws->fc1_t16[i], nullptr, ws->t4h, M, D, st))) return rc;
+        if ((rc = bgemm<256, 128, BPRO_BF16, BEPI_BF16>(ws->t2h, ws->fc1_t16[i], nullptr, ws->t4h, M, D, st))) return rc;
         }
-        // LN2 backward into dx, merged with the attention branch's gate backward: dp = g1 * dx, dgate1
+        // LN2 backward into dx, merged with the attention branch's gate backward: t1 = dp = g1 * dx, dgate1
         { TimeScope ts(h, TC_TR_ELEM, st);
         ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t4h, ws->x_mid[i], ws->mod, base + 3 * D, base + 4 * D, ws->dx, ws->dmod,
-                                             ws->ph[i], base + 2 * D, dp);
+                                             ws->ph[i], base + 2 * D, ws->t1h);
         T2S_LAUNCH_CHECK();
         }
         // ---- attention branch: x_mid = x_in + g1 * p
-        if ((rc = hand_to_side())) return rc;
-        { TimeScope ts(h, TC_TR_WGRAD, sd);
-        if ((rc = launch_wgrad16(dp, ws->oh[i], b.proj_w, b.proj_b, M, D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, sd))) return rc;
+        { TimeScope ts(h, TC_TR_WGRAD, st);
+        if ((rc = launch_wgrad16(ws->t1h, ws->oh[i], b.proj_w, b.proj_b, M, D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
         }
-        T2S_HIP_CHECK(hipEventRecord(ws->ev_side3[i], sd));
         { TimeScope ts(h, TC_TR_GEMM, st);
-        if ((rc = bgemm<128, 128, BPRO_BF16, BEPI_BF16>(dp, ws->proj_t16[i], nullptr, ws->t4h, M, D, st))) return rc;   // do
+        if ((rc = bgemm<128, 128, BPRO_BF16, BEPI_BF16>(ws->t1h, ws->proj_t16[i], nullptr, ws->t4h, M, D, st))) return rc;   // do
         }
-        if (i + 2 < NBLK) T2S_HIP_CHECK(hipStreamWaitEvent(st, ws->ev_side4[i + 2], 0));   // dqkv of this parity is free again
         { TimeScope ts(h, TC_TR_ATTN_BWD, st);
-        if ((rc = attn16_bwd(ws->qh[i], ws->kh[i], ws->vh[i], ws->oh[i], ws->t4h, ws->lse[i], ws->dsum, dqkv, S * NH, st)))
+        if ((rc = attn16_bwd(ws->qh[i], ws->kh[i], ws->vh[i], ws->oh[i], ws->t4h, ws->lse[i], ws->dsum, ws->t3h, S * NH, st)))
             return rc;
         }
-        if ((rc = hand_to_side())) return rc;
-        { TimeScope ts(h, TC_TR_WGRAD, sd);
-        if ((rc = launch_wgrad16(dqkv, ws->a1h[i], b.qkv_w, b.qkv_b, M, 3 * D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, sd))) return rc;
+        { TimeScope ts(h, TC_TR_WGRAD, st);
+        if ((rc = launch_wgrad16(ws->t3h, ws->a1h[i], b.qkv_w, b.qkv_b, M, 3 * D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
         }
-        T2S_HIP_CHECK(hipEventRecord(ws->ev_side4[i], sd));
         // da1 = dqkv Wqkv -> t4
         { TimeScope ts(h, TC_TR_GEMM, st);
-        if ((rc = bgemm<384, 128, BPRO_BF16, BEPI_BF16>(dqkv, ws->qkv_t16[i], nullptr, ws->t4h, M, D, st))) return rc;
+        if ((rc = bgemm<384, 128, BPRO_BF16, BEPI_BF16>(ws->t3h, ws->qkv_t16[i], nullptr, ws->t4h, M, D, st))) return rc;
         }
-        // LN1 backward into dx, merged with the gate backward of block i-1's MLP branch (its df has the other parity)
+        // LN1 backward into dx, merged with the gate backward of block i-1's MLP branch
         { TimeScope ts(h, TC_TR_ELEM, st);
         ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t4h, ws->x_in[i], ws->mod, base + 0 * D, base + 1 * D, ws->dx, ws->dmod,
-                                             i > 0 ? ws->fh[i - 1] : (const __bf16*)nullptr, (i - 1) * MODW + 5 * D,
-                                             ws->dfh[par ^ 1]);
+                                             i > 0 ? ws->fh[i - 1] : (const __bf16*)nullptr, (i - 1) * MODW + 5 * D, ws->t1h);
         T2S_LAUNCH_CHECK();
         }
-    }
-    if (bf) {   // join: the tail below reuses the weight-gradient scratch on the main stream
-        T2S_HIP_CHECK(hipEventRecord(ws->ev_op, sd));
-        T2S_HIP_CHECK(hipStreamWaitEvent(st, ws->ev_op, 0));
     }
     for (int i = NBLK - 1; i >= 0 && !bf; --i) {
         const int base = i * MODW;

@@ -152,20 +152,20 @@ constexpr int VAE_LDS_FLOATS = 2 * VAE_CMAX * LD + 128 * 4 + 64 * 2 * VAE_TMAX;
 __global__ __launch_bounds__(VAE_THREADS) void vae_decode_kernel(const VaeDev w,
                                                                  const float* __restrict__ z,
                                                                  float* __restrict__ recon,
-                                                                 float* __restrict__ after, int L) {
+                                                                 float* __restrict__ after, int L, int W) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* bufA = smem;                   // [<=256][LD]
     float* bufB = smem + VAE_CMAX * LD;   // [<=256][LD]
     float* wide = bufB + VAE_CMAX * LD;   // [hidden/2][2T] for the first transposed conv
     const int b = blockIdx.x;
     const int T = L / 4;
-    // latent (64,30) -> bufB (row stride LD covers 30 <= 32)
-    for (int o = threadIdx.x; o < w.emb * LATW; o += VAE_THREADS) {
-        const int c = o / LATW, t = o - c * LATW;
-        bufB[c * LD + t] = z[(size_t)b * w.emb * LATW + o];
+    // latent (64,W) -> bufB (row stride LD covers W <= 32; W = 30 on the DiT path, L/4 on the MLP-denoiser path)
+    for (int o = threadIdx.x; o < w.emb * W; o += VAE_THREADS) {
+        const int c = o / W, t = o - c * W;
+        bufB[c * LD + t] = z[(size_t)b * w.emb * W + o];
     }
     __syncthreads();
-    interp_linear_ac(bufB, w.emb, LATW, LD, bufA, T, LD);
+    interp_linear_ac(bufB, w.emb, W, LD, bufA, T, LD);
     __syncthreads();
     if (after) {
         for (int o = threadIdx.x; o < w.emb * T; o += VAE_THREADS) {
@@ -362,7 +362,19 @@ extern "C" int t2s_vae_decode(t2s_vae* h, const float* z, float* recon, float* a
     T2S_REQUIRE(h->has_decoder, "t2s_vae_decode: handle was created without decoder weights");
     T2S_REQUIRE(B > 0, "t2s_vae_decode: B=%d", B);
     T2S_REQUIRE(L >= 4 && L % 4 == 0 && L / 4 <= VAE_TMAX, "t2s_vae_decode: L=%d unsupported (multiple of 4, <= 128)", L);
-    vae_decode_kernel<<<B, VAE_THREADS, VAE_LDS_FLOATS * 4, (hipStream_t)stream>>>(h->dev, z, recon, after, L);
+    vae_decode_kernel<<<B, VAE_THREADS, VAE_LDS_FLOATS * 4, (hipStream_t)stream>>>(h->dev, z, recon, after, L, LATW);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+extern "C" int t2s_vae_decode_w(t2s_vae* h, const float* z, float* recon, float* after, int B, int L, int latent_w,
+                                void* stream) {
+    T2S_REQUIRE(h && z && recon, "t2s_vae_decode_w: NULL argument");
+    T2S_REQUIRE(h->has_decoder, "t2s_vae_decode_w: handle was created without decoder weights");
+    T2S_REQUIRE(B > 0, "t2s_vae_decode_w: B=%d", B);
+    T2S_REQUIRE(L >= 4 && L % 4 == 0 && L / 4 <= VAE_TMAX, "t2s_vae_decode_w: L=%d unsupported (multiple of 4, <= 128)", L);
+    T2S_REQUIRE(latent_w >= 1 && latent_w <= VAE_TMAX, "t2s_vae_decode_w: latent width %d unsupported (1..%d)", latent_w, VAE_TMAX);
+    vae_decode_kernel<<<B, VAE_THREADS, VAE_LDS_FLOATS * 4, (hipStream_t)stream>>>(h->dev, z, recon, after, L, latent_w);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }

@@ -47,8 +47,9 @@ class DDPM:
     def _rows(self, x: torch.Tensor, t: torch.Tensor):
         if not x.is_cuda:
             raise L.T2SError("DDPM: tensors must live on a GPU; the HIP path has no CPU fallback")
-        if x.dim() != 3 or x.shape[1] * x.shape[2] != L.LAT:
-            raise L.T2SError(f"DDPM: latent must be (B,64,30), got {tuple(x.shape)}")
+        if x.dim() != 3 or (x.shape[1] * x.shape[2]) % 4 != 0:
+            raise L.T2SError(f"DDPM: latent must be (B,C,W) with C*W a multiple of 4 ((B,64,30) on the DiT path), "
+                             f"got {tuple(x.shape)}")
         ti = t.to(device=x.device, dtype=torch.int32).contiguous()
         if ti.shape != (x.shape[0],):
             raise L.T2SError(f"DDPM: t must be ({x.shape[0]},), got {tuple(ti.shape)}")
@@ -69,10 +70,10 @@ class DDPM:
         x0c, epsc = L.as_f32(x0), L.as_f32(eps)
         out = torch.empty_like(x0c)
         with torch.cuda.device(x0.device):
-            L.check(L.lib().t2s_ddpm_q_sample(L.dev_ptr(x0c, "x0"), L.dev_ptr(epsc, "eps"),
-                                              L.dev_ptr(ti, "t", torch.int32), L.dev_ptr(self._sqrt_ab),
-                                              L.dev_ptr(self._sqrt_1mab), L.dev_ptr(out), x0.shape[0],
-                                              L.stream_ptr(x0.device)), "t2s_ddpm_q_sample")
+            L.check(L.lib().t2s_ddpm_q_sample_n(L.dev_ptr(x0c, "x0"), L.dev_ptr(epsc, "eps"),
+                                                L.dev_ptr(ti, "t", torch.int32), L.dev_ptr(self._sqrt_ab),
+                                                L.dev_ptr(self._sqrt_1mab), L.dev_ptr(out), x0.shape[0],
+                                                x0.shape[1] * x0.shape[2], L.stream_ptr(x0.device)), "t2s_ddpm_q_sample")
         return out, eps
 
     def p_sample(self, xt: torch.Tensor, n_xt: torch.Tensor, t: torch.Tensor, eps: Optional[torch.Tensor] = None):
@@ -84,10 +85,10 @@ class DDPM:
         x, e, z = L.as_f32(xt), L.as_f32(n_xt), L.as_f32(eps)
         out = torch.empty_like(x)
         with torch.cuda.device(xt.device):
-            L.check(L.lib().t2s_ddpm_p_sample(L.dev_ptr(x, "xt"), L.dev_ptr(e, "n_xt"),
-                                              L.dev_ptr(ti, "t", torch.int32), L.dev_ptr(z, "eps"),
-                                              L.dev_ptr(self._coef), L.dev_ptr(out), xt.shape[0],
-                                              L.stream_ptr(xt.device)), "t2s_ddpm_p_sample")
+            L.check(L.lib().t2s_ddpm_p_sample_n(L.dev_ptr(x, "xt"), L.dev_ptr(e, "n_xt"),
+                                                L.dev_ptr(ti, "t", torch.int32), L.dev_ptr(z, "eps"),
+                                                L.dev_ptr(self._coef), L.dev_ptr(out), xt.shape[0],
+                                                xt.shape[1] * xt.shape[2], L.stream_ptr(xt.device)), "t2s_ddpm_p_sample")
         return out
 
     def loss(self, n_gt: torch.Tensor, n_xt: torch.Tensor):

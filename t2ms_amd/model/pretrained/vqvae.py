@@ -169,19 +169,22 @@ class Decoder(_Codec):
         return w, keep
 
     def forward(self, inputs, length):
-        """z (B,64,30) -> (recon, after (B,64,L/4)); vqvae.py:97-105.  ``recon`` follows
-        torch.squeeze's shape rule: (B,L), or (L,) when B == 1."""
+        """z (B,64,W) -> (recon, after (B,64,L/4)); vqvae.py:97-105 (W = 30 on the DiT path; any W <= 32, e.g. the L/4
+        of the MLP-denoiser path, as F.interpolate accepts).  ``recon`` follows torch.squeeze's shape rule: (B,L), or
+        (L,) when B == 1."""
         if not inputs.is_cuda:
             raise L.T2SError("Decoder.forward: input must live on a GPU; the HIP path has no CPU fallback")
         z = L.as_f32(inputs)
+        if z.dim() != 3 or not 1 <= z.shape[2] <= 32:
+            raise L.T2SError(f"Decoder.forward: latent must be (B,C,W) with W <= 32, got {tuple(z.shape)}")
         B, dev = z.shape[0], z.device
         Ln = int(length / 4) * 4
         with torch.cuda.device(dev):
             h = self._handle(dev)
             recon = torch.empty(B, Ln, device=dev, dtype=torch.float32)
             after = torch.empty(B, z.shape[1], Ln // 4, device=dev, dtype=torch.float32)
-            L.check(L.lib().t2s_vae_decode(h, L.dev_ptr(z, "inputs"), L.dev_ptr(recon), L.dev_ptr(after), B, Ln,
-                                           L.stream_ptr(dev)), "t2s_vae_decode")
+            L.check(L.lib().t2s_vae_decode_w(h, L.dev_ptr(z, "inputs"), L.dev_ptr(recon), L.dev_ptr(after), B, Ln,
+                                             z.shape[2], L.stream_ptr(dev)), "t2s_vae_decode")
         return torch.squeeze(recon.unsqueeze(1)), after
 
 

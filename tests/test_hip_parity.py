@@ -698,3 +698,63 @@ def test_chain_1000_steps_stepwise_taps(dev, vae):
                 taps[j] = x.cpu().numpy()
         series, _ = vae.decoder(x, length=96)
     check_chain1000(x.cpu().numpy(), series.cpu().numpy(), taps)
+
+
+# ---------------------------------------------------------------- evaluation metrics against the reference's own functions
+def test_eval_ed_crps_mse_wape_mrr_reference_fixture(golden_dir, dev):
+    """t2s_eval_* against evaluation.py's calculate_mse / _wape / _ed / _crps / _mrr as the generator ran them
+    (tests/golden/metrics.npz: an all-zero row, negated runs, an exact copy at run 7)."""
+    from t2ms_amd import metrics as M
+    g = _load(golden_dir, "metrics")
+    ori, gen, runs = g["ori"], g["gen"], g["runs"]
+    mse, wape, _ = M.mse_wape(ori, gen)
+    np.testing.assert_allclose(mse, float(g["mse"]), rtol=2e-6)
+    np.testing.assert_allclose(wape, float(g["wape"]), rtol=2e-6)
+    np.testing.assert_allclose(M.ed(ori, gen)[0], float(g["ed"]), rtol=2e-6)
+    np.testing.assert_allclose(M.crps(ori, runs)[0], float(g["crps"]), rtol=1e-5)
+    m, sims, _ = M.mrr(ori, runs)
+    assert abs(m - float(g["mrr"])) < 1e-6
+    np.testing.assert_allclose(sims.numpy(), g["sims"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(M.fid(g["fid_act1"], g["fid_act2"]), float(g["fid"]), rtol=1e-9)
+
+
+def test_eval_dtw_vs_oracle(dev):
+    """t2s_eval_dtw against the oracle's restatement of dtaidistance's dtw_ndim.distance (UNPINNED: third party, absent)
+    on (N, L, n_series) arrays with L in {24, 96} and 1 or 3 series, plus the known answers (shift-invariance of a step)."""
+    from t2ms_amd import metrics as M
+    rs = np.random.RandomState(5)
+    for L_, S in ((24, 1), (96, 1), (40, 3)):
+        a = rs.uniform(0, 1, size=(6, L_, S)).astype(np.float32)
+        b = (a + 0.3 * rs.randn(6, L_, S)).astype(np.float32)
+        got, per = M.dtw(a, b)
+        np.testing.assert_allclose(got, O.eval_dtw(a, b), rtol=1e-5)
+        assert per.shape == (6,)
+    a = np.zeros((1, 8, 1), np.float32)
+    a[0, 3:, 0] = 1.0
+    b = np.zeros((1, 8, 1), np.float32)
+    b[0, 5:, 0] = 1.0
+    assert M.dtw(a, b)[0] == 0.0
+
+
+def test_ts2vec_encoder_reference_fixture(golden_dir, dev):
+    """t2s_ts2vec_encode against TSEncoder.forward of the reference (tests/golden/ts2vec.npz, seeded weights, a NaN
+    stretch in one series): per-step representations and the full-series max pooling, 1e-4 relative to max|rep|;
+    C-FID of two sets through the same encoder equals the oracle's."""
+    from t2ms_amd import metrics as M
+    g = _load(golden_dir, "ts2vec")
+    sd = synth.make_ts2vec_state_dict(2025)
+    enc = M.TS2VecEncoder(sd, dev)
+    x = torch.from_numpy(g["x"])
+    rep = enc.encode(x, encoding_window=None).cpu().numpy()
+    full = enc.encode(x).cpu().numpy()
+    scale = float(np.abs(g["rep"]).max())
+    assert rep.shape == (5, 96, 100) and full.shape == (5, 100)
+    assert float(np.abs(rep[:, ::6] - g["rep"]).max()) <= TOL * scale
+    assert float(np.abs(full - g["full_series"]).max()) <= TOL * scale
+    rs = np.random.RandomState(3)
+    a = rs.uniform(0, 1, size=(40, 24, 1)).astype(np.float32)
+    b = (a + 0.2 * rs.randn(40, 24, 1)).astype(np.float32)
+    with torch.no_grad():
+        ra = O.ts2vec_encode(sd, torch.from_numpy(a))[1].numpy()
+        rb = O.ts2vec_encode(sd, torch.from_numpy(b))[1].numpy()
+    np.testing.assert_allclose(M.cfid(a, b, enc), O.eval_fid(ra, rb), rtol=2e-3)

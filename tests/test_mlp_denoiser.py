@@ -75,3 +75,46 @@ def test_latent_cache_plumbing_cpu():
     assert groups[1][3].tolist() == [2] and groups[2][3].tolist() == [5, 9]
     with pytest.raises(ValueError):
         parts[0].attach_latents(torch.zeros(3, 4))
+
+
+@pytest.mark.gpu
+def test_config1_end_to_end_through_infer_driver(tmp_path, monkeypatch):
+    """BASELINE configs[0] wired end to end: `infer.py --denoiser MLP` on L=24 series, B=32,
+    50-step DDPM with CFG -- HIP encoder -> `before` (32,64,6) -> torch MLP denoiser + HIP DDPM update on the 6-wide
+    latent -> HIP Decoder(length=24) -- against the CPU oracle run on the same rows, draws (Philox restated in numpy)
+    and weights; the four .npy files keep the reference layout."""
+    import infer as drv
+    from datafactory.dataset import SyntheticT2SDataset
+    assert torch.cuda.is_available()
+    monkeypatch.chdir(tmp_path)
+    save = str(tmp_path / "results")
+    steps, cfg, B, seed = 50, 7.0, 32, 3
+    drv.main(["--dataset_name", "ETTh1_24", "--backbone", "ddpm", "--denoiser", "MLP", "--total_step", str(steps),
+              "--cfg_scale", str(cfg), "--batch_size", str(B), "--save_path", save, "--synthetic", "40", "--random_init",
+              "--seed", str(seed)])
+    out = os.path.join(save, "generation", f"ddpm_MLP_ETTh1_24_{cfg}_{steps}")
+    x1 = np.load(os.path.join(out, "x_1.npy"))
+    xt = np.load(os.path.join(out, "x_t.npy"))
+    lat = np.load(os.path.join(out, "x_t_latent_dec_array.npy"))
+    enc = np.load(os.path.join(out, "x_t_latent_enc_array.npy"))
+    assert x1.shape == xt.shape == (B, 24, 1) and lat.shape == enc.shape == (B, 64, 30)
+    # the rows the (shuffled) loader served, and their embeddings
+    ds = SyntheticT2SDataset(40, 24)
+    rows = [int(np.argmin(np.abs(ds.samples - x1[i, :, 0][None]).sum(axis=1))) for i in range(B)]
+    assert len(set(rows)) == B and np.allclose(ds.samples[rows], x1[:, :, 0], atol=1e-6)
+    text = torch.from_numpy(ds.embedding[rows]).float()
+    msd, vsd = synth.make_mlp_state_dict(seed), synth.make_vae_state_dict(seed)
+    tab = O.ddpm_tables(steps)
+    with torch.no_grad():
+        z_ref, before = O.vae_encode(vsd, torch.from_numpy(x1[:, :, 0]))
+        x = torch.from_numpy(O.device_normal(seed, 0xFFFFFFFF, 0, B, 384)).view(B, 64, 6)
+        for j in range(steps):
+            t = torch.full((B,), steps - 1 - j, dtype=torch.long)
+            u = O.mlp_denoiser_forward(msd, x, t, None)
+            c = O.mlp_denoiser_forward(msd, x, t, text)
+            x = O.ddpm_p_sample(tab, x, u + cfg * (c - u), t, torch.from_numpy(O.device_normal(seed, j, 0, B, 384)).view(B, 64, 6))
+        series, _ = O.vae_decode(vsd, x, 24)
+    scale = max(1.0, float(x.abs().max()))
+    assert float(np.abs(enc - z_ref.numpy()).max()) < 1e-5
+    assert float(np.abs(lat[:, :, :6] - x.numpy()).max()) < 1e-4 * scale and float(np.abs(lat[:, :, 6:]).max()) == 0.0
+    assert float(np.abs(xt[:, :, 0] - series.numpy()).max()) < 1e-4 * scale
