@@ -286,19 +286,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dY
     }
 }
 
-// Rows per workgroup of the two "tail" backward kernels below: their small gradients are reduced
-// in the workgroup and flushed with one set of atomics, so fewer, longer workgroups mean
-// proportionally less same-address atomic traffic (64 rows per workgroup cost 1.1-1.7 ms at
-// B=1152, almost all of it atomics).
+// Rows per workgroup of the two "tail" backward kernels below.  Their small gradients are reduced in the workgroup and
+// written as ONE partial row per workgroup (FINAL_COLS / PATCH_COLS floats); tail_reduce_kernel then adds the partial
+// rows in workgroup order -- deterministic, and without the ~800 K same-address fp32 atomics the round-1 kernels
+// flushed with (they were most of these kernels' 0.3 ms each at B=1152).
 constexpr int TAIL_ROWS = 512;
+constexpr int FINAL_COLS = 772;   // ln.weight 128 | ln.bias 128 | linear_emb_to_patch.weight 4x128 | .bias 4
+constexpr int PATCH_COLS = 660;   // patch_emb.weight 128x4 | .bias 128 | conv.weight 16 | conv.bias 4
+
+struct TailDst { float* p[4]; int n[4]; };   // consecutive column ranges of a partial row -> gradient tensors
+__global__ __launch_bounds__(256) void tail_reduce_kernel(const float* __restrict__ part, int n_wg, int cols, const TailDst d) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int w = 0; w < n_wg; ++w) s += part[(size_t)w * cols + c];
+    int off = c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (off < d.n[i]) { d.p[i][off] = s; return; }
+        off -= d.n[i];
+    }
+}
 
 // final layer backward (transformer.py:182-191): dout (S,64,30) -> dx (M,128) and grads of
 // ln.weight, ln.bias, linear_emb_to_patch.{weight,bias}.  32 lanes per token row.
 __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout,
                                                         const float* __restrict__ lng, const float* __restrict__ lnb,
                                                         const float* __restrict__ ow, float* __restrict__ dx,
-                                                        float* __restrict__ g_lnw, float* __restrict__ g_lnb,
-                                                        float* __restrict__ g_ow, float* __restrict__ g_ob, int M) {
+                                                        float* __restrict__ part, int M) {
     __shared__ f32x4 red[6][8][32];
     __shared__ float redb[8][4];
     const int c4 = threadIdx.x & 31, rg = threadIdx.x >> 5;
@@ -310,9 +325,12 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
     f32x4 a_g = {0, 0, 0, 0}, a_b = {0, 0, 0, 0}, a_w[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     float a_ob[4] = {0.f, 0.f, 0.f, 0.f};
     const int row0 = blockIdx.x * TAIL_ROWS;
-    for (int rr = rg; rr < TAIL_ROWS; rr += 8) {
-        const int row = row0 + rr;
-        if (row >= M) break;   // uniform per 32-lane group; shuffles below stay inside the group
+#pragma unroll 4
+    for (int it = 0; it < TAIL_ROWS / 8; ++it) {            // 4 rows of a wave in flight: the shuffle chains overlap
+        const int rr = rg + 8 * it;
+        const bool valid = row0 + rr < M;                  // rows past the end: clamped, their contributions masked
+        const int row = valid ? row0 + rr : M - 1;
+        const float keep = valid ? 1.f : 0.f;
         const size_t idx = (size_t)row * 32 + c4;
         const f32x4 xv = reinterpret_cast<const f32x4*>(x)[idx];
         float s = (xv.x + xv.y) + (xv.z + xv.w);
@@ -332,7 +350,7 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
         float dl[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-            dl[p] = dout[(size_t)seq * LAT + (2 * ww + (p & 1)) * LATW + 2 * hh + (p >> 1)];
+            dl[p] = keep * dout[(size_t)seq * LAT + (2 * ww + (p & 1)) * LATW + 2 * hh + (p >> 1)];
         f32x4 dy = {0, 0, 0, 0};
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -352,7 +370,7 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
         }
         m1 *= (1.0f / 128.0f);
         m2 *= (1.0f / 128.0f);
-        reinterpret_cast<f32x4*>(dx)[idx] = (dn - m1 - n * m2) * rstd;
+        if (valid) reinterpret_cast<f32x4*>(dx)[idx] = (dn - m1 - n * m2) * rstd;
     }
     red[0][rg][c4] = a_g;
     red[1][rg][c4] = a_b;
@@ -366,22 +384,18 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
         f32x4 s = red[rg][0][c4];
 #pragma unroll
         for (int i = 1; i < 8; ++i) s += red[rg][i][c4];
-        float* dst = rg == 0 ? g_lnw + c4 * 4 : (rg == 1 ? g_lnb + c4 * 4 : g_ow + (rg - 2) * D + c4 * 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(dst + e, s[e]);
+        *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * FINAL_COLS + rg * D + c4 * 4) = s;   // lnw | lnb | ow[p]
     } else if (rg == 6 && c4 < 4) {
         float s = 0.f;
         for (int i = 0; i < 8; ++i) s += redb[i][c4];
-        atomicAdd(g_ob + c4, s);
+        part[(size_t)blockIdx.x * FINAL_COLS + 6 * D + c4] = s;
     }
 }
 
 // patchify backward (transformer.py:166-172): dtok (M,128) -> grads of patch_emb.{weight,bias}, conv.{weight,bias}
 __global__ __launch_bounds__(256) void patchify_bwd_kernel(const float* __restrict__ dtok, const float* __restrict__ lat,
                                                            int B, const float* __restrict__ cw, const float* __restrict__ cb,
-                                                           const float* __restrict__ pw, float* __restrict__ g_pw,
-                                                           float* __restrict__ g_pb, float* __restrict__ g_cw,
-                                                           float* __restrict__ g_cb, int M) {
+                                                           const float* __restrict__ pw, float* __restrict__ part, int M) {
     __shared__ f32x4 red[5][8][32];
     __shared__ float redc[8][20];
     const int c4 = threadIdx.x & 31, rg = threadIdx.x >> 5;
@@ -396,10 +410,13 @@ __global__ __launch_bounds__(256) void patchify_bwd_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < 4; ++i) a_cb[i] = 0.f;
     const int row0 = blockIdx.x * TAIL_ROWS;
-    for (int rr = rg; rr < TAIL_ROWS; rr += 8) {
-        const int row = row0 + rr;
-        if (row >= M) break;
-        const f32x4 g = reinterpret_cast<const f32x4*>(dtok)[(size_t)row * 32 + c4];
+#pragma unroll 4
+    for (int it = 0; it < TAIL_ROWS / 8; ++it) {
+        const int rr = rg + 8 * it;
+        const bool valid = row0 + rr < M;
+        const int row = valid ? row0 + rr : M - 1;
+        f32x4 g = reinterpret_cast<const f32x4*>(dtok)[(size_t)row * 32 + c4];
+        if (!valid) g = g * 0.f;
         const int seq = row / NTOK, tok = row - seq * NTOK;
         const int hh = tok >> 5, ww = tok & 31;
         const float* xin = lat + (size_t)(seq % B) * LAT;
@@ -445,17 +462,17 @@ __global__ __launch_bounds__(256) void patchify_bwd_kernel(const float* __restri
         f32x4 s = red[rg][0][c4];
 #pragma unroll
         for (int i = 1; i < 8; ++i) s += red[rg][i][c4];
+        float* prow = part + (size_t)blockIdx.x * PATCH_COLS;
         if (rg < 4) {   // g_pw[d][c], d = 4*c4+e, c = rg
 #pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(g_pw + (c4 * 4 + e) * 4 + rg, s[e]);
+            for (int e = 0; e < 4; ++e) prow[(c4 * 4 + e) * 4 + rg] = s[e];
         } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(g_pb + c4 * 4 + e, s[e]);
+            *reinterpret_cast<f32x4*>(prow + 512 + c4 * 4) = s;
         }
     } else if (rg == 5 && c4 < 20) {
         float s = 0.f;
         for (int i = 0; i < 8; ++i) s += redc[i][c4];
-        atomicAdd(c4 < 16 ? g_cw + c4 : g_cb + (c4 - 16), s);
+        part[(size_t)blockIdx.x * PATCH_COLS + 640 + c4] = s;     // conv.weight 16 | conv.bias 4
     }
 }
 
@@ -976,9 +993,13 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
         i = k;
     }
     // ---- final layer
+    const int tail_wgs = (M + TAIL_ROWS - 1) / TAIL_ROWS;
+    T2S_REQUIRE((size_t)tail_wgs * FINAL_COLS <= ws->wg_scratch_floats, "t2s_dit_train_backward: scratch too small for the tail partials");
     { TimeScope ts(h, TC_TR_TAIL, st);
-    final_bwd_kernel<<<(M + TAIL_ROWS - 1) / TAIL_ROWS, 256, 0, st>>>(ws->x_in[NBLK], dout, h->ln_w, h->ln_b, h->out_w, ws->dx, g->ln_w,
-                                                    g->ln_b, g->out_w, g->out_b, M);
+    final_bwd_kernel<<<tail_wgs, 256, 0, st>>>(ws->x_in[NBLK], dout, h->ln_w, h->ln_b, h->out_w, ws->dx, ws->wg_scratch, M);
+    T2S_LAUNCH_CHECK();
+    tail_reduce_kernel<<<(FINAL_COLS + 255) / 256, 256, 0, st>>>(ws->wg_scratch, tail_wgs, FINAL_COLS,
+                                                                 TailDst{{g->ln_w, g->ln_b, g->out_w, g->out_b}, {D, D, 4 * D, 4}});
     T2S_LAUNCH_CHECK();
     }
     const bool bf = ws->dtype == T2S_TRAIN_BF16;
@@ -1106,8 +1127,10 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
     }
     // ---- patchify
     { TimeScope ts(h, TC_TR_TAIL, st);
-    patchify_bwd_kernel<<<(M + TAIL_ROWS - 1) / TAIL_ROWS, 256, 0, st>>>(ws->dx, ws->lat, S, h->conv_w, h->conv_b, h->patch_w, g->patch_w,
-                                                       g->patch_b, g->conv_w, g->conv_b, M);
+    patchify_bwd_kernel<<<tail_wgs, 256, 0, st>>>(ws->dx, ws->lat, S, h->conv_w, h->conv_b, h->patch_w, ws->wg_scratch, M);
+    T2S_LAUNCH_CHECK();
+    tail_reduce_kernel<<<(PATCH_COLS + 255) / 256, 256, 0, st>>>(ws->wg_scratch, tail_wgs, PATCH_COLS,
+                                                                 TailDst{{g->patch_w, g->patch_b, g->conv_w, g->conv_b}, {4 * D, D, 16, 4}});
     T2S_LAUNCH_CHECK();
     }
     // ---- adaLN linear: mod = silu(c) W_ada^T + b_ada  (per block rows [768 i, 768 i + 768) of the (3072,128) stack)

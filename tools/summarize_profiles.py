@@ -1,5 +1,11 @@
-"""Write profiles/<tag>_summary.md from the files tools/collect_profiles.sh <tag> produced (copied into profiles/).
-    python tools/summarize_profiles.py r01_v7"""
+"""Write profiles/<tag>_summary.md, profiles/attn_pmc.json and profiles/train_traffic.json from the files
+tools/collect_profiles.sh <tag> produced (copied into profiles/).
+
+    python tools/summarize_profiles.py r02_v1
+
+The two json files are what bench.py reports as `roofline.traffic` / `roofline.pmc` (headline) and `train.roofline.traffic`:
+counter values that need rocprofv3 passes of their own, so they are read from here and carry the tag they came from.
+FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE under-reports 2x on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section)."""
 import csv
 import json
 import os
@@ -7,59 +13,115 @@ import sys
 
 tag = sys.argv[1]
 P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+CLOCK_GHZ = 2.4          # MI355X_MICROARCH.md peak engine clock; profiles/r01_clocks_under_load.txt measured 2.39 under load
+N_SIMD = 1024
 
 
-def table(name, top=10):
-    rows = list(csv.DictReader(open(os.path.join(P, f"{tag}_{name}.csv"))))[:top]
+def stats(name):
+    return list(csv.DictReader(open(os.path.join(P, f"{tag}_{name}.csv"))))
+
+
+def table(rows, top=10):
     out = ["| kernel | calls | avg us | % |", "|---|---|---|---|"]
-    for r in rows:
-        out.append("| `%s` | %s | %.1f | %.1f |" % (r["Name"][:72], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
-    return "\n".join(out), {r["Name"]: float(r["AverageNs"]) / 1e3 for r in rows}
+    for r in rows[:top]:
+        out.append("| `%s` | %s | %.1f | %.1f |" % (r["Name"][:80], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+    return "\n".join(out)
 
 
 def pmc(name):
-    rows = list(csv.DictReader(open(os.path.join(P, f"{tag}_pmc_{name}.csv"))))
-    return {r["kernel"]: float(r["avg_per_dispatch"]) for r in rows}
+    """{(kernel, counter): (dispatches, avg)}"""
+    path = os.path.join(P, f"{tag}_{name}.csv")
+    if not os.path.exists(path):
+        return {}
+    return {(r["kernel"], r["counter"]): (int(r["dispatches"]), float(r["avg_per_dispatch"])) for r in csv.DictReader(open(path))}
+
+
+def find(d, kernel_part, counter):
+    for (k, c), v in d.items():
+        if kernel_part in k and c == counter:
+            return v
+    return None
 
 
 b = json.load(open(os.path.join(P, f"{tag}_bench.json")))
-rf, cb, am = b["roofline"], b["cpu_baseline"], b.get("alt_math")
-t2, _ = table("kernel_stats")
-t1, k1 = table("kernel_stats_lanes1")
-attn1 = next(v for k, v in k1.items() if "attn_fwd_persistent" in k)
-fs, ws = pmc("FETCH_SIZE"), pmc("WRITE_SIZE")
-fa = next(v for k, v in fs.items() if "attn_fwd_persistent" in k)
-wa = next(v for k, v in ws.items() if "attn_fwd_persistent" in k)
+rf, cb, am, tr = b["roofline"], b.get("cpu_baseline"), b.get("alt_math"), b.get("train")
+k2, k1 = stats("kernel_stats"), stats("kernel_stats_lanes1")
+attn1 = next(float(r["AverageNs"]) / 1e3 for r in k1 if "attn_fwd_persistent" in r["Name"])
+fs, ws = pmc("pmc_FETCH_SIZE"), pmc("pmc_WRITE_SIZE")
+fa, wa = find(fs, "attn_fwd_persistent", "FETCH_SIZE"), find(ws, "attn_fwd_persistent", "WRITE_SIZE")
+attn_bytes = (2 * fa[1] + wa[1]) * 1024 if fa and wa else None
+sq = {}
+sq.update(pmc("pmc_sq1"))
+sq.update(pmc("pmc_sq2"))
+busy = find(sq, "attn_fwd_persistent", "SQ_VALU_MFMA_BUSY_CYCLES")
+mfma_busy = busy[1] / N_SIMD / (attn1 * 1e-6 * CLOCK_GHZ * 1e9) if busy else None
+json.dump({"kernel": "attn_fwd_persistent_kernel", "hbm_bytes_per_launch": attn_bytes,
+           "fetch_size_kb_raw": fa[1] if fa else None, "write_size_kb": wa[1] if wa else None,
+           "mfma_busy_frac": mfma_busy,
+           "mfma_busy_formula": "SQ_VALU_MFMA_BUSY_CYCLES per dispatch / 1024 SIMDs / (rocprofv3 average duration of the one-lane run x 2.4 GHz)",
+           "avg_launch_us_rocprof_lanes1": attn1,
+           "source": f"profiles/{tag}_pmc_FETCH_SIZE.csv, {tag}_pmc_WRITE_SIZE.csv, {tag}_pmc_sq1.csv (separate rocprofv3 --pmc passes of "
+                     f"`bench.py --lanes 1 --diffusion-steps 3`, tools/collect_profiles.sh {tag}); FETCH_SIZE x2 (gfx950 correction)"},
+          open(os.path.join(P, "attn_pmc.json"), "w"), indent=1)
+
 lines = [f"# {tag}: MI355X, collected by `tools/collect_profiles.sh {tag}` in one gpurun call", "",
          "## Headline: sampling (BASELINE configs[1]), f32 MFMA",
          f"`python bench.py --gpus 1 --steps 3 --warmup 1` (`profiles/{tag}_bench.json`): **{b['value']:.1f} series/s**, "
          f"{b['ms_per_step']:.0f} ms per 256-series batch, sampler lanes = {b['config'].get('sampler_lanes')}; whole path "
-         f"{b['whole_path_tflops']:.1f} TFLOP/s = {b['whole_path_frac_of_fp32_mfma_peak']:.3f} of the fp32 MFMA peak; CPU oracle "
-         f"{cb['value']:.4f} series/s on {cb['cores']} cores ({b['gpu_over_cpu']:.0f}x).",
-         "",
-         f"Roofline block (dominant kernel, alone on the chip at the 512-sequence launch shape): attention {rf['avg_launch_us']:.1f} us "
-         f"in situ = {rf['achieved']:.1f} TFLOP/s = **{rf['frac']:.3f}** of peak; rocprofv3 average of the one-lane run below: {attn1:.1f} us.",
-         "",
-         "### One lane (`--lanes 1`): every kernel alone on the chip -- the configuration the roofline block is quoted on",
-         "`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline --no-alt-math --lanes 1`",
-         "", t1, "",
-         "### Two lanes (the default, the timed region of the headline): same command without `--lanes 1`",
-         "Each kernel is issued as two 256-sequence launches, one per lane, that time-share the CUs with the other lane's kernels: "
-         "the per-launch averages below include that sharing (and queueing behind the other lane for the small kernels) and are "
-         "not kernel properties; what the pipelining buys is the batch time above.", "", t2, "",
-         f"HBM traffic of the dominant kernel (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes on the one-lane run, "
-         f"`{tag}_pmc_*.csv`; FETCH_SIZE is in KB and under-reports 2x on gfx950): attention 2 x {fa:,.0f} KB + {wa:,.0f} KB = "
-         f"{(2 * fa + wa) * 1024 / 1e6:.1f} MB per launch = its algorithmic bytes (q, k, v in, o out for 2048 heads) -> no re-reads.", ""]
+         f"{b['whole_path_tflops']:.1f} TFLOP/s = {b['whole_path_frac_of_fp32_mfma_peak']:.3f} of the fp32 MFMA peak."]
+if cb:
+    lines.append(f"CPU baseline (oracle, fused SDPA): {cb['value']:.4f} series/s on {cb['cores']} cores ({b['gpu_over_cpu']:.0f}x), "
+                 f"{cb['one_thread']['value']:.4f} series/s on one thread.")
+lines += ["",
+          f"Roofline block (dominant kernel, alone on the chip at the 512-sequence launch shape): attention {rf['avg_launch_us']:.1f} us "
+          f"in situ = {rf['achieved']:.1f} TFLOP/s = **{rf['frac']:.3f}** of peak; rocprofv3 average of the one-lane run below: {attn1:.1f} us "
+          f"= {60397977600 / (attn1 * 1e-6) / 1e12 / 157.3:.3f}.",
+          "",
+          "### One lane (`--lanes 1`): every kernel alone on the chip -- the configuration the roofline block is quoted on",
+          "`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline --no-alt-math --no-train --lanes 1`",
+          "", table(k1), "",
+          "### Two lanes (the default, the timed region of the headline): same command without `--lanes 1`",
+          "Each kernel is issued as two 256-sequence launches, one per lane, that time-share the CUs with the other lane's kernels: "
+          "the per-launch averages below include that sharing and are not kernel properties; what the pipelining buys is the batch time above.",
+          "", table(k2), ""]
+if attn_bytes:
+    lines += [f"HBM traffic of the dominant kernel (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes on the one-lane run): attention "
+              f"2 x {fa[1]:,.0f} KB + {wa[1]:,.0f} KB = {attn_bytes / 1e6:.1f} MB per launch against 503.3 MB of algorithmic bytes "
+              f"(q, k, v in, o out for 2048 heads).", ""]
+if mfma_busy:
+    lines += [f"Matrix-pipe busy share of the same kernel: SQ_VALU_MFMA_BUSY_CYCLES {busy[1]:,.0f} per dispatch = **{mfma_busy:.3f}** of the kernel's "
+              f"SIMD-cycles (formula in `profiles/attn_pmc.json`).", ""]
+rows_busy = [(k, v) for (k, c), v in sq.items() if c == "SQ_VALU_MFMA_BUSY_CYCLES" and "dit_rows" in k]
+if rows_busy:
+    lines += ["Row-chain kernels, same pass: " + "; ".join(f"`{k[:60]}` {v[1]:,.0f} busy cycles / dispatch" for k, v in rows_busy), ""]
 if am:
     lines += ["## Opt-in bf16x3 arithmetic (include/t2s.h T2S_MATH_BF16X3; DESIGN.md 4.4) -- not the headline",
               f"`bench.py` reports it as `alt_math`: **{am['value']:.1f} series/s** ({am['ms_per_step']:.0f} ms per batch); attention "
               f"{am['attention_us']:.0f} us alone on the chip, row chain {am['row_chain_us']:.0f} us average.  rocprofv3 kernel stats of "
-              f"`bench.py --math bf16x3 --diffusion-steps 50` (two lanes; `{tag}_x3_kernel_stats.csv`):", "", table("x3_kernel_stats", 6)[0], ""]
-tb = [json.loads(l) for l in open(os.path.join(P, f"{tag}_train_bench.jsonl")) if l.strip()]
-lines += ["## Training step (BASELINE config 4 shape, B=1152/GPU, L=96) -- `tools/bench_train.py`",
-          "| dtype | latents | ms/step | samples/s |", "|---|---|---|---|"]
-lines += ["| %s | %s | %.2f | %.0f |" % (t["dtype"], t["latents"], t["ms_per_step"], t["value"]) for t in tb]
-lines += ["", f"rocprofv3 kernel stats of the bf16 / cached-latent step (`{tag}_train_bf16_kernel_stats.csv`; 1 warm-up + 3 timed steps; the "
-          "single `vae_encode_kernel` call is the one-off latent-cache fill):", "", table("train_bf16_kernel_stats", 24)[0], ""]
+              f"`bench.py --math bf16x3 --diffusion-steps 50` (`{tag}_x3_kernel_stats.csv`):", "", table(stats("x3_kernel_stats"), 6), ""]
+
+# ---- training
+tb_path = os.path.join(P, f"{tag}_train_bench.json")
+if os.path.exists(tb_path):
+    t = json.load(open(tb_path))
+    kt = stats("train_bf16_kernel_stats")
+    tf, tw = pmc("train_pmc_FETCH_SIZE"), pmc("train_pmc_WRITE_SIZE")
+    n_steps = 1 + 3 + 3          # tools/bench_train.py --steps 3 --warmup 1, plus the 3 event-timed steps of the class breakdown
+    tot_f = sum(n * v for (k, c), (n, v) in tf.items() if c == "FETCH_SIZE")
+    tot_w = sum(n * v for (k, c), (n, v) in tw.items() if c == "WRITE_SIZE")
+    per_step = (2 * tot_f + tot_w) * 1024 / n_steps if tf and tw else None
+    json.dump({"per_gpu_batch": t["per_gpu_batch"], "hbm_bytes_per_step": per_step,
+               "source": f"profiles/{tag}_train_pmc_FETCH_SIZE.csv + _WRITE_SIZE.csv: all kernels of `tools/bench_train.py --steps 3 --warmup 1` "
+                         f"({n_steps} training steps incl. the event-timed ones; the one-off latent-cache fill and the few torch kernels are "
+                         f"included, < 1 %); FETCH_SIZE x2 (gfx950 correction)"},
+              open(os.path.join(P, "train_traffic.json"), "w"), indent=1)
+    lines += ["## Training step (BASELINE configs[3] shape: bf16, B=1152/GPU, L=96, DDPM T=100, cached latents)",
+              f"`tools/bench_train.py --steps 20 --warmup 3` = the `train` leg of bench.py (`{tag}_train_bench.json`): **{t['ms_per_step']:.2f} ms/step, "
+              f"{t['value']:,.0f} samples/s**, {t['tflops_algorithmic']:.0f} algorithmic TFLOP/s.",
+              "", "Per class, HIP events in situ (ms per step): " + ", ".join(f"{k} {v['ms_per_step']:.2f}" for k, v in t["kernel_classes"].items()), ""]
+    if per_step:
+        lines += [f"HBM bytes per step from the PMC passes: **{per_step / 1e9:.1f} GB** (design count {t['hbm_bytes_per_step_model'] / 1e9:.1f} GB) "
+                  f"= {per_step / (t['ms_per_step'] * 1e-3) / 1e12:.2f} TB/s over the whole step.", ""]
+    lines += [f"rocprofv3 kernel stats (`{tag}_train_bf16_kernel_stats.csv`; 1 warm-up + 3 timed + 3 event-timed steps):", "", table(kt, 26), ""]
 open(os.path.join(P, f"{tag}_summary.md"), "w").write("\n".join(lines))
-print("\n".join(lines[:14]))
+print("\n".join(lines[:16]))
