@@ -3,7 +3,9 @@
 // Same mathematics as t2s_attn_bwd.hip (timm 1.0.11 Attention core; reference call site
 // model/denoiser/transformer.py:116 under autograd, train.py:123-125).
 //
-// q, k, v: bf16 (BH, 480, 32), bh = seq*4 + head.  o, do: bf16 token rows (S*480, 128), head h at
+// q, k, v: bf16 (BH, 480, 32), bh = seq*4 + head; q is PRE-SCALED by log2(e)/sqrt(32) (ATT_QS, applied by the qkv GEMM's
+// epilogue), so q.k is the score in the log2 domain and the softmax reference / log-sum-exp / D_i are subtracted for free
+// as the C operand of the score MFMAs (mfma16_from).  o, do: bf16 token rows (S*480, 128), head h at
 // columns 32h..32h+31.  dqkv: bf16 token rows (S*480, 384) = [dq | dk | dv] x heads.  lse: fp32
 // (BH, 480) in the log2 domain of the scaled scores.
 //
@@ -22,7 +24,7 @@ namespace {
 constexpr int NKB = NTOK / 32;                 // 15 tiles of 32 tokens
 constexpr int IMG = NTOK * 64;                 // bytes of one (480 x 32) bf16 image
 constexpr float SCALE = 0.17677669529663687f;  // 32^-0.5
-constexpr float QS = SCALE * 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;     // SCALE / ATT_QS: dK = dS^T q SCALE = dS^T (q ATT_QS) ln 2
 
 __device__ __forceinline__ int img_off(int row, int chunk) { return row * 64 + 16 * (chunk ^ ((row >> 2) & 3)); }
 
@@ -86,39 +88,43 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_fwd_kernel(const __b
         // are exponentiated against it without a max or an output rescale (the kernel is VALU-bound:
         // that is a third of its vector work).  A block whose row sum shows the reference is stale by
         // more than 2^40 re-references the running state (classic online-softmax step), wave-uniformly.
-        float m_run = -INFINITY, l_lane = 0.f;
+        float m_run = 0.f, l_lane = 0.f;    // m_run: the reference, in the log2 domain of the (pre-scaled) scores
+        f32x16 negm;                        // -m_run in all 16 registers: the C operand of every score MFMA
         for (int jb = 0; jb < NKB; ++jb) {
-            f32x16 st;
+            if (jb == 0) {                  // reference = row max of the first key block (two extra MFMAs per tile)
+                f32x16 raw;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+                for (int r = 0; r < 16; ++r) raw[r] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) st = mfma16(row_frag(Ks, jb * 32, lane, s), qf[s], st);   // S^T[key][query], raw
-            if (jb == 0) {
-                float mloc = st[0];
+                for (int s = 0; s < 2; ++s) raw = mfma16(row_frag(Ks, 0, lane, s), qf[s], raw);
+                float mloc = raw[0];
 #pragma unroll
-                for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[r]);
+                for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, raw[r]);
                 m_run = pair_max_f(mloc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[r] = -m_run;
             }
-            float mq = m_run * QS;
+            f32x16 st = mfma16_from(row_frag(Ks, jb * 32, lane, 0), qf[0], negm);   // S^T[key][query] - m_run
+            st = mfma16(row_frag(Ks, jb * 32, lane, 1), qf[1], st);
             f32x16 pt;
             float ps = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                pt[r] = __builtin_amdgcn_exp2f(st[r] * QS - mq);
+                pt[r] = __builtin_amdgcn_exp2f(st[r]);
                 ps += pt[r];
             }
             if (__builtin_amdgcn_ballot_w64(!(ps < 1.0995116e12f)) != 0) {      // 2^40; also catches inf / NaN
                 float mloc = st[0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[r]);
-                const float m_new = fmaxf(m_run, pair_max_f(mloc));
-                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * QS);
-                m_run = m_new;
-                mq = m_new * QS;
+                const float up = fmaxf(0.f, pair_max_f(mloc));                  // the new reference is m_run + up
+                const float alpha = __builtin_amdgcn_exp2f(-up);
+                m_run += up;
                 ps = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    pt[r] = __builtin_amdgcn_exp2f(st[r] * QS - mq);
+                    negm[r] = -m_run;
+                    pt[r] = __builtin_amdgcn_exp2f(st[r] - up);
                     ps += pt[r];
                     ot[r] *= alpha;
                 }
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_fwd_kernel(const __b
             const f32x4 w = {ot[4 * g] * inv, ot[4 * g + 1] * inv, ot[4 * g + 2] * inv, ot[4 * g + 3] * inv};
             *reinterpret_cast<bf16x4*>(orow + 8 * g) = pack4(w);
         }
-        if (half == 0) lse[(size_t)bh * NTOK + tok] = m_run * QS + __builtin_amdgcn_logf(l_tot);   // v_log_f32 = log2
+        if (half == 0) lse[(size_t)bh * NTOK + tok] = m_run + __builtin_amdgcn_logf(l_tot);   // v_log_f32 = log2
     }
 }
 
@@ -186,23 +192,20 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_bwd_dq_kernel(const 
         }
         const float lse_i = lse[(size_t)bh * NTOK + tok];
         const float d_i = dsum[(size_t)bh * NTOK + tok];
-        f32x16 dq;
+        f32x16 dq, nl, nd;     // nl / nd: -lse_i / -D_i in all 16 registers, the C operands of the score / dP MFMAs
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+        for (int r = 0; r < 16; ++r) {
+            dq[r] = 0.f;
+            nl[r] = -lse_i;
+            nd[r] = -d_i;
+        }
         for (int jb = 0; jb < NKB; ++jb) {
-            f32x16 st, dp;
+            f32x16 st = mfma16_from(row_frag(Ks, jb * 32, lane, 0), qf[0], nl);    // S^T[key][query] - lse (log2 domain)
+            f32x16 dp = mfma16_from(row_frag(Vs, jb * 32, lane, 0), dof[0], nd);   // dP^T[key][query] - D = V dO^T - D
+            st = mfma16(row_frag(Ks, jb * 32, lane, 1), qf[1], st);
+            dp = mfma16(row_frag(Vs, jb * 32, lane, 1), dof[1], dp);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[r] = dp[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                st = mfma16(row_frag(Ks, jb * 32, lane, s), qf[s], st);     // S^T[key][query], raw
-                dp = mfma16(row_frag(Vs, jb * 32, lane, s), dof[s], dp);    // dP^T[key][query] = V dO^T
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(st[r] * QS - lse_i);
-                st[r] = p * (dp[r] - d_i);                                   // dS^T
-            }
+            for (int r = 0; r < 16; ++r) st[r] = __builtin_amdgcn_exp2f(st[r]) * dp[r];   // dS^T = P (dP - D)
 #pragma unroll
             for (int s = 0; s < 2; ++s) dq = mfma16(col_frag(Ks, jb * 32, lane, s), acc_frag(st, s), dq);   // dQ^T += K^T dS^T
         }
@@ -232,8 +235,8 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_bwd_dkv_kernel(const
     stage_img(Qs, q + (size_t)bh * NTOK * DH, DH, tid, 512);
     stage_img(Os, do_rows + (size_t)seq * NTOK * D + head * DH, D, tid, 512);
     for (int t = tid; t < NTOK; t += 512) {
-        Ls[t] = lse[(size_t)bh * NTOK + t];
-        Ds[t] = dsum[(size_t)bh * NTOK + t];
+        Ls[t] = -lse[(size_t)bh * NTOK + t];      // negated: they initialise the accumulators (C operands) below
+        Ds[t] = -dsum[(size_t)bh * NTOK + t];
     }
     wg_sync();
     const __bf16* kg = k + (size_t)bh * NTOK * DH;
@@ -250,26 +253,29 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_bwd_dkv_kernel(const
 #pragma unroll
         for (int r = 0; r < 16; ++r) dk[r] = dv[r] = 0.f;
         for (int qb = 0; qb < NKB; ++qb) {
+            // accumulators start at the per-register query statistics (queries 8g + 4 half + 0..3 of this block):
+            // sc = S - lse, dp = dP - D come straight out of the MFMAs
             f32x16 sc, dp;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[r] = dp[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                sc = mfma16(row_frag(Qs, qb * 32, lane, s), kf[s], sc);    // S[query][key], raw (registers = queries)
-                dp = mfma16(row_frag(Os, qb * 32, lane, s), vf[s], dp);    // dP[query][key] = dO V^T
-            }
-            // per-register query statistics: queries 8g + 4 half + 0..3 of this block
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qb * 32 + 8 * g + 4 * half);
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ds + qb * 32 + 8 * g + 4 * half);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g + e;
-                    const float p = __builtin_amdgcn_exp2f(sc[r] * QS - l4[e]);
-                    dp[r] = p * (dp[r] - d4[e]);   // dS[query][key]
-                    sc[r] = p;                     // P[query][key]
+                    sc[4 * g + e] = l4[e];
+                    dp[4 * g + e] = d4[e];
                 }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                sc = mfma16(row_frag(Qs, qb * 32, lane, s), kf[s], sc);    // S[query][key] - lse (registers = queries)
+                dp = mfma16(row_frag(Os, qb * 32, lane, s), vf[s], dp);    // dP[query][key] - D = dO V^T - D
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(sc[r]);
+                dp[r] = p * dp[r];             // dS[query][key]
+                sc[r] = p;                     // P[query][key]
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_bwd_dkv_kernel(const
         __bf16* dst = dqkv + ((size_t)seq * NTOK + key) * (3 * D) + head * DH + 4 * half;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 wk = {dk[4 * g] * SCALE, dk[4 * g + 1] * SCALE, dk[4 * g + 2] * SCALE, dk[4 * g + 3] * SCALE};
+            const f32x4 wk = {dk[4 * g] * LN2, dk[4 * g + 1] * LN2, dk[4 * g + 2] * LN2, dk[4 * g + 3] * LN2};   // Qs holds q ATT_QS
             const f32x4 wv = {dv[4 * g], dv[4 * g + 1], dv[4 * g + 2], dv[4 * g + 3]};
             *reinterpret_cast<bf16x4*>(dst + D + 8 * g) = pack4(wk);
             *reinterpret_cast<bf16x4*>(dst + 2 * D + 8 * g) = pack4(wv);
@@ -310,9 +316,9 @@ int attn16_bwd(const __bf16* q, const __bf16* k, const __bf16* v, const __bf16* 
 
 // ------------------------------------------------------------------ C ABI: stand-alone bf16 attention forward
 namespace {
-__global__ void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n4) {
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n4, float scale) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n4) reinterpret_cast<t2s::bf16x4*>(dst)[i] = t2s::pack4(reinterpret_cast<const t2s::f32x4*>(src)[i]);
+    if (i < n4) reinterpret_cast<t2s::bf16x4*>(dst)[i] = t2s::pack4(reinterpret_cast<const t2s::f32x4*>(src)[i] * scale);
 }
 __global__ void bf16_to_f32_kernel(const __bf16* __restrict__ src, float* __restrict__ dst, size_t n4) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -329,9 +335,9 @@ extern "C" int t2s_attn_fwd_bf16(const float* q, const float* k, const float* v,
     __bf16* buf = nullptr;
     T2S_HIP_CHECK(hipMalloc(&buf, 4 * n * sizeof(__bf16)));
     const unsigned blocks = (unsigned)((n / 4 + 255) / 256);
-    f32_to_bf16_kernel<<<blocks, 256, 0, st>>>(q, buf, n / 4);
-    f32_to_bf16_kernel<<<blocks, 256, 0, st>>>(k, buf + n, n / 4);
-    f32_to_bf16_kernel<<<blocks, 256, 0, st>>>(v, buf + 2 * n, n / 4);
+    f32_to_bf16_kernel<<<blocks, 256, 0, st>>>(q, buf, n / 4, ATT_QS);   // the kernels take q pre-scaled (as the qkv GEMM stores it)
+    f32_to_bf16_kernel<<<blocks, 256, 0, st>>>(k, buf + n, n / 4, 1.0f);
+    f32_to_bf16_kernel<<<blocks, 256, 0, st>>>(v, buf + 2 * n, n / 4, 1.0f);
     int rc = attn16_train_fwd(buf, buf + n, buf + 2 * n, buf + 3 * n, lse, n_seq * NH, st);
     if (rc == T2S_OK) {
         bf16_to_f32_kernel<<<blocks, 256, 0, st>>>(buf + 3 * n, o_rows, n / 4);

@@ -30,6 +30,20 @@ __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// The same with the result in registers of its own (vdst != src2): c survives, so a loop-invariant C operand -- the
+// negated softmax reference, log-sum-exp or D_i broadcast over an accumulator -- subtracts for free, block after block.
+// (The builtin ties vdst to src2 and the compiler would copy c first: 16 v_mov per use.)  Follow it with builtin MFMAs that
+// accumulate in place on the result before any VALU instruction reads it.
+__device__ __forceinline__ f32x16 mfma16_from(bf16x8 a, bf16x8 b, const f32x16& c) {
+    f32x16 d;
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// Attention of the bf16 training path keeps q PRE-SCALED by log2(e) / sqrt(head_dim): the qkv GEMM's epilogue applies
+// it before the bf16 rounding, so q.k is the score in the log2 domain and no kernel multiplies scores again.
+constexpr float ATT_QS = 0.17677669529663687f * 1.4426950408889634f;
+
 __device__ __forceinline__ bf16x4 pack4(f32x4 v) { return __builtin_convertvector(v, bf16x4); }
 __device__ __forceinline__ f32x4 unpack4(bf16x4 v) { return __builtin_convertvector(v, f32x4); }
 __device__ __forceinline__ bf16x8 pack8(f32x4 lo, f32x4 hi) {
@@ -237,6 +251,9 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_kernel(const BGemmArgs a) {
                 const int col = nt * 32 + 8 * g + 4 * h;
                 f32x4 y = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
                 y += *reinterpret_cast<const f32x4*>(blds + col);
+                if constexpr (EPI == BEPI_QKV) {
+                    if ((nt >> 2) == 0) y = y * ATT_QS;        // q heads: scores come out in the log2 domain
+                }
                 if constexpr (EPI == BEPI_GELUBWD) {
                     const f32x4 u = unpack4(aux4[g]);
                     y.x *= gelu_tanh_grad(u.x); y.y *= gelu_tanh_grad(u.y);

@@ -295,11 +295,23 @@ constexpr int FINAL_COLS = 772;   // ln.weight 128 | ln.bias 128 | linear_emb_to
 constexpr int PATCH_COLS = 660;   // patch_emb.weight 128x4 | .bias 128 | conv.weight 16 | conv.bias 4
 
 struct TailDst { float* p[4]; int n[4]; };   // consecutive column ranges of a partial row -> gradient tensors
+// grid = cols / 32 workgroups of 32 columns x 8 row slices: slice j adds partial rows j, j+8, ... (independent loads, many in
+// flight), then the 8 slice sums are added in slice order.  (One thread per column walking all ~1000 rows serially paid a
+// full memory latency per row: 260 us.)
 __global__ __launch_bounds__(256) void tail_reduce_kernel(const float* __restrict__ part, int n_wg, int cols, const TailDst d) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
+    __shared__ float red[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
-    for (int w = 0; w < n_wg; ++w) s += part[(size_t)w * cols + c];
+    if (c < cols) {
+#pragma unroll 8
+        for (int w = sl; w < n_wg; w += 8) s += part[(size_t)w * cols + c];
+    }
+    red[sl][cl] = s;
+    __syncthreads();
+    if (sl != 0 || c >= cols) return;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) s += red[j][cl];
     int off = c;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -998,7 +1010,7 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
     { TimeScope ts(h, TC_TR_TAIL, st);
     final_bwd_kernel<<<tail_wgs, 256, 0, st>>>(ws->x_in[NBLK], dout, h->ln_w, h->ln_b, h->out_w, ws->dx, ws->wg_scratch, M);
     T2S_LAUNCH_CHECK();
-    tail_reduce_kernel<<<(FINAL_COLS + 255) / 256, 256, 0, st>>>(ws->wg_scratch, tail_wgs, FINAL_COLS,
+    tail_reduce_kernel<<<(FINAL_COLS + 31) / 32, 256, 0, st>>>(ws->wg_scratch, tail_wgs, FINAL_COLS,
                                                                  TailDst{{g->ln_w, g->ln_b, g->out_w, g->out_b}, {D, D, 4 * D, 4}});
     T2S_LAUNCH_CHECK();
     }
@@ -1129,7 +1141,7 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
     { TimeScope ts(h, TC_TR_TAIL, st);
     patchify_bwd_kernel<<<tail_wgs, 256, 0, st>>>(ws->dx, ws->lat, S, h->conv_w, h->conv_b, h->patch_w, ws->wg_scratch, M);
     T2S_LAUNCH_CHECK();
-    tail_reduce_kernel<<<(PATCH_COLS + 255) / 256, 256, 0, st>>>(ws->wg_scratch, tail_wgs, PATCH_COLS,
+    tail_reduce_kernel<<<(PATCH_COLS + 31) / 32, 256, 0, st>>>(ws->wg_scratch, tail_wgs, PATCH_COLS,
                                                                  TailDst{{g->patch_w, g->patch_b, g->conv_w, g->conv_b}, {4 * D, D, 16, 4}});
     T2S_LAUNCH_CHECK();
     }

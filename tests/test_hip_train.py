@@ -242,8 +242,12 @@ def test_bf16_attention_forward_and_stale_reference_branch(dev):
     k[:, 410] = q[:, 200] * 12.0                       # log2-domain jump of ~100 at key block 12
     k[:, 0:32] = -q[:, 7:8] * 3.0 + 0.01 * k[:, 0:32]  # first block hugely negative for query 7 ...
     k[:, 448] = q[:, 7] * 10.0                         # ... and its real maximum in block 14
-    qb, kb, vb = (t.to(torch.bfloat16).double() for t in (q, k, v))
-    s = (qb @ kb.transpose(-1, -2)) * 32 ** -0.5
+    # the kernels take q PRE-SCALED by log2(e)/sqrt(32) before the bf16 rounding (t2s_bf16.h ATT_QS; the wrapper applies it
+    # as the qkv GEMM's epilogue does): the reference uses exactly those operands, scores in the log2 domain
+    QS = float(np.float32(0.17677669529663687) * np.float32(1.4426950408889634))
+    qb = (q * QS).to(torch.bfloat16).double()
+    kb, vb = (t.to(torch.bfloat16).double() for t in (k, v))
+    s = (qb @ kb.transpose(-1, -2)) * np.log(2.0)
     ref = torch.softmax(s, dim=-1) @ vb
     lse_ref = torch.logsumexp(s, dim=-1) / np.log(2.0)
     qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
