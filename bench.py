@@ -251,16 +251,38 @@ def train_leg(dev, dist, rank, world, batch=1152, length=96, steps=30, warmup=4,
     return out
 
 
+# Bytes the bf16 training step moves BY DESIGN, per launch of each kernel, in units u = one bf16 (M,128) tensor
+# (M = batch * 480 tokens; an fp32 (M,128) tensor is 2 u).  Kept next to the launch list of t2s_dit_train_forward /
+# _backward (csrc/t2s_train.hip): update both together.  DESIGN.md section 4.3 has the same table.
+TRAIN_U = {
+    # forward, per block
+    "qkv GEMM, LN prologue fused with the previous block's gate/residual add (x 2 + branch 1 in; x 2 + a1 1 + q,k,v 3 out)": (9, 4),
+    "  ... block 0 has no add to fuse (x 2 in; a1 1 + q,k,v 3 out)": (-3, 1),
+    "attention forward (q,k,v in; o out)": (4, 4),
+    "proj GEMM": (2, 4),
+    "fc1 GEMM, LN prologue fused with the attention gate/residual add (x 2 + p 1 in; x_mid 2 + a2 1 + u 2 out)": (8, 4),
+    "fc2 GEMM, GELU prologue (u 2 in; f 1 out)": (3, 4),
+    "last gate/residual add (feeds the final layer)": (5, 1),
+    # backward, per block
+    "fc2 weight gradient (df 1, u 2)": (3, 4), "fc2 data gradient x gelu' (df 1, u 2 in; du 2 out)": (5, 4),
+    "fc1 weight gradient (du 2, a2 1)": (3, 4), "fc1 data gradient (du 2 in; da2 1 out)": (3, 4),
+    "LN2 backward + attention-branch gate backward (da 1, x 2, dx 2, p 1 in; dx 2, dp 1 out)": (9, 4),
+    "proj weight gradient (dp 1, o 1)": (2, 4), "proj data gradient": (2, 4),
+    "attention D_i (o 1, do 1)": (2, 4), "attention dQ (q,k,v,do in; dq out)": (5, 4), "attention dK,dV (q,k,v,do in; dk,dv out)": (6, 4),
+    "qkv weight gradient (dqkv 3, a1 1)": (4, 4), "qkv data gradient (dqkv 3 in; da1 1 out)": (4, 4),
+    "LN1 backward + next gate backward": (9, 4),
+    "weight-gradient partial tiles written + re-read (4 gradients)": (2.6, 4),
+    "MLP gate backward of the last block": (4, 1),
+    # tails
+    "patchify + final layer forward": (4, 1), "final layer + patchify backward": (6, 1),
+}
+
+
 def train_bytes_model(batch):
-    """Bytes the bf16 training step moves BY DESIGN, in units u = one bf16 (M,128) tensor,
-    M = batch * 480 tokens; fp32 (M,128) = 2u.  Kept next to the kernels' launch list: update both together."""
     u = batch * 480 * 128 * 2
-    units = TRAIN_UNITS_PER_BLOCK * 4
-    return {"total": units * u, "note": f"{TRAIN_UNITS_PER_BLOCK} u per block x 4 blocks, u = {u / 1e6:.1f} MB "
-                                        f"(one bf16 (M,128) tensor); tails < 1 %"}
-
-
-TRAIN_UNITS_PER_BLOCK = 83   # forward 27 u (gate / residual adds fused into the consuming GEMM, gelu(u) not saved) + backward 56 u (DESIGN.md 4.3)
+    units = sum(per * n for per, n in TRAIN_U.values())
+    return {"total": units * u, "note": f"{units:.1f} u per step by design (table TRAIN_U in bench.py / DESIGN.md 4.3), "
+                                        f"u = {u / 1e6:.1f} MB = one bf16 (M,128) tensor"}
 
 
 def _train_traffic_from_profile(batch):

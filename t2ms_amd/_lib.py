@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libt2s_hip.so")
+LIB_PATH = os.environ.get("T2S_LIB", os.path.join(_HERE, "libt2s_hip.so"))   # T2S_LIB: A/B another build (tools/)
 
 N_BLOCKS = 4
 LAT_C, LAT_W, LAT = 64, 30, 1920

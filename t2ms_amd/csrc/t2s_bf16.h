@@ -315,42 +315,42 @@ inline int launch_bgemm(const BGemmArgs& a, hipStream_t st) {
 
 // ------------------------------------------------------------------------------------------ wgrad
 // dW[n][k] = sum_rows dY[row][n] X[row][k],  db[n] = sum_rows dY[row][n], in two deterministic
-// stages: wgrad16_kernel writes fp32 partial tiles (128 x 128, + 128 bias sums) per workgroup and (n, k) chunk
+// stages: wgrad16_kernel writes one fp32 partial tile (128 x 128, + 128 bias sums) per workgroup
 // with plain coalesced stores, wgrad16_reduce_kernel adds the partials of all row slabs in slab
 // order.  (fp32 atomics into the 64 KB gradient tile from ~500 workgroups ran at 0.3 TB/s and
 // cost 100 us per call -- more than streaming the operands.)
-// One workgroup owns a slab of token rows and ALL of N x K: 4 waves per (128-output, 128-input) chunk pair, i.e.
-// 4 / 8 / 8 / 12 waves for proj / fc1 / fc2 / qkv, sharing ONE LDS copy of the slab's dY and X rows -- each operand
-// crosses HBM once.  (Round 1 launched a workgroup per chunk pair: X of the qkv gradient was read three times, dY of
-// fc2 and X of fc1 twice; the PMC passes showed none of that absorbed by the caches.)
-// MFMA: D[n][k] = sum_row A[n][row] B[row][k]: both operands are read column-wise out of row-major LDS tiles (64
-// rows per pass; row strides of 64 (mod 256) bytes put four consecutive rows into disjoint bank quarters, so the
-// transposed reads are conflict-free).
+// (Round 2 measured the alternative of ONE workgroup per row slab owning all (n, k) chunk pairs -- 4 / 8 / 8 / 12 waves
+// sharing one LDS copy of dY and X, each operand crossing HBM once instead of X of the qkv gradient three times and dY of
+// fc2 / X of fc1 twice: 8 % SLOWER on the same box, 2.15 vs 1.99 ms per step for the 16 launches (tools/ab_lib.sh); the
+// wider barrier domain costs more than the re-reads, which the 256 MB Infinity Cache largely serves.  Kept per chunk pair.)
+// grid (row slabs, N/128, K/128); wave w of a workgroup owns outputs [128 y + 32 w, +32) x inputs
+// [128 z, +128).  MFMA: D[n][k] = sum_row A[n][row] B[row][k]: both operands are read column-wise
+// out of row-major LDS tiles (64 rows per pass, row stride 320 B: four consecutive rows land in
+// disjoint bank quarters, so the transposed reads are conflict-free).
 // XGELU: the X operand is gelu(X) (the fc2 weight gradient needs gelu(u); applying it to the fetched chunks here
 // costs VALU time the HBM-bound kernel has to spare and saves writing + re-reading a (M,256) tensor per block).
-template <int NC, int KC, bool XGELU>
-static __global__ __launch_bounds__(256 * NC * KC) void wgrad16_kernel(const __bf16* __restrict__ dY, const __bf16* __restrict__ X,
-                                                                float* __restrict__ part, float* __restrict__ bpart, int M,
-                                                                int rows_per_wg) {
-    constexpr int N = 128 * NC, K = 128 * KC, NTHR = 256 * NC * KC;
-    constexpr int KT = 4;          // 32-wide k-tiles per wave (its 128-wide input chunk)
+template <bool XGELU>
+static __global__ __launch_bounds__(256) void wgrad16_kernel(const __bf16* __restrict__ dY, const __bf16* __restrict__ X,
+                                                      float* __restrict__ part, float* __restrict__ bpart, int M, int N,
+                                                      int K, int rows_per_wg) {
+    constexpr int KT = 4;          // 32-wide k-tiles per workgroup
     constexpr int SLAB = 64;
-    constexpr int YS = N * 2 + 64, XS = K * 2 + 64;      // LDS row strides (bytes)
-    extern __shared__ __attribute__((aligned(16))) char wsm[];
-    char* ys = wsm;
-    char* xs = wsm + SLAB * YS;
+    constexpr int STR = 320;
+    __shared__ __attribute__((aligned(16))) char ys[SLAB * STR];
+    __shared__ __attribute__((aligned(16))) char xs[SLAB * STR];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int sub = wave & 3, nc = (wave >> 2) % NC, kc = (wave >> 2) / NC;
     const int half = lane >> 5;
+    const int ncol0 = blockIdx.y * 128;
+    const int kcol0 = blockIdx.z * 128;
     const int r0 = blockIdx.x * rows_per_wg;
     const int r1 = min(M, r0 + rows_per_wg);
     // transposed-read addressing of this lane
     const int grp = (lane >> 4) & 3, nhalf = grp & 1, q = (lane & 15) >> 2, p = lane & 3;
     const int rbase = 8 * half + q;                      // row inside a 16-row k-step (second read: +4)
-    const char* ya = ys + rbase * YS + (nc * 128 + sub * 32 + 16 * nhalf + 4 * p) * 2;
-    const char* xa = xs + rbase * XS + (kc * 128 + 16 * nhalf + 4 * p) * 2;
+    const char* ya = ys + rbase * STR + (wave * 32 + 16 * nhalf + 4 * p) * 2;
+    const char* xa = xs + rbase * STR + (16 * nhalf + 4 * p) * 2;
 
     f32x16 acc[KT], accb;
 #pragma unroll
@@ -364,78 +364,60 @@ static __global__ __launch_bounds__(256 * NC * KC) void wgrad16_kernel(const __b
     const bf16x8 zero8 = __builtin_convertvector(onesf * 0.f, bf16x8);
 
     // Register-staged, software-pipelined row slabs: the NEXT slab's 16-byte chunks are in flight
-    // while the current one is multiplied.  Rows past the end are clamped for the load and zeroed afterwards.
-    constexpr int NY = SLAB * (N / 8), NX = SLAB * (K / 8);          // 16-byte chunks per slab
-    constexpr int CHY = (NY + NTHR - 1) / NTHR, CHX = (NX + NTHR - 1) / NTHR;
-    bf16x8 py[CHY], px[CHX];
+    // while the current one is multiplied (one chunk at a time behind vmcnt(0) cost 8 HBM round
+    // trips per slab).  Rows past the end are clamped for the load and zeroed afterwards.
+    constexpr int CH = SLAB * 16 / 256;             // 16-byte chunks of each operand per thread and slab
+    bf16x8 py[CH], px[CH];
     auto fetch = [&](int rs) {
 #pragma unroll
-        for (int u = 0; u < CHY; ++u) {
-            const int idx = tid + NTHR * u;
-            if (NY % NTHR == 0 || idx < NY) {
-                const int rr = idx / (N / 8), c = idx - rr * (N / 8);
-                py[u] = *reinterpret_cast<const bf16x8*>(dY + (size_t)min(rs + rr, r1 - 1) * N + c * 8);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < CHX; ++u) {
-            const int idx = tid + NTHR * u;
-            if (NX % NTHR == 0 || idx < NX) {
-                const int rr = idx / (K / 8), c = idx - rr * (K / 8);
-                px[u] = *reinterpret_cast<const bf16x8*>(X + (size_t)min(rs + rr, r1 - 1) * K + c * 8);
-            }
+        for (int u = 0; u < CH; ++u) {
+            const int idx = tid + 256 * u, rr = idx >> 4, c = idx & 15;
+            const int row = min(rs + rr, r1 - 1);
+            py[u] = *reinterpret_cast<const bf16x8*>(dY + (size_t)row * N + ncol0 + c * 8);
+            px[u] = *reinterpret_cast<const bf16x8*>(X + (size_t)row * K + kcol0 + c * 8);
         }
     };
     fetch(r0);
     for (int rs = r0; rs < r1; rs += SLAB) {
         __syncthreads();   // previous pass fully consumed
 #pragma unroll
-        for (int u = 0; u < CHY; ++u) {
-            const int idx = tid + NTHR * u;
-            if (NY % NTHR == 0 || idx < NY) {
-                const int rr = idx / (N / 8), c = idx - rr * (N / 8);
-                *reinterpret_cast<bf16x8*>(ys + rr * YS + c * 16) = rs + rr < r1 ? py[u] : zero8;
-            }
-        }
+        for (int u = 0; u < CH; ++u) {
+            const int idx = tid + 256 * u, rr = idx >> 4, c = idx & 15;
+            const bool in = rs + rr < r1;
+            *reinterpret_cast<bf16x8*>(ys + rr * STR + c * 16) = in ? py[u] : zero8;
+            bf16x8 xv = px[u];
+            if constexpr (XGELU) {
+                f32x8 g = unpack8(xv);
 #pragma unroll
-        for (int u = 0; u < CHX; ++u) {
-            const int idx = tid + NTHR * u;
-            if (NX % NTHR == 0 || idx < NX) {
-                const int rr = idx / (K / 8), c = idx - rr * (K / 8);
-                bf16x8 xv = px[u];
-                if constexpr (XGELU) {
-                    f32x8 g = unpack8(xv);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) g[e] = gelu_tanh(g[e]);
-                    xv = __builtin_convertvector(g, bf16x8);
-                }
-                *reinterpret_cast<bf16x8*>(xs + rr * XS + c * 16) = rs + rr < r1 ? xv : zero8;
+                for (int e = 0; e < 8; ++e) g[e] = gelu_tanh(g[e]);
+                xv = __builtin_convertvector(g, bf16x8);
             }
+            *reinterpret_cast<bf16x8*>(xs + rr * STR + c * 16) = in ? xv : zero8;
         }
         __syncthreads();
         if (rs + SLAB < r1) fetch(rs + SLAB);
 #pragma unroll
         for (int s = 0; s < SLAB / 16; ++s) {
-            const bf16x8 af = join_tr(lds_tr16(ya + (16 * s) * YS), lds_tr16(ya + (16 * s + 4) * YS));
-            if (kc == 0) accb = mfma16(af, ones, accb);
+            const bf16x8 af = join_tr(lds_tr16(ya + (16 * s) * STR), lds_tr16(ya + (16 * s + 4) * STR));
+            if (blockIdx.z == 0) accb = mfma16(af, ones, accb);
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
-                const bf16x8 bf = join_tr(lds_tr16(xa + (16 * s) * XS + t * 64), lds_tr16(xa + (16 * s + 4) * XS + t * 64));
+                const bf16x8 bf = join_tr(lds_tr16(xa + (16 * s) * STR + t * 64), lds_tr16(xa + (16 * s + 4) * STR + t * 64));
                 acc[t] = mfma16(af, bf, acc[t]);
             }
         }
     }
-    // partial tiles of this workgroup: [(x * NC + nc) * KC + kc][128 n][128 k], bias sums [(x * NC + nc)][128]
+    // partial tile of this workgroup: [(x * gy + y) * gz + z][128 n][128 k], bias sums [(x * gy + y)][128]
     const int j = lane & 31;
-    float* pt = part + ((size_t)(blockIdx.x * NC + nc) * KC + kc) * (128 * 128);
+    float* pt = part + ((size_t)(blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * (128 * 128);
 #pragma unroll
     for (int t = 0; t < KT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pt[(sub * 32 + acc_row(r, half)) * 128 + t * 32 + j] = acc[t][r];
-    if (j == 0 && kc == 0) {
-        float* bp = bpart + (size_t)(blockIdx.x * NC + nc) * 128;
+        for (int r = 0; r < 16; ++r) pt[(wave * 32 + acc_row(r, half)) * 128 + t * 32 + j] = acc[t][r];
+    if (j == 0 && blockIdx.z == 0) {
+        float* bp = bpart + (size_t)(blockIdx.x * gridDim.y + blockIdx.y) * 128;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bp[sub * 32 + acc_row(r, half)] = accb[r];
+        for (int r = 0; r < 16; ++r) bp[wave * 32 + acc_row(r, half)] = accb[r];
     }
 }
 
@@ -493,21 +475,6 @@ inline size_t wgrad16_scratch_floats(int M, int n_cu) {      // worst case over 
     return worst;
 }
 
-template <int NC, int KC, bool XGELU>
-inline int launch_wgrad16_shape(const __bf16* dY, const __bf16* X, float* part, float* bpart, int M, int rows_per_wg, int gx,
-                                hipStream_t st) {
-    constexpr int lds = 64 * ((128 * NC * 2 + 64) + (128 * KC * 2 + 64));
-    static bool attr = false;   // first call is never under stream capture (training is not captured)
-    if (!attr) {
-        T2S_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16_kernel<NC, KC, XGELU>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = true;
-    }
-    wgrad16_kernel<NC, KC, XGELU><<<gx, 256 * NC * KC, lds, st>>>(dY, X, part, bpart, M, rows_per_wg);
-    T2S_LAUNCH_CHECK();
-    return T2S_OK;
-}
-
 template <bool XGELU = false>
 inline int launch_wgrad16(const __bf16* dY, const __bf16* X, float* dW, float* db, int M, int N, int K, float* scratch,
                           size_t scratch_floats, int n_cu, hipStream_t st) {
@@ -525,16 +492,8 @@ inline int launch_wgrad16(const __bf16* dY, const __bf16* X, float* dW, float* d
     }
     float* part = scratch;
     float* bpart = scratch + part_floats;
-    int rc;
-    if (gy == 1 && gz == 1) rc = launch_wgrad16_shape<1, 1, XGELU>(dY, X, part, bpart, M, rows_per_wg, gx, st);
-    else if (gy == 2 && gz == 1) rc = launch_wgrad16_shape<2, 1, XGELU>(dY, X, part, bpart, M, rows_per_wg, gx, st);
-    else if (gy == 1 && gz == 2) rc = launch_wgrad16_shape<1, 2, XGELU>(dY, X, part, bpart, M, rows_per_wg, gx, st);
-    else if (gy == 3 && gz == 1) rc = launch_wgrad16_shape<3, 1, XGELU>(dY, X, part, bpart, M, rows_per_wg, gx, st);
-    else {
-        set_error("wgrad16: no instantiation for N=%d K=%d (the DiT's linears are 128x128, 256x128, 128x256, 384x128)", N, K);
-        return T2S_E_INVALID;
-    }
-    if (rc != T2S_OK) return rc;
+    wgrad16_kernel<XGELU><<<dim3(gx, gy, gz), 256, 0, st>>>(dY, X, part, bpart, M, N, K, rows_per_wg);
+    T2S_LAUNCH_CHECK();
     wgrad16_reduce_kernel<<<dim3(65, gy * gz), 256, 0, st>>>(part, bpart, dW, db, gx, gy, gz, K);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
