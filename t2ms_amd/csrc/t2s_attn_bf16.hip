@@ -146,29 +146,11 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_fwd_kernel(const __b
     }
 }
 
-// ------------------------------------------------------------------ D_i = sum_d dO[i][d] * O[i][d]
-__global__ __launch_bounds__(256) void attn16_dsum_kernel(const __bf16* __restrict__ o_rows, const __bf16* __restrict__ do_rows,
-                                                          float* __restrict__ dsum, int M) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (token row, head): 32 bf16 = 64 B
-    if (idx >= M * NH) return;
-    const int row = idx >> 2, head = idx & 3;
-    const bf16x8* a = reinterpret_cast<const bf16x8*>(o_rows + (size_t)row * D + head * DH);
-    const bf16x8* b = reinterpret_cast<const bf16x8*>(do_rows + (size_t)row * D + head * DH);
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const f32x8 x = unpack8(a[c]), y = unpack8(b[c]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += x[e] * y[e];
-    }
-    const int seq = row / NTOK, tok = row - seq * NTOK;
-    dsum[((size_t)seq * NH + head) * NTOK + tok] = s;
-}
-
 // ------------------------------------------------------------------ kernel A: dQ (queries on lanes)
 __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_bwd_dq_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
-                                                            const __bf16* __restrict__ v, const __bf16* __restrict__ do_rows,
-                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                            const __bf16* __restrict__ v, const __bf16* __restrict__ o_rows,
+                                                            const __bf16* __restrict__ do_rows,
+                                                            const float* __restrict__ lse, float* __restrict__ dsum,
                                                             __bf16* __restrict__ dqkv) {
     __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
     char* Ks = smem;
@@ -191,7 +173,20 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_bwd_dq_kernel(const 
             dof[s] = *reinterpret_cast<const bf16x8*>(dorow + 16 * s);
         }
         const float lse_i = lse[(size_t)bh * NTOK + tok];
-        const float d_i = dsum[(size_t)bh * NTOK + tok];
+        // D_i = sum_d dO[i][d] O[i][d]: each lane half holds 16 of the query's 32 features; published for the dK/dV
+        // kernel (which runs next on the same stream) instead of a separate pass over o and do
+        float d_i = 0.f;
+        {
+            const __bf16* orow = o_rows + ((size_t)seq * NTOK + tok) * D + head * DH + 8 * half;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f32x8 ov = unpack8(*reinterpret_cast<const bf16x8*>(orow + 16 * s)), dv8 = unpack8(dof[s]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d_i += ov[e] * dv8[e];
+            }
+            d_i = pair_sum_f(d_i);
+            if (half == 0) dsum[(size_t)bh * NTOK + tok] = d_i;
+        }
         f32x16 dq, nl, nd;     // nl / nd: -lse_i / -D_i in all 16 registers, the C operands of the score / dP MFMAs
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -302,10 +297,7 @@ int attn16_train_fwd(const __bf16* q, const __bf16* k, const __bf16* v, __bf16* 
 
 int attn16_bwd(const __bf16* q, const __bf16* k, const __bf16* v, const __bf16* o_rows, const __bf16* do_rows,
                const float* lse, float* dsum, __bf16* dqkv_rows, int BH, hipStream_t st) {
-    const int M = (BH / NH) * NTOK;
-    attn16_dsum_kernel<<<(M * NH + 255) / 256, 256, 0, st>>>(o_rows, do_rows, dsum, M);
-    T2S_LAUNCH_CHECK();
-    attn16_bwd_dq_kernel<<<BH, 512, 0, st>>>(q, k, v, do_rows, lse, dsum, dqkv_rows);
+    attn16_bwd_dq_kernel<<<BH, 512, 0, st>>>(q, k, v, o_rows, do_rows, lse, dsum, dqkv_rows);   // also writes D_i -> dsum
     T2S_LAUNCH_CHECK();
     attn16_bwd_dkv_kernel<<<BH, 512, 0, st>>>(q, k, v, do_rows, lse, dsum, dqkv_rows);
     T2S_LAUNCH_CHECK();
