@@ -88,6 +88,11 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_fwd_kernel(const __b
         // are exponentiated against it without a max or an output rescale (the kernel is VALU-bound:
         // that is a third of its vector work).  A block whose row sum shows the reference is stale by
         // more than 2^40 re-references the running state (classic online-softmax step), wave-uniformly.
+        // (Round 2 measured hand-pipelined LDS reads here -- K fragments of block jb+1 fetched behind the score MFMAs of
+        // block jb, V^T fragments before the exponentials, four independent row-sum chains: no gain, 0.96 vs 0.94 ms per
+        // step in a same-box A/B; the other waves of the SIMD already cover those round trips.  PMC view of this kernel
+        // (tools/pmc_train.sh): VALU busy 56 %, matrix pipe 24 % (half of it co-executing), 31 % of the cycles neither,
+        // 2.7 of 4 wave slots occupied on average -- the per-workgroup K / V staging and the 15-tiles-over-8-waves tail.)
         float m_run = 0.f, l_lane = 0.f;    // m_run: the reference, in the log2 domain of the (pre-scaled) scores
         f32x16 negm;                        // -m_run in all 16 registers: the C operand of every score MFMA
         for (int jb = 0; jb < NKB; ++jb) {

@@ -758,3 +758,27 @@ def test_ts2vec_encoder_reference_fixture(golden_dir, dev):
         ra = O.ts2vec_encode(sd, torch.from_numpy(a))[1].numpy()
         rb = O.ts2vec_encode(sd, torch.from_numpy(b))[1].numpy()
     np.testing.assert_allclose(M.cfid(a, b, enc), O.eval_fid(ra, rb), rtol=2e-3)
+
+
+def test_sampler_set_row0_keeps_graph_and_matches_fresh_sampler(dev, vae):
+    """infer.py walks the test loader with ONE sampler: t2s_sampler_set_row0 moves it to another shard position without
+    re-capturing the hipGraph (the Philox row key is read from device memory).  The result must equal a sampler created
+    at that position, bit for bit, and the corresponding rows of one big batch (sharding invariance)."""
+    from t2ms_amd.sampler import Sampler
+    from model.denoiser.transformer import Transformer
+    m = Transformer()
+    m.load_state_dict(synth.make_dit_state_dict(31337, gain=0.7), strict=True)
+    m = m.to(dev).eval()
+    text = synth.make_text_embeddings(4, 6).to(dev)
+    big = Sampler(m, vae.decoder, "ddpm", 6, 7.0, 6, 48, dev, use_graph=True, seed=77, row0=10)
+    lat_big, ser_big, _ = big.run(text)
+    s = Sampler(m, vae.decoder, "ddpm", 6, 7.0, 3, 48, dev, use_graph=True, seed=77, row0=10)
+    lat_a, ser_a, _ = s.run(text[:3].contiguous())
+    ptr_before = s.ptr.value
+    s.set_row0(13)
+    lat_b, ser_b, _ = s.run(text[3:].contiguous())
+    assert s.ptr.value == ptr_before                                   # the C sampler (and its graph) was kept
+    fresh = Sampler(m, vae.decoder, "ddpm", 6, 7.0, 3, 48, dev, use_graph=True, seed=77, row0=13)
+    lat_c, ser_c, _ = fresh.run(text[3:].contiguous())
+    assert torch.equal(lat_b, lat_c) and torch.equal(ser_b, ser_c)
+    assert torch.equal(torch.cat([lat_a, lat_b]), lat_big) and torch.equal(torch.cat([ser_a, ser_b]), ser_big)

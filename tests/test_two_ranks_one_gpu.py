@@ -146,11 +146,26 @@ def test_two_rank_default_seed_is_rank0s(tmp_path):
     assert a["seed"] == b["seed"], (a, b)
 
 
+def test_two_rank_train_cli_with_groups_smaller_than_the_world(tmp_path):
+    """train.py itself under two ranks, mix-train (three length groups per batch) with batches so small that groups of ONE
+    row occur: the rank without rows must still join the all-reduce (round 1 returned early there: an RCCL hang).  The
+    run has to finish and rank 0 has to write the reference checkpoint dict."""
+    argv = ["--dataset_name", "ETTh1", "--backbone", "ddpm", "--denoiser", "DiT", "--total_step", "100", "--batch_size", "4",
+            "--epochs", "2", "--save_path", str(tmp_path / "res"), "--synthetic", "5", "--random_init", "--checkpoint_path", ""]
+    r = _launch([os.path.join(REPO, "train.py")] + argv, 29557, True, str(tmp_path), timeout=600)
+    ck = torch.load(tmp_path / "res" / "checkpoints" / "ddpm_DiT_ETTh1" / "model_1.pth", map_location="cpu")
+    assert set(ck) == {"model", "optimizer", "epoch", "loss_list"} and ck["epoch"] == 1
+    assert len(ck["loss_list"]) >= 6 and np.isfinite(ck["loss_list"]).all(), r.stdout[-1500:]
+    assert len(ck["optimizer"]["param_groups"][0]["params"]) == 67 and len(ck["optimizer"]["state"]) == 48
+
+
 def test_bench_two_ranks_prints_one_json_line(tmp_path):
     r = _launch([os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--diffusion-steps", "20",
-                 "--batch", "64", "--no-cpu-baseline", "--no-train"], 29556, True, REPO)
+                 "--batch", "64", "--no-cpu-baseline", "--train-batch", "32", "--train-steps", "3"], 29556, True, REPO)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["value"] > 0
     assert out["scaling"] == "weak" and out["steps"] == 1
+    tr = out["train"]                 # the training leg ran on both ranks with the gradient all-reduce in it
+    assert tr["global_batch"] == 64 and tr["value"] > 0 and 0.0 <= tr["allreduce_share"] < 1.0 and np.isfinite(tr["loss"])
