@@ -92,7 +92,11 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_fwd_kernel(const __b
         // block jb, V^T fragments before the exponentials, four independent row-sum chains: no gain, 0.96 vs 0.94 ms per
         // step in a same-box A/B; the other waves of the SIMD already cover those round trips.  PMC view of this kernel
         // (tools/pmc_train.sh): VALU busy 56 %, matrix pipe 24 % (half of it co-executing), 31 % of the cycles neither,
-        // 2.7 of 4 wave slots occupied on average -- the per-workgroup K / V staging and the 15-tiles-over-8-waves tail.)
+        // 2.7 of 4 wave slots occupied on average -- the per-workgroup K / V staging and the 15-tiles-over-8-waves tail.
+        // A persistent variant was built to remove exactly that (one 16-wave workgroup per CU walking 18 heads, the next
+        // head's K / V images arriving by LDS-DMA into a second buffer, Q fetched a head ahead, counted vmcnt so the
+        // output stores stay in flight across the per-head barrier): 1.01 vs 0.93 ms per step -- SLOWER; the barrier puts the
+        // 16 waves back into lockstep at every head (offsetting them with s_sleep changed nothing).  Dropped.)
         float m_run = 0.f, l_lane = 0.f;    // m_run: the reference, in the log2 domain of the (pre-scaled) scores
         f32x16 negm;                        // -m_run in all 16 registers: the C operand of every score MFMA
         for (int jb = 0; jb < NKB; ++jb) {
