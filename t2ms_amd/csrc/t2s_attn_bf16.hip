@@ -37,6 +37,34 @@ __device__ __forceinline__ float pair_sum_f(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// Store the 32 features of this lane pair's row (accumulator layout: the lane of half h holds features 8g + 4h + e) as
+// bf16 in TWO 16-byte pieces per lane: the halves first trade pieces with v_permlane32_swap so that half 0 owns features
+// 0..15 and half 1 features 16..31 -- a contiguous 64 bytes per row instead of eight scattered 8-byte pieces (which reach
+// HBM as partial lines at less than half the store rate).  `row32` points at feature 0 of the row.
+__device__ __forceinline__ void store_row32(__bf16* row32, const f32x16& acc, float scale, int half) {
+    uint32_t d[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 w = {acc[4 * g] * scale, acc[4 * g + 1] * scale, acc[4 * g + 2] * scale, acc[4 * g + 3] * scale};
+        const bf16x4 pk = pack4(w);
+        d[g][0] = __builtin_bit_cast(uint2, pk).x;
+        d[g][1] = __builtin_bit_cast(uint2, pk).y;
+    }
+    uint4 lo, hi;   // after the swaps: [features 8G..8G+3 | 8G+4..8G+7] for G = 2 half (lo) and 2 half + 1 (hi)
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const auto a = __builtin_amdgcn_permlane32_swap(d[0][w], d[2][w], false, false);   // pieces g = 0 and 2
+        const auto b = __builtin_amdgcn_permlane32_swap(d[1][w], d[3][w], false, false);   // pieces g = 1 and 3
+        (&lo.x)[w] = a[0];
+        (&lo.x)[2 + w] = a[1];
+        (&hi.x)[w] = b[0];
+        (&hi.x)[2 + w] = b[1];
+    }
+    uint4* dst = reinterpret_cast<uint4*>(row32 + 16 * half);
+    dst[0] = lo;
+    dst[1] = hi;
+}
+
 // stage 480 rows of 32 bf16 (64 B, src row stride in elements) into a swizzled image
 __device__ __forceinline__ void stage_img(char* img, const __bf16* src, int src_stride, int tid, int nthreads) {
     for (int idx = tid; idx < NTOK * 4; idx += nthreads) {
@@ -145,12 +173,7 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_fwd_kernel(const __b
         }
         const float l_tot = pair_sum_f(l_lane);
         const float inv = 1.0f / l_tot;
-        __bf16* orow = o_rows + ((size_t)seq * NTOK + tok) * D + head * DH + 4 * half;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 w = {ot[4 * g] * inv, ot[4 * g + 1] * inv, ot[4 * g + 2] * inv, ot[4 * g + 3] * inv};
-            *reinterpret_cast<bf16x4*>(orow + 8 * g) = pack4(w);
-        }
+        store_row32(o_rows + ((size_t)seq * NTOK + tok) * D + head * DH, ot, inv, half);
         if (half == 0) lse[(size_t)bh * NTOK + tok] = m_run + __builtin_amdgcn_logf(l_tot);   // v_log_f32 = log2
     }
 }
@@ -213,12 +236,7 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_bwd_dq_kernel(const 
 #pragma unroll
             for (int s = 0; s < 2; ++s) dq = mfma16(col_frag(Ks, jb * 32, lane, s), acc_frag(st, s), dq);   // dQ^T += K^T dS^T
         }
-        __bf16* dst = dqkv + ((size_t)seq * NTOK + tok) * (3 * D) + head * DH + 4 * half;   // dq block
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 w = {dq[4 * g] * SCALE, dq[4 * g + 1] * SCALE, dq[4 * g + 2] * SCALE, dq[4 * g + 3] * SCALE};
-            *reinterpret_cast<bf16x4*>(dst + 8 * g) = pack4(w);
-        }
+        store_row32(dqkv + ((size_t)seq * NTOK + tok) * (3 * D) + head * DH, dq, SCALE, half);   // dq block
     }
 }
 
@@ -287,14 +305,9 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_bwd_dkv_kernel(const
                 dk = mfma16(col_frag(Qs, qb * 32, lane, s), acc_frag(dp, s), dk);   // dK^T += Q^T dS
             }
         }
-        __bf16* dst = dqkv + ((size_t)seq * NTOK + key) * (3 * D) + head * DH + 4 * half;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 wk = {dk[4 * g] * LN2, dk[4 * g + 1] * LN2, dk[4 * g + 2] * LN2, dk[4 * g + 3] * LN2};   // Qs holds q ATT_QS
-            const f32x4 wv = {dv[4 * g], dv[4 * g + 1], dv[4 * g + 2], dv[4 * g + 3]};
-            *reinterpret_cast<bf16x4*>(dst + D + 8 * g) = pack4(wk);
-            *reinterpret_cast<bf16x4*>(dst + 2 * D + 8 * g) = pack4(wv);
-        }
+        __bf16* dst = dqkv + ((size_t)seq * NTOK + key) * (3 * D) + head * DH;
+        store_row32(dst + D, dk, LN2, half);        // Qs holds q ATT_QS: dK = dS^T (q ATT_QS) ln 2
+        store_row32(dst + 2 * D, dv, 1.0f, half);
     }
 }
 
