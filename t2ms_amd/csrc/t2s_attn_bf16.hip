@@ -124,7 +124,11 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_fwd_kernel(const __b
         // A persistent variant was built to remove exactly that (one 16-wave workgroup per CU walking 18 heads, the next
         // head's K / V images arriving by LDS-DMA into a second buffer, Q fetched a head ahead, counted vmcnt so the
         // output stores stay in flight across the per-head barrier): 1.01 vs 0.93 ms per step -- SLOWER; the barrier puts the
-        // 16 waves back into lockstep at every head (offsetting them with s_sleep changed nothing).  Dropped.)
+        // 16 waves back into lockstep at every head (offsetting them with s_sleep changed nothing).  Dropped.
+        // Also without effect: a one-time half-block s_sleep offset between the two waves a SIMD holds of a workgroup, and a
+        // software pipeline that issues the score MFMAs of block jb+1 before the exponentials of block jb (two alternating
+        // accumulators; 0.91 vs 0.91 ms).  What is left is the exponential itself: 16 v_exp per 4 MFMAs at head_dim 32 --
+        // the kernel does 4.7 T exp/s, the chip's v_exp issue rate is ~20 T/s only if nothing else used the port.)
         float m_run = 0.f, l_lane = 0.f;    // m_run: the reference, in the log2 domain of the (pre-scaled) scores
         f32x16 negm;                        // -m_run in all 16 registers: the C operand of every score MFMA
         for (int jb = 0; jb < NKB; ++jb) {
