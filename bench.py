@@ -13,6 +13,10 @@ One "step" = one pass of the hot path over one batch: x_T (Philox, on device) ->
 Multi-GPU = weak scaling: every rank samples its own 256-series shard (global rows
 [256*rank, 256*rank+256) of the Philox stream); no data-path collective, RCCL only for the
 barrier and the max-over-ranks time.
+
+The same JSON line carries, as extra keys: `roofline` (dominant kernel, in-situ HIP-event timing), `cpu_baseline` (the
+oracle on the host cores, N=1 only), `alt_math` (the opt-in bf16x3 arithmetic, N=1 only) and `train` (BASELINE
+configs[3] shape: the bf16 DiT training step of train.py at B=1152 per GPU with the gradient all-reduce at N>1).
 """
 import argparse
 import json
