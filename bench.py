@@ -397,7 +397,12 @@ def main():
     }
     train = None
     if not args.no_train:
-        train = train_leg(dev, dist, rank, world, batch=args.train_batch, steps=args.train_steps)
+        try:
+            train = train_leg(dev, dist, rank, world, batch=args.train_batch, steps=args.train_steps)
+        except Exception as e:          # the headline line must still be printed; the failure is reported in it
+            import traceback
+            traceback.print_exc()
+            train = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         # roofline of the dominant kernel (fused attention; 48 % of all FLOPs), same shapes as the workload
         kt = time_kernels_in_situ(model, dev, lat.clone(), text)
