@@ -73,6 +73,24 @@ __device__ __forceinline__ void stage_img(char* img, const __bf16* src, int src_
     }
 }
 
+// The same image filled by LDS-DMA (no registers, asynchronous): piece p of 30 = rows [16p, 16p+16) = 1 KiB; lane l writes
+// LDS bytes [16 l, 16 l + 16) of the piece = row 16p + (l>>2), swizzled chunk l&3, so it FETCHES chunk (l&3) ^ ((row>>2)&3).
+// hipcc compiled stage_img's loop as load -> s_waitcnt vmcnt(0) -> ds_write per iteration: eight serialized HBM round trips
+// per workgroup before its first MFMA (a forward kernel run with ONE key block instead of 15 still took 63 % of the time).
+__device__ __forceinline__ void dma_img_piece(char* img, const __bf16* src, int src_stride, int p, int lane) {
+    const int row = 16 * p + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    glds16(reinterpret_cast<const f32x4*>(src + (size_t)row * src_stride + chunk * 8), reinterpret_cast<f32x4*>(img + p * 1024));
+}
+// two images (60 pieces) over the 8 waves of a workgroup; complete after s_waitcnt vmcnt(0) + barrier
+__device__ __forceinline__ void dma_two_images(char* img_a, const __bf16* src_a, int stride_a, char* img_b, const __bf16* src_b,
+                                               int stride_b, int wave, int lane) {
+    for (int p = wave; p < 60; p += 8) {
+        if (p < 30) dma_img_piece(img_a, src_a, stride_a, p, lane);
+        else dma_img_piece(img_b, src_b, stride_b, p - 30, lane);
+    }
+}
+
 // operand with the image row (token base + lane&31) on the lane: k = feature 16s + 8h + 0..7
 __device__ __forceinline__ bf16x8 row_frag(const char* img, int base, int lane, int s) {
     return *reinterpret_cast<const bf16x8*>(img + img_off(base + (lane & 31), 2 * s + (lane >> 5)));
@@ -100,8 +118,8 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_fwd_kernel(const __b
     const int lane = tid & 63, half = lane >> 5, i = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int seq = bh / NH, head = bh % NH;
-    stage_img(Ks, k + (size_t)bh * NTOK * DH, DH, tid, 512);
-    stage_img(Vs, v + (size_t)bh * NTOK * DH, DH, tid, 512);
+    dma_two_images(Ks, k + (size_t)bh * NTOK * DH, DH, Vs, v + (size_t)bh * NTOK * DH, DH, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_sync();
     const __bf16* qg = q + (size_t)bh * NTOK * DH;
     for (int qt = wave; qt < NKB; qt += 8) {
@@ -195,8 +213,8 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_bwd_dq_kernel(const 
     const int lane = tid & 63, half = lane >> 5, i = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int seq = bh / NH, head = bh % NH;
-    stage_img(Ks, k + (size_t)bh * NTOK * DH, DH, tid, 512);
-    stage_img(Vs, v + (size_t)bh * NTOK * DH, DH, tid, 512);
+    dma_two_images(Ks, k + (size_t)bh * NTOK * DH, DH, Vs, v + (size_t)bh * NTOK * DH, DH, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_sync();
     const __bf16* qg = q + (size_t)bh * NTOK * DH;
     for (int qt = wave; qt < NKB; qt += 8) {
@@ -258,12 +276,12 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_bwd_dkv_kernel(const
     const int lane = tid & 63, half = lane >> 5, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int seq = bh / NH, head = bh % NH;
-    stage_img(Qs, q + (size_t)bh * NTOK * DH, DH, tid, 512);
-    stage_img(Os, do_rows + (size_t)seq * NTOK * D + head * DH, D, tid, 512);
+    dma_two_images(Qs, q + (size_t)bh * NTOK * DH, DH, Os, do_rows + (size_t)seq * NTOK * D + head * DH, D, wave, lane);
     for (int t = tid; t < NTOK; t += 512) {
         Ls[t] = -lse[(size_t)bh * NTOK + t];      // negated: they initialise the accumulators (C operands) below
         Ds[t] = -dsum[(size_t)bh * NTOK + t];
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_sync();
     const __bf16* kg = k + (size_t)bh * NTOK * DH;
     const __bf16* vg = v + (size_t)bh * NTOK * DH;
