@@ -287,7 +287,7 @@ class Transformer(nn.Module):
 
     def __getstate__(self):
         state = self.__dict__.copy()
-        for k in ("_t2s_h", "_t2s_dev", "_t2s_stamp", "_t2s_math_applied"):
+        for k in ("_t2s_h", "_t2s_dev", "_t2s_stamp", "_t2s_math_applied", "_t2s_bucket", "_t2s_flat_grad", "_t2s_fwd_gen"):
             state.pop(k, None)
         return state
 

@@ -317,3 +317,23 @@ def test_backward_fails_loudly_after_a_second_grad_forward(dev):
     g1 = m.layers[0].attn.qkv.weight.grad.clone()
     mse_loss(m(input=x * 2, t=t, text_input=None), x).backward()
     torch.testing.assert_close(m.layers[0].attn.qkv.weight.grad, 2 * g1, rtol=1e-5, atol=1e-8)
+
+
+def test_model_pickles_after_a_training_step(dev):
+    """The handle, the packed weights and the persistent gradient bucket (device pointers in ctypes structs) are process
+    state, not model state: a module that has trained still pickles / deep-copies (whole-module checkpoints, infer.py:39
+    style) and the copy trains on."""
+    import copy
+    import pickle
+    from t2ms_amd.train import mse_loss
+    m = _model(dev)
+    x = synth.make_latents(1, 2).to(dev)
+    t = torch.tensor([3, 4], device=dev)
+    mse_loss(m(input=x, t=t, text_input=None), x).backward()
+    blob = pickle.dumps(m)
+    m2 = pickle.loads(blob)
+    m3 = copy.deepcopy(m)
+    for mm in (m2, m3):
+        mm.zero_grad()
+        mse_loss(mm(input=x, t=t, text_input=None), x).backward()
+        torch.testing.assert_close(mm.layers[0].attn.qkv.weight.grad, m.layers[0].attn.qkv.weight.grad, rtol=1e-5, atol=1e-9)
