@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dY
 // written as ONE partial row per workgroup (FINAL_COLS / PATCH_COLS floats); tail_reduce_kernel then adds the partial
 // rows in workgroup order -- deterministic, and without the ~800 K same-address fp32 atomics the round-1 kernels
 // flushed with (they were most of these kernels' 0.3 ms each at B=1152).
-constexpr int TAIL_ROWS = 512;
+constexpr int TAIL_ROWS = 256;
 constexpr int FINAL_COLS = 772;   // ln.weight 128 | ln.bias 128 | linear_emb_to_patch.weight 4x128 | .bias 4
 constexpr int PATCH_COLS = 660;   // patch_emb.weight 128x4 | .bias 128 | conv.weight 16 | conv.bias 4
 
@@ -337,52 +337,61 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
     f32x4 a_g = {0, 0, 0, 0}, a_b = {0, 0, 0, 0}, a_w[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     float a_ob[4] = {0.f, 0.f, 0.f, 0.f};
     const int row0 = blockIdx.x * TAIL_ROWS;
-#pragma unroll 4
-    for (int it = 0; it < TAIL_ROWS / 8; ++it) {            // 4 rows of a wave in flight: the shuffle chains overlap
-        const int rr = rg + 8 * it;
-        const bool valid = row0 + rr < M;                  // rows past the end: clamped, their contributions masked
-        const int row = valid ? row0 + rr : M - 1;
-        const float keep = valid ? 1.f : 0.f;
-        const size_t idx = (size_t)row * 32 + c4;
-        const f32x4 xv = reinterpret_cast<const f32x4*>(x)[idx];
-        float s = (xv.x + xv.y) + (xv.z + xv.w);
+    for (int it0 = 0; it0 < TAIL_ROWS / 8; it0 += 4) {      // 4 rows per 32-lane group in flight: loads first, then the chains
+        f32x4 xv4[4];
+        float dl4[4][4];
+        bool valid4[4];
+        size_t idx4[4];
 #pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-        const float mean = s * (1.0f / 128.0f);
-        const f32x4 d = xv - mean;
-        float ss = (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        for (int u = 0; u < 4; ++u) {
+            const int rr = rg + 8 * (it0 + u);
+            valid4[u] = row0 + rr < M;                      // rows past the end: clamped, their contributions masked
+            const int row = valid4[u] ? row0 + rr : M - 1;
+            idx4[u] = (size_t)row * 32 + c4;
+            xv4[u] = reinterpret_cast<const f32x4*>(x)[idx4[u]];
+            // gather d(lin)[p] from the unpatchified output gradient
+            const int seq = row / NTOK, tok = row - seq * NTOK;
+            const int hh = tok >> 5, ww = tok & 31;
+            const float keep = valid4[u] ? 1.f : 0.f;
 #pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        const float rstd = rsqrtf(ss * (1.0f / 128.0f) + 1e-5f);
-        const f32x4 n = d * rstd;
-        const f32x4 y = n * gam + bet;
-        // gather d(lin)[p] from the unpatchified output gradient
-        const int seq = row / NTOK, tok = row - seq * NTOK;
-        const int hh = tok >> 5, ww = tok & 31;
-        float dl[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            dl[p] = keep * dout[(size_t)seq * LAT + (2 * ww + (p & 1)) * LATW + 2 * hh + (p >> 1)];
-        f32x4 dy = {0, 0, 0, 0};
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            dy += w[p] * dl[p];
-            a_w[p] += y * dl[p];
-            a_ob[p] += dl[p];
+            for (int p = 0; p < 4; ++p)
+                dl4[u][p] = keep * dout[(size_t)seq * LAT + (2 * ww + (p & 1)) * LATW + 2 * hh + (p >> 1)];
         }
-        a_g += dy * n;
-        a_b += dy;
-        const f32x4 dn = dy * gam;
-        float m1 = (dn.x + dn.y) + (dn.z + dn.w);
-        float m2 = (dn.x * n.x + dn.y * n.y) + (dn.z * n.z + dn.w * n.w);
 #pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) {
-            m1 += __shfl_xor(m1, o, 64);
-            m2 += __shfl_xor(m2, o, 64);
+        for (int u = 0; u < 4; ++u) {
+            const f32x4 xv = xv4[u];
+            float s = (xv.x + xv.y) + (xv.z + xv.w);
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+            const float mean = s * (1.0f / 128.0f);
+            const f32x4 d = xv - mean;
+            float ss = (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            const float rstd = rsqrtf(ss * (1.0f / 128.0f) + 1e-5f);
+            const f32x4 n = d * rstd;
+            const f32x4 y = n * gam + bet;
+            f32x4 dy = {0, 0, 0, 0};
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                dy += w[p] * dl4[u][p];
+                a_w[p] += y * dl4[u][p];
+                a_ob[p] += dl4[u][p];
+            }
+            a_g += dy * n;
+            a_b += dy;
+            const f32x4 dn = dy * gam;
+            float m1 = (dn.x + dn.y) + (dn.z + dn.w);
+            float m2 = (dn.x * n.x + dn.y * n.y) + (dn.z * n.z + dn.w * n.w);
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) {
+                m1 += __shfl_xor(m1, o, 64);
+                m2 += __shfl_xor(m2, o, 64);
+            }
+            m1 *= (1.0f / 128.0f);
+            m2 *= (1.0f / 128.0f);
+            if (valid4[u]) reinterpret_cast<f32x4*>(dx)[idx4[u]] = (dn - m1 - n * m2) * rstd;
         }
-        m1 *= (1.0f / 128.0f);
-        m2 *= (1.0f / 128.0f);
-        if (valid) reinterpret_cast<f32x4*>(dx)[idx] = (dn - m1 - n * m2) * rstd;
     }
     red[0][rg][c4] = a_g;
     red[1][rg][c4] = a_b;
@@ -404,87 +413,77 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
     }
 }
 
-// patchify backward (transformer.py:166-172): dtok (M,128) -> grads of patch_emb.{weight,bias}, conv.{weight,bias}
+// patchify backward (transformer.py:166-172): dtok (M,128) -> grads of patch_emb.{weight,bias}, conv.{weight,bias}.
+// With g = dtok row, px = the token's 2x2 latent patch, cv = conv(px):
+//   d patch_emb.weight[d][c] = sum_rows g[d] cv[c] = sum_ij conv.w[c][ij] G[d][ij] + conv.b[c] PB[d]
+//   d conv.weight[c][ij]     = sum_rows (sum_d g[d] Wpe[d][c]) px[ij] = sum_d Wpe[d][c] G[d][ij],   d conv.bias[c] = sum_d Wpe[d][c] PB[d]
+// where G[d][ij] = sum_rows g[d] px[ij] and PB[d] = sum_rows g[d]: the row loop only accumulates G and PB (20 FMAs per
+// lane and row, no cross-lane step) and the contractions with the weights run once per workgroup.
 __global__ __launch_bounds__(256) void patchify_bwd_kernel(const float* __restrict__ dtok, const float* __restrict__ lat,
                                                            int B, const float* __restrict__ cw, const float* __restrict__ cb,
                                                            const float* __restrict__ pw, float* __restrict__ part, int M) {
     __shared__ f32x4 red[5][8][32];
-    __shared__ float redc[8][20];
+    __shared__ float Gs[4][D], PBs[D];
     const int c4 = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    f32x4 wpe[4];   // patch_emb.weight[d][c] for d = 4*c4+e
-#pragma unroll
-    for (int e = 0; e < 4; ++e) wpe[e] = *reinterpret_cast<const f32x4*>(pw + (c4 * 4 + e) * 4);
-    f32x4 a_pw[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // [c] over the lane's 4 features
+    f32x4 G[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // [ij] over the lane's 4 features
     f32x4 a_pb = {0, 0, 0, 0};
-    float a_cw[16], a_cb[4];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) a_cw[i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a_cb[i] = 0.f;
     const int row0 = blockIdx.x * TAIL_ROWS;
-#pragma unroll 4
-    for (int it = 0; it < TAIL_ROWS / 8; ++it) {
-        const int rr = rg + 8 * it;
-        const bool valid = row0 + rr < M;
-        const int row = valid ? row0 + rr : M - 1;
-        f32x4 g = reinterpret_cast<const f32x4*>(dtok)[(size_t)row * 32 + c4];
-        if (!valid) g = g * 0.f;
-        const int seq = row / NTOK, tok = row - seq * NTOK;
-        const int hh = tok >> 5, ww = tok & 31;
-        const float* xin = lat + (size_t)(seq % B) * LAT;
-        float px[4];   // [i*2+j] = in[2hh+i][2ww+j]
+    for (int it0 = 0; it0 < TAIL_ROWS / 8; it0 += 4) {
+        f32x4 g4[4];
+        float px4[4][4];   // [u][i*2+j] = in[2hh+i][2ww+j]
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int u = 0; u < 4; ++u) {
+            const int rr = rg + 8 * (it0 + u);
+            const bool valid = row0 + rr < M;
+            const int row = valid ? row0 + rr : M - 1;
+            g4[u] = reinterpret_cast<const f32x4*>(dtok)[(size_t)row * 32 + c4];
+            if (!valid) g4[u] = g4[u] * 0.f;
+            const int seq = row / NTOK, tok = row - seq * NTOK;
+            const int hh = tok >> 5, ww = tok & 31;
+            const float* xin = lat + (size_t)(seq % B) * LAT;
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) px[i * 2 + jj] = xin[(2 * ww + jj) * LATW + 2 * hh + i];
-        float cv[4];
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            cv[c] = cw[c * 4] * px[0] + cw[c * 4 + 1] * px[1] + cw[c * 4 + 2] * px[2] + cw[c * 4 + 3] * px[3] + cb[c];
-        float dc[4];   // dconv[c] = sum_d dtok[d] * Wpe[d][c]
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float s = g.x * wpe[0][c] + g.y * wpe[1][c] + g.z * wpe[2][c] + g.w * wpe[3][c];
-#pragma unroll
-            for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-            dc[c] = s;
-            a_pw[c] += g * cv[c];
+                for (int jj = 0; jj < 2; ++jj) px4[u][i * 2 + jj] = xin[(2 * ww + jj) * LATW + 2 * hh + i];
         }
-        a_pb += g;
-        if (c4 == 0) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                a_cb[c] += dc[c];
+        for (int u = 0; u < 4; ++u) {
 #pragma unroll
-                for (int ij = 0; ij < 4; ++ij) a_cw[c * 4 + ij] += dc[c] * px[ij];
-            }
+            for (int ij = 0; ij < 4; ++ij) G[ij] += g4[u] * px4[u][ij];
+            a_pb += g4[u];
         }
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) red[c][rg][c4] = a_pw[c];
+    for (int ij = 0; ij < 4; ++ij) red[ij][rg][c4] = G[ij];
     red[4][rg][c4] = a_pb;
-    if (c4 == 0) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) redc[rg][i] = a_cw[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) redc[rg][16 + i] = a_cb[i];
-    }
     __syncthreads();
     if (rg < 5) {
         f32x4 s = red[rg][0][c4];
 #pragma unroll
         for (int i = 1; i < 8; ++i) s += red[rg][i][c4];
-        float* prow = part + (size_t)blockIdx.x * PATCH_COLS;
-        if (rg < 4) {   // g_pw[d][c], d = 4*c4+e, c = rg
+        if (rg < 4) *reinterpret_cast<f32x4*>(&Gs[rg][c4 * 4]) = s;
+        else *reinterpret_cast<f32x4*>(&PBs[c4 * 4]) = s;
+    }
+    __syncthreads();
+    float* prow = part + (size_t)blockIdx.x * PATCH_COLS;
+    if (rg < 4) {   // patch_emb.weight[d][c], d = 4*c4+e, c = rg
 #pragma unroll
-            for (int e = 0; e < 4; ++e) prow[(c4 * 4 + e) * 4 + rg] = s[e];
-        } else {
-            *reinterpret_cast<f32x4*>(prow + 512 + c4 * 4) = s;
+        for (int e = 0; e < 4; ++e) {
+            const int d = c4 * 4 + e;
+            float acc = cw[rg * 4] * Gs[0][d];
+            acc += cw[rg * 4 + 1] * Gs[1][d];
+            acc += cw[rg * 4 + 2] * Gs[2][d];
+            acc += cw[rg * 4 + 3] * Gs[3][d];
+            prow[d * 4 + rg] = acc + cb[rg] * PBs[d];
         }
-    } else if (rg == 5 && c4 < 20) {
-        float s = 0.f;
-        for (int i = 0; i < 8; ++i) s += redc[i][c4];
-        part[(size_t)blockIdx.x * PATCH_COLS + 640 + c4] = s;     // conv.weight 16 | conv.bias 4
+    } else if (rg == 4) {
+        *reinterpret_cast<f32x4*>(prow + 512 + c4 * 4) = *reinterpret_cast<const f32x4*>(&PBs[c4 * 4]);
+    } else if (rg == 5 && c4 < 20) {   // conv.weight[c][ij] (16) | conv.bias[c] (4): one thread per output, d in order
+        const int c = c4 < 16 ? c4 >> 2 : c4 - 16;
+        const float* src = c4 < 16 ? Gs[c4 & 3] : PBs;
+        float acc = 0.f;
+        for (int d = 0; d < D; ++d) acc += pw[d * 4 + c] * src[d];
+        prow[640 + c4] = acc;
     }
 }
 
@@ -564,73 +563,103 @@ __global__ __launch_bounds__(256) void patchify_rows_kernel(const float* __restr
                                                             const float* __restrict__ cw, const float* __restrict__ cb,
                                                             const float* __restrict__ pw, const float* __restrict__ pb,
                                                             const float* __restrict__ pos) {
+    // one thread = 4 features of token n for FOUR series: the weights, bias and position row are loaded once per thread
+    // and the four 16-byte stores are independent (one series per thread ran at 2.6 TB/s of pure stores)
+    constexpr int SPT = 4;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= S * NTOK * 32) return;
-    const int c4 = gid & 31, tokg = gid >> 5;
-    const int s = tokg / NTOK, n = tokg - s * NTOK;
+    const int c4 = gid & 31, rest = gid >> 5;
+    const int sg = rest / NTOK, n = rest - sg * NTOK;
+    if (sg * SPT >= S) return;
     const int hh = n >> 5, ww = n & 31;
-    const float* xin = x + (size_t)s * LAT;
-    float px[4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) px[i * 2 + j] = xin[(2 * ww + j) * LATW + 2 * hh + i];
-    float cv[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        float acc = cw[c * 4 + 0] * px[0];
-        acc += cw[c * 4 + 1] * px[1];
-        acc += cw[c * 4 + 2] * px[2];
-        acc += cw[c * 4 + 3] * px[3];
-        cv[c] = acc + cb[c];
-    }
-    f32x4 o;
+    f32x4 w[4], bias, posr;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int d = c4 * 4 + e;
-        const f32x4 w = *reinterpret_cast<const f32x4*>(pw + d * 4);
-        float acc = w.x * cv[0];
-        acc += w.y * cv[1];
-        acc += w.z * cv[2];
-        acc += w.w * cv[3];
-        o[e] = acc + pb[d] + pos[n * D + d];
+        w[e] = *reinterpret_cast<const f32x4*>(pw + d * 4);
+        bias[e] = pb[d];
+        posr[e] = pos[n * D + d];
     }
-    reinterpret_cast<f32x4*>(h)[gid] = o;
+    float px[SPT][4];
+#pragma unroll
+    for (int u = 0; u < SPT; ++u) {
+        const int s = sg * SPT + u < S ? sg * SPT + u : S - 1;
+        const float* xin = x + (size_t)s * LAT;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) px[u][i * 2 + j] = xin[(2 * ww + j) * LATW + 2 * hh + i];
+    }
+#pragma unroll
+    for (int u = 0; u < SPT; ++u) {
+        const int s = sg * SPT + u;
+        float cv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float acc = cw[c * 4 + 0] * px[u][0];
+            acc += cw[c * 4 + 1] * px[u][1];
+            acc += cw[c * 4 + 2] * px[u][2];
+            acc += cw[c * 4 + 3] * px[u][3];
+            cv[c] = acc + cb[c];
+        }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float acc = w[e].x * cv[0];
+            acc += w[e].y * cv[1];
+            acc += w[e].z * cv[2];
+            acc += w[e].w * cv[3];
+            o[e] = acc + bias[e] + posr[e];
+        }
+        if (s < S) reinterpret_cast<f32x4*>(h)[((size_t)s * NTOK + n) * 32 + c4] = o;
+    }
 }
 
 // final layer, row-major input (transformer.py:182-191)
 __global__ __launch_bounds__(256) void final_rows_kernel(const float* __restrict__ h, int S, const float* __restrict__ lnw,
                                                          const float* __restrict__ lnb, const float* __restrict__ ow,
                                                          const float* __restrict__ ob, float* __restrict__ out) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c4 = gid & 31;
-    int tokg = gid >> 5;
-    const bool valid = tokg < S * NTOK;
-    if (!valid) tokg = S * NTOK - 1;
-    const f32x4 v = reinterpret_cast<const f32x4*>(h)[(size_t)tokg * 32 + c4];
-    float s1 = (v.x + v.y) + (v.z + v.w);
+    // 32 lanes per token row, FOUR rows per group in flight: a row is 3 dependent butterfly reductions (mean, variance,
+    // the four output dots) and one row per group left the kernel latency-bound at 2.7 TB/s
+    constexpr int RPG = 4;
+    const int c4 = threadIdx.x & 31;
+    const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int M = S * NTOK;
+    const f32x4 gam = *reinterpret_cast<const f32x4*>(lnw + c4 * 4), bet = *reinterpret_cast<const f32x4*>(lnb + c4 * 4);
+    f32x4 w[4];
 #pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o, 64);
-    const float mean = s1 * (1.0f / 128.0f);
-    const f32x4 d = v - mean;
-    float s2 = (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    for (int p = 0; p < 4; ++p) w[p] = *reinterpret_cast<const f32x4*>(ow + p * D + c4 * 4);
+    f32x4 v[RPG];
+    int tok[RPG];
 #pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
-    const float rstd = rsqrtf(s2 * (1.0f / 128.0f) + 1e-5f);
-    const f32x4 y = (d * rstd) * *reinterpret_cast<const f32x4*>(lnw + c4 * 4) + *reinterpret_cast<const f32x4*>(lnb + c4 * 4);
-    float acc[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(ow + p * D + c4 * 4);
-        float a = (y.x * w.x + y.y * w.y) + (y.z * w.z + y.w * w.w);
-#pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
-        acc[p] = a + ob[p];
+    for (int u = 0; u < RPG; ++u) {
+        tok[u] = grp * RPG + u;
+        v[u] = reinterpret_cast<const f32x4*>(h)[(size_t)(tok[u] < M ? tok[u] : M - 1) * 32 + c4];
     }
-    if (valid && c4 < 4) {
-        const int s = tokg / NTOK, n = tokg - s * NTOK;
-        const int hh = n >> 5, ww = n & 31;
-        out[(size_t)s * LAT + (2 * ww + (c4 & 1)) * LATW + 2 * hh + (c4 >> 1)] = acc[c4];
+#pragma unroll
+    for (int u = 0; u < RPG; ++u) {
+        float s1 = (v[u].x + v[u].y) + (v[u].z + v[u].w);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+        const float mean = s1 * (1.0f / 128.0f);
+        const f32x4 d = v[u] - mean;
+        float s2 = (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+        const float rstd = rsqrtf(s2 * (1.0f / 128.0f) + 1e-5f);
+        const f32x4 y = (d * rstd) * gam + bet;
+        float acc[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float a = (y.x * w[p].x + y.y * w[p].y) + (y.z * w[p].z + y.w * w[p].w);
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
+            acc[p] = a + ob[p];
+        }
+        if (tok[u] < M && c4 < 4) {
+            const int s = tok[u] / NTOK, n = tok[u] - s * NTOK;
+            const int hh = n >> 5, ww = n & 31;
+            out[(size_t)s * LAT + (2 * ww + (c4 & 1)) * LATW + 2 * hh + (c4 >> 1)] = acc[c4];
+        }
     }
 }
 
@@ -894,7 +923,7 @@ int t2s_dit_train_forward(t2s_dit* h, const t2s_dit_weights* w, const float* x, 
     if ((rc = gemm<128, 3, PRO_PLAIN, EPI_BIAS>(ws->silu_c, h->ada_p, h->ada_b, ws->mod, S, MODROW, st))) return rc;
     }
     { TimeScope ts(h, TC_TR_TAIL, st);
-    patchify_rows_kernel<<<(S * NTOK * 32 + 255) / 256, 256, 0, st>>>(x, ws->x_in[0], S, h->conv_w, h->conv_b, h->patch_w,
+    patchify_rows_kernel<<<((S + 3) / 4 * NTOK * 32 + 255) / 256, 256, 0, st>>>(x, ws->x_in[0], S, h->conv_w, h->conv_b, h->patch_w,
                                                                       h->patch_b, h->pos);
     T2S_LAUNCH_CHECK();
     }
@@ -970,7 +999,7 @@ int t2s_dit_train_forward(t2s_dit* h, const t2s_dit_weights* w, const float* x, 
         }
     }
     { TimeScope ts(h, TC_TR_TAIL, st);
-    final_rows_kernel<<<(M * 32 + 255) / 256, 256, 0, st>>>(ws->x_in[NBLK], S, h->ln_w, h->ln_b, h->out_w, h->out_b, out);
+    final_rows_kernel<<<((M + 3) / 4 * 32 + 255) / 256, 256, 0, st>>>(ws->x_in[NBLK], S, h->ln_w, h->ln_b, h->out_w, h->out_b, out);
     T2S_LAUNCH_CHECK();
     }
     return T2S_OK;
