@@ -93,7 +93,7 @@ static __global__ void pack16_kernel(const float* __restrict__ W, __bf16* __rest
 
 // ------------------------------------------------------------------------------------------ bgemm
 enum { BPRO_BF16 = 0, BPRO_LN = 1, BPRO_GELU = 2, BPRO_LN_RES = 3 };
-enum { BEPI_BF16 = 0, BEPI_QKV = 1, BEPI_GELUBWD = 2 };
+enum { BEPI_BF16 = 0, BEPI_QKV = 1, BEPI_GELUBWD = 2, BEPI_LNBWD = 3 };
 
 struct BGemmArgs {
     const void* A;        // BPRO_LN: float (M,128) residual stream; otherwise bf16 (M,K)
@@ -113,6 +113,15 @@ struct BGemmArgs {
     __bf16* q;            // BEPI_QKV destinations, each (S*4, 480, 32)
     __bf16* k;
     __bf16* v;
+    // BEPI_LNBWD (N = 128): the product is da = grad wrt modulate(LN(ln_x)); the epilogue is the LayerNorm + modulate
+    // backward of ln_mod_bwd_kernel (t2s_train.hip) on the accumulators: dx += rstd (dn - mean(dn) - n mean(dn n)),
+    // dn = da (1 + scale), and -- when res != NULL -- the gate backward of the branch differentiated next on the dx just
+    // produced: out = mod[gate_off] * dx (bf16), dgate = sum_tok dx * res.  The three per-sequence column sums
+    // (dshift = sum da, dscale = sum da n, dgate) leave as one partial row per 32-token tile: colpart (M/32, 3, 128),
+    // added over the 15 tiles of a sequence, in tile order, by lnbwd_colsum_reduce_kernel.
+    const float* ln_x;
+    float* dx;
+    float* colpart;
 };
 
 // Weights-stationary streaming GEMM: one persistent workgroup of 12 waves per CU keeps the whole
@@ -121,12 +130,139 @@ struct BGemmArgs {
 // (lane-linear 16-byte fragments: conflict-free ds_read_b128) -> epilogue stores.  No barrier after
 // the weight load; HBM latency is hidden by the three waves per SIMD.
 constexpr int BG_THREADS = 768;
+// The LayerNorm-backward epilogue holds a 32 x 128 fp32 product AND the matching LayerNorm input per wave (2 x 64
+// registers per lane before any temporaries): 8 waves per workgroup (256 registers per lane) instead of 12 (168, where
+// hipcc spilled 94 of them to scratch).
+constexpr int bg_threads(int epi) { return epi == 3 ? 512 : 768; }
 constexpr int BG_STAGE_STRIDE = 144;                     // bytes per staged token row (128 data + 16 pad)
 constexpr int BG_STAGE_BYTES = 32 * BG_STAGE_STRIDE;     // per wave
 
+// BEPI_LNBWD on one 32-token tile: acc = da (lane = token i, half h; register 4g+e of n-tile nt = feature 32nt + 8g + 4h + e).
+// The pointers are __restrict__ ON PURPOSE although dx_rows and dx_tile are the same tensor: no element is loaded after
+// it was stored, and without the promise every load inside the n-tile loops waits behind the previous n-tile's stores
+// (measured: 36 us per tile and wave, a dozen serialized HBM round trips).
+//   x_rows / dx_rows / res_rows: this lane's token row + 4h;  dx_tile / out_tile: row 0 of the tile;  mrow: LDS, scale
+//   row (+128: next gate row) + 4h;  stage: the wave's 32 x 144-byte staging tile, used in program order for the column
+//   sums over the 32 tokens (each lane writes its row pieces, then adds one column over 16 rows + the other half), the
+//   fp32 dx rows and the bf16 out rows, which leave as whole 128-byte lines.
+__device__ __forceinline__ void lnbwd_epilogue(f32x16 (&acc)[4], const float* __restrict__ x_rows, const float* __restrict__ dx_rows,
+                                               float* __restrict__ dx_tile, const __bf16* __restrict__ res_rows,
+                                               __bf16* __restrict__ out_tile, float* __restrict__ cp, const float* mrow,
+                                               char* stage, int lane) {
+    const int h = lane >> 5, i = lane & 31;
+    f32x4 nv[4][4];
+    float s = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            nv[nt][g] = *reinterpret_cast<const f32x4*>(x_rows + nt * 32 + 8 * g);
+            s += (nv[nt][g].x + nv[nt][g].y) + (nv[nt][g].z + nv[nt][g].w);
+        }
+    s += xhalf(s);
+    const float mean = s * (1.0f / 128.0f);
+    float ss = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            nv[nt][g] -= mean;
+            ss += (nv[nt][g].x * nv[nt][g].x + nv[nt][g].y * nv[nt][g].y) + (nv[nt][g].z * nv[nt][g].z + nv[nt][g].w * nv[nt][g].w);
+        }
+    ss += xhalf(ss);
+    const float rstd = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+    float* srow = reinterpret_cast<float*>(stage + i * BG_STAGE_STRIDE) + 4 * h;
+    const char* scol = stage + (16 * h) * BG_STAGE_STRIDE + 4 * i;
+    auto colsum = [&](float* dst) {
+        float cs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cs += *reinterpret_cast<const float*>(scol + r * BG_STAGE_STRIDE);
+        cs += xhalf(cs);
+        if (h == 0) dst[i] = cs;
+    };
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            nv[nt][g] = nv[nt][g] * rstd;
+            const f32x4 da = {acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(srow + 8 * g) = da;
+        }
+        colsum(cp + nt * 32);                                   // dshift
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 da = {acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(srow + 8 * g) = da * nv[nt][g];
+        }
+        colsum(cp + 128 + nt * 32);                             // dscale
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(mrow + nt * 32 + 8 * g);
+            const f32x4 da = {acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
+            const f32x4 dn = da * (1.0f + sc);
+            const f32x4 n = nv[nt][g];
+            m1 += (dn.x + dn.y) + (dn.z + dn.w);
+            m2 += (dn.x * n.x + dn.y * n.y) + (dn.z * n.z + dn.w * n.w);
+            acc[nt][4 * g] = dn.x; acc[nt][4 * g + 1] = dn.y; acc[nt][4 * g + 2] = dn.z; acc[nt][4 * g + 3] = dn.w;
+        }
+    }
+    m1 += xhalf(m1);
+    m2 += xhalf(m2);
+    m1 *= (1.0f / 128.0f);
+    m2 *= (1.0f / 128.0f);
+    bf16x4 dpk[4];   // out pieces of the even n-tile, staged together with the odd one's (64 + 64 B = one line per row)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        f32x4 rr[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 dn = {acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
+            rr[g] = *reinterpret_cast<const f32x4*>(dx_rows + nt * 32 + 8 * g) + (dn - m1 - nv[nt][g] * m2) * rstd;
+            *reinterpret_cast<f32x4*>(srow + 8 * g) = rr[g];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                           // 8 rows x 128 B per store
+            const int r = 8 * u + (lane >> 3), c16 = lane & 7;
+            *reinterpret_cast<f32x4*>(dx_tile + (size_t)r * 128 + nt * 32 + c16 * 4) =
+                *reinterpret_cast<const f32x4*>(stage + r * BG_STAGE_STRIDE + c16 * 16);
+        }
+        if (res_rows != nullptr) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 pv = unpack4(*reinterpret_cast<const bf16x4*>(res_rows + nt * 32 + 8 * g));
+                *reinterpret_cast<f32x4*>(srow + 8 * g) = rr[g] * pv;
+            }
+            colsum(cp + 256 + nt * 32);                         // dgate of the next branch
+            bf16x4 dp4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 gn = *reinterpret_cast<const f32x4*>(mrow + 128 + nt * 32 + 8 * g);
+                dp4[g] = pack4(gn * rr[g]);
+            }
+            if (!(nt & 1)) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) dpk[g] = dp4[g];
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    *reinterpret_cast<bf16x4*>(stage + i * BG_STAGE_STRIDE + 16 * g + 8 * h) = dpk[g];
+                    *reinterpret_cast<bf16x4*>(stage + i * BG_STAGE_STRIDE + 64 + 16 * g + 8 * h) = dp4[g];
+                }
+                char* dst = reinterpret_cast<char*>(out_tile + (nt - 1) * 32);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = 8 * u + (lane >> 3), c16 = lane & 7;
+                    *reinterpret_cast<bf16x8*>(dst + (size_t)r * 256 + c16 * 16) = *reinterpret_cast<const bf16x8*>(stage + r * BG_STAGE_STRIDE + c16 * 16);
+                }
+            }
+        }
+    }
+}
+
 template <int K, int N, int PRO, int EPI>
-__global__ __launch_bounds__(BG_THREADS) void bgemm_kernel(const BGemmArgs a) {
-    constexpr int KS = K / 16, NT = N / 32;
+__global__ __launch_bounds__(bg_threads(EPI)) void bgemm_kernel(const BGemmArgs a) {
+    constexpr int KS = K / 16, NT = N / 32, THREADS = bg_threads(EPI);
     static_assert((PRO != BPRO_LN && PRO != BPRO_LN_RES) || K == 128, "LayerNorm prologue is over d_model = 128");
     extern __shared__ __attribute__((aligned(16))) char wl[];
     bf16x8* wlds = reinterpret_cast<bf16x8*>(wl);
@@ -136,15 +272,15 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_kernel(const BGemmArgs a) {
     // 5.6 TB/s of loads), so two 32-column n-tiles are gathered in LDS and leave as whole 128-byte lines, 16 bytes per
     // lane (q / k / v head tiles: 64-byte rows that are contiguous across tokens, one 2 KiB run per n-tile).
     char* stage = wl + (size_t)N * K * 2 + (size_t)N * 4 + (size_t)(threadIdx.x >> 6) * BG_STAGE_BYTES;
-    for (int c = threadIdx.x; c < N * K / 8; c += BG_THREADS) wlds[c] = a.Wp[c];
-    for (int c = threadIdx.x; c < N; c += BG_THREADS) blds[c] = a.bias != nullptr ? a.bias[c] : 0.f;
+    for (int c = threadIdx.x; c < N * K / 8; c += THREADS) wlds[c] = a.Wp[c];
+    for (int c = threadIdx.x; c < N; c += THREADS) blds[c] = a.bias != nullptr ? a.bias[c] : 0.f;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, i = lane & 31;
     const int n_tiles = a.M >> 5;
-    for (int tile = blockIdx.x * (BG_THREADS / 64) + wave; tile < n_tiles; tile += gridDim.x * (BG_THREADS / 64)) {
+    for (int tile = blockIdx.x * (THREADS / 64) + wave; tile < n_tiles; tile += gridDim.x * (THREADS / 64)) {
         const size_t row = (size_t)tile * 32 + i;   // a 32-token tile never straddles a sequence (480 = 15 x 32)
         const int seq = tile / (NTOK / 32);
         const int tok = (tile - seq * (NTOK / 32)) * 32 + i;
@@ -233,6 +369,27 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_kernel(const BGemmArgs a) {
         // otherwise hoist ALL their LDS reads out of the persistent loop into (spilled) registers.
         int wo = lane;
         asm volatile("" : "+v"(wo));
+        if constexpr (EPI == BEPI_LNBWD) {
+            static_assert(EPI != BEPI_LNBWD || N == 128, "LayerNorm backward epilogue is over d_model = 128");
+            f32x16 acc[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < KS; ++t) acc[nt] = mfma16(wlds[(nt * KS + t) * 64 + wo], xf[t], acc[nt]);
+            }
+            float* mlds = reinterpret_cast<float*>(wl + (size_t)N * K * 2 + (size_t)N * 4 + (size_t)(THREADS / 64) * BG_STAGE_BYTES) + wave * 256;
+            const bool has_gate = a.res != nullptr;
+            {   // this sequence's scale and next-gate rows (2 x 128 fp32) into the wave's own LDS kilobyte
+                const float* src = a.mod + (size_t)seq * MODROW + (lane < 32 || !has_gate ? a.scale_off : a.gate_off) + (lane & 31) * 4;
+                *reinterpret_cast<f32x4*>(mlds + lane * 4) = *reinterpret_cast<const f32x4*>(src);
+            }
+            lnbwd_epilogue(acc, a.ln_x + row * 128 + 4 * h, a.dx + row * 128 + 4 * h, a.dx + (size_t)tile * 32 * 128,
+                           has_gate ? a.res + row * 128 + 4 * h : nullptr, a.out + (size_t)tile * 32 * 128,
+                           a.colpart + (size_t)tile * 384, mlds + 4 * h, stage, lane);
+            continue;
+        }
 #pragma unroll 2
         for (int nt = 0; nt < NT; ++nt) {
             bf16x4 aux4[4];
@@ -286,11 +443,12 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_kernel(const BGemmArgs a) {
 
 template <int K, int N, int PRO, int EPI>
 inline int launch_bgemm(const BGemmArgs& a, hipStream_t st) {
+    constexpr int THREADS = bg_threads(EPI);
     if (a.M <= 0 || a.M % 32 != 0 || a.N != N) {
         set_error("bgemm: M=%d must be a positive multiple of 32 and N=%d must equal %d", a.M, a.N, N);
         return T2S_E_INVALID;
     }
-    constexpr int lds = N * K * 2 + N * 4 + (BG_THREADS / 64) * BG_STAGE_BYTES;
+    constexpr int lds = N * K * 2 + N * 4 + (THREADS / 64) * BG_STAGE_BYTES + (EPI == BEPI_LNBWD ? (THREADS / 64) * 1024 : 0);
     static int n_cu = 0;
     static bool attr = false;   // first call is never under stream capture (training is not captured)
     if (n_cu == 0) {
@@ -305,12 +463,24 @@ inline int launch_bgemm(const BGemmArgs& a, hipStream_t st) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
     }
-    const int tiles = a.M / 32, per_wg = BG_THREADS / 64;
+    const int tiles = a.M / 32, per_wg = THREADS / 64;
     int grid = (tiles + per_wg - 1) / per_wg < n_cu ? (tiles + per_wg - 1) / per_wg : n_cu;
     if (const char* e = getenv("T2S_BG_GRID")) grid = (tiles + per_wg - 1) / per_wg < atoi(e) ? (tiles + per_wg - 1) / per_wg : atoi(e);
-    bgemm_kernel<K, N, PRO, EPI><<<grid, BG_THREADS, lds, st>>>(a);
+    bgemm_kernel<K, N, PRO, EPI><<<grid, THREADS, lds, st>>>(a);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
+}
+
+// colpart (M/32, 3, 128) of BEPI_LNBWD -> dmod[seq][shift_off | scale_off | gate_off + f]: the 15 tile rows of a sequence
+// added in tile order (deterministic).  grid = sequences, 384 threads (256 when there is no gate column).
+static __global__ void lnbwd_colsum_reduce_kernel(const float* __restrict__ part, float* __restrict__ dmod, int shift_off,
+                                                  int scale_off, int gate_off) {
+    const int seq = blockIdx.x, t = threadIdx.x, q = t >> 7, f = t & 127;
+    const float* p = part + (size_t)seq * (NTOK / 32) * 384 + t;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NTOK / 32; ++k) s += p[k * 384];
+    dmod[(size_t)seq * MODROW + (q == 0 ? shift_off : (q == 1 ? scale_off : gate_off)) + f] = s;
 }
 
 // ------------------------------------------------------------------------------------------ wgrad

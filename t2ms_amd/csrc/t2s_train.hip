@@ -62,6 +62,7 @@ struct t2s_train_ws {
     __bf16 *a1h[NBLK], *qh[NBLK], *kh[NBLK], *vh[NBLK], *oh[NBLK], *ph[NBLK], *a2h[NBLK], *uh[NBLK], *fh[NBLK];
     __bf16 *t1h = nullptr, *t2h = nullptr, *t3h = nullptr, *t4h = nullptr;   // (M,128) (M,256) (M,384) (M,128)
     float* wg_scratch = nullptr;   // partial weight-gradient tiles (wgrad16 stage 1 -> stage 2)
+    float* colpart = nullptr;      // bf16: (M/32, 3, 128) column-sum partials of the fused LayerNorm backward (BEPI_LNBWD)
     size_t wg_scratch_floats = 0;
     int n_cu = 0;
 };
@@ -738,6 +739,7 @@ int ensure_ws(t2s_dit* h, int S) {
         if (ada > w->wg_scratch_floats) w->wg_scratch_floats = ada;
         o_wgs = atake(w->wg_scratch_floats);
     }
+    const size_t o_colpart = atake(bf ? M / 32 * 384 : 64);
     size_t o_t2a = 0, o_t2b = 0, o_t3 = 0, o_t4 = 0;
     if (!bf) { o_t2a = atake(M * 2 * D); o_t2b = atake(M * 2 * D); o_t3 = atake(M * 3 * D); o_t4 = atake(M * D); }
     if (hipMalloc(&w->act, aoff * sizeof(float)) != hipSuccess) return fail("activations", aoff * 4 / 1e6);
@@ -755,6 +757,7 @@ int ensure_ws(t2s_dit* h, int S) {
     w->dsum = A + o_dsum; w->dmod = A + o_dmod; w->t1 = A + o_t1;
     if (!bf) { w->t2a = A + o_t2a; w->t2b = A + o_t2b; w->t3 = A + o_t3; w->t4 = A + o_t4; }
     w->wg_scratch = A + o_wgs;
+    w->colpart = A + o_colpart;
     // ---- bf16 arena
     if (bf) {
         size_t hoff = 0;
@@ -806,6 +809,21 @@ int bgemm(const void* A, const bf16x8* Wp, const float* bias, __bf16* out, int M
     a.scale_off = scale_off; a.save_A = save_A; a.aux = aux; a.q = q; a.k = k; a.v = v;
     a.res = res; a.gate_off = gate_off; a.x_out = x_out;
     return launch_bgemm<K, N, PRO, EPI>(a, st);
+}
+
+// data-gradient GEMM (M,K) x W^T -> (M,128) whose epilogue is the LayerNorm + modulate backward (BEPI_LNBWD), then the
+// per-sequence column sums of its partials into dmod
+template <int K>
+int bgemm_lnbwd(t2s_train_ws* ws, const __bf16* dY, const bf16x8* Wt, const float* ln_x, int shift_off, int scale_off,
+                const __bf16* f_next, int gate_next_off, __bf16* t_next, int M, hipStream_t st) {
+    BGemmArgs a{};
+    a.A = dY; a.Wp = Wt; a.M = M; a.N = D; a.mod = ws->mod; a.shift_off = shift_off; a.scale_off = scale_off;
+    a.res = f_next; a.gate_off = gate_next_off; a.out = t_next; a.ln_x = ln_x; a.dx = ws->dx; a.colpart = ws->colpart;
+    int rc;
+    if ((rc = launch_bgemm<K, 128, BPRO_BF16, BEPI_LNBWD>(a, st))) return rc;
+    lnbwd_colsum_reduce_kernel<<<M / NTOK, f_next != nullptr ? 384 : 256, 0, st>>>(ws->colpart, ws->dmod, shift_off, scale_off, gate_next_off);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
 }
 
 template <int K, int NT, int PRO, int EPI>
@@ -1071,15 +1089,11 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
         { TimeScope ts(h, TC_TR_WGRAD, st);
         if ((rc = launch_wgrad16(ws->t2h, ws->a2h[i], b.fc1_w, b.fc1_b, M, 2 * D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
         }
-        // da2 = du W1 -> t4
+        // da2 = du W1, consumed in the accumulators: LN2 backward into dx merged with the attention branch's gate
+        // backward (t1 = dp = g1 * dx, dgate1) -- the epilogue of the data-gradient GEMM (BEPI_LNBWD; da2 never reaches HBM)
         { TimeScope ts(h, TC_TR_GEMM, st);
-        if ((rc = bgemm<256, 128, BPRO_BF16, BEPI_BF16>(ws->t2h, ws->fc1_t16[i], nullptr, ws->t4h, M, D, st))) return rc;
-        }
-        // LN2 backward into dx, merged with the attention branch's gate backward: t1 = dp = g1 * dx, dgate1
-        { TimeScope ts(h, TC_TR_ELEM, st);
-        ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t4h, ws->x_mid[i], ws->mod, base + 3 * D, base + 4 * D, ws->dx, ws->dmod,
-                                             ws->ph[i], base + 2 * D, ws->t1h);
-        T2S_LAUNCH_CHECK();
+        if ((rc = bgemm_lnbwd<256>(ws, ws->t2h, ws->fc1_t16[i], ws->x_mid[i], base + 3 * D, base + 4 * D, ws->ph[i], base + 2 * D, ws->t1h, M, st)))
+            return rc;
         }
         // ---- attention branch: x_mid = x_in + g1 * p
         { TimeScope ts(h, TC_TR_WGRAD, st);
@@ -1095,15 +1109,11 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
         { TimeScope ts(h, TC_TR_WGRAD, st);
         if ((rc = launch_wgrad16(ws->t3h, ws->a1h[i], b.qkv_w, b.qkv_b, M, 3 * D, D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
         }
-        // da1 = dqkv Wqkv -> t4
+        // da1 = dqkv Wqkv with LN1 backward into dx as its epilogue, merged with the gate backward of block i-1's MLP branch
         { TimeScope ts(h, TC_TR_GEMM, st);
-        if ((rc = bgemm<384, 128, BPRO_BF16, BEPI_BF16>(ws->t3h, ws->qkv_t16[i], nullptr, ws->t4h, M, D, st))) return rc;
-        }
-        // LN1 backward into dx, merged with the gate backward of block i-1's MLP branch
-        { TimeScope ts(h, TC_TR_ELEM, st);
-        ln_mod_bwd_kernel<<<S, 256, 0, st>>>(ws->t4h, ws->x_in[i], ws->mod, base + 0 * D, base + 1 * D, ws->dx, ws->dmod,
-                                             i > 0 ? ws->fh[i - 1] : (const __bf16*)nullptr, (i - 1) * MODW + 5 * D, ws->t1h);
-        T2S_LAUNCH_CHECK();
+        if ((rc = bgemm_lnbwd<384>(ws, ws->t3h, ws->qkv_t16[i], ws->x_in[i], base + 0 * D, base + 1 * D,
+                                   i > 0 ? ws->fh[i - 1] : (const __bf16*)nullptr, (i - 1) * MODW + 5 * D, ws->t1h, M, st)))
+            return rc;
         }
     }
     for (int i = NBLK - 1; i >= 0 && !bf; --i) {
