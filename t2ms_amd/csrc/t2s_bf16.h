@@ -502,7 +502,14 @@ static __global__ void lnbwd_colsum_reduce_kernel(const float* __restrict__ part
 template <bool XGELU>
 static __global__ __launch_bounds__(256) void wgrad16_kernel(const __bf16* __restrict__ dY, const __bf16* __restrict__ X,
                                                       float* __restrict__ part, float* __restrict__ bpart, int M, int N,
-                                                      int K, int rows_per_wg) {
+                                                      int K, int rows_per_wg, int gx, int gy, int gz) {
+    // XCD-aware 1-D grid: workgroup ids go round-robin over the 8 XCDs, so id = (slab8 * tiles + tile) * 8 + xcd puts the
+    // gy * gz workgroups that read the SAME row slab (different 128-column chunks of dY / X) on one XCD, back to back:
+    // the slab crosses HBM once and the siblings hit that XCD's L2.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, tiles = gy * gz;
+    const int tile_id = slot % tiles, bx = (slot / tiles) * 8 + xcd;
+    if (bx >= gx) return;
+    const int by = tile_id / gz, bz = tile_id - by * gz;
     constexpr int KT = 4;          // 32-wide k-tiles per workgroup
     constexpr int SLAB = 64;
     constexpr int STR = 320;
@@ -512,9 +519,9 @@ static __global__ __launch_bounds__(256) void wgrad16_kernel(const __bf16* __res
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
-    const int ncol0 = blockIdx.y * 128;
-    const int kcol0 = blockIdx.z * 128;
-    const int r0 = blockIdx.x * rows_per_wg;
+    const int ncol0 = by * 128;
+    const int kcol0 = bz * 128;
+    const int r0 = bx * rows_per_wg;
     const int r1 = min(M, r0 + rows_per_wg);
     // transposed-read addressing of this lane
     const int grp = (lane >> 4) & 3, nhalf = grp & 1, q = (lane & 15) >> 2, p = lane & 3;
@@ -569,7 +576,7 @@ static __global__ __launch_bounds__(256) void wgrad16_kernel(const __bf16* __res
 #pragma unroll
         for (int s = 0; s < SLAB / 16; ++s) {
             const bf16x8 af = join_tr(lds_tr16(ya + (16 * s) * STR), lds_tr16(ya + (16 * s + 4) * STR));
-            if (blockIdx.z == 0) accb = mfma16(af, ones, accb);
+            if (bz == 0) accb = mfma16(af, ones, accb);
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
                 const bf16x8 bf = join_tr(lds_tr16(xa + (16 * s) * STR + t * 64), lds_tr16(xa + (16 * s + 4) * STR + t * 64));
@@ -579,13 +586,13 @@ static __global__ __launch_bounds__(256) void wgrad16_kernel(const __bf16* __res
     }
     // partial tile of this workgroup: [(x * gy + y) * gz + z][128 n][128 k], bias sums [(x * gy + y)][128]
     const int j = lane & 31;
-    float* pt = part + ((size_t)(blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * (128 * 128);
+    float* pt = part + ((size_t)(bx * gy + by) * gz + bz) * (128 * 128);
 #pragma unroll
     for (int t = 0; t < KT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) pt[(wave * 32 + acc_row(r, half)) * 128 + t * 32 + j] = acc[t][r];
-    if (j == 0 && blockIdx.z == 0) {
-        float* bp = bpart + (size_t)(blockIdx.x * gridDim.y + blockIdx.y) * 128;
+    if (j == 0 && bz == 0) {
+        float* bp = bpart + (size_t)(bx * gy + by) * 128;
 #pragma unroll
         for (int r = 0; r < 16; ++r) bp[wave * 32 + acc_row(r, half)] = accb[r];
     }
@@ -662,7 +669,7 @@ inline int launch_wgrad16(const __bf16* dY, const __bf16* X, float* dW, float* d
     }
     float* part = scratch;
     float* bpart = scratch + part_floats;
-    wgrad16_kernel<XGELU><<<dim3(gx, gy, gz), 256, 0, st>>>(dY, X, part, bpart, M, N, K, rows_per_wg);
+    wgrad16_kernel<XGELU><<<(gx + 7) / 8 * 8 * gy * gz, 256, 0, st>>>(dY, X, part, bpart, M, N, K, rows_per_wg, gx, gy, gz);
     T2S_LAUNCH_CHECK();
     wgrad16_reduce_kernel<<<dim3(65, gy * gz), 256, 0, st>>>(part, bpart, dW, db, gx, gy, gz, K);
     T2S_LAUNCH_CHECK();
