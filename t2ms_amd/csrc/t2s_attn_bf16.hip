@@ -148,7 +148,9 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_fwd_kernel(const __b
         // 16 waves back into lockstep at every head (offsetting them with s_sleep changed nothing).  Dropped.
         // Also without effect: a one-time half-block s_sleep offset between the two waves a SIMD holds of a workgroup, and a
         // software pipeline that issues the score MFMAs of block jb+1 before the exponentials of block jb (two alternating
-        // accumulators; 0.91 vs 0.91 ms).  What is left is the exponential itself: 16 v_exp per 4 MFMAs at head_dim 32 --
+        // accumulators; 0.91 vs 0.91 ms), and a staged arrival of the images (four 16 KiB stages, the first query tile gated per
+        // stage with counted vmcnt + s_barrier so that it starts on the first 128 keys: 0.98 vs 0.89 ms -- every extra barrier
+        // re-aligns the eight waves, whose drift apart is what overlaps their exp and MFMA phases).  What is left is the exponential itself: 16 v_exp per 4 MFMAs at head_dim 32 --
         // the kernel does 4.7 T exp/s, the chip's v_exp issue rate is ~20 T/s only if nothing else used the port.)
         float m_run = 0.f, l_lane = 0.f;    // m_run: the reference, in the log2 domain of the (pre-scaled) scores
         f32x16 negm;                        // -m_run in all 16 registers: the C operand of every score MFMA
