@@ -269,12 +269,14 @@ TRAIN_U = {
     "last gate/residual add (feeds the final layer)": (5, 1),
     # backward, per block
     "fc2 weight gradient (df 1, u 2)": (3, 4), "fc2 data gradient x gelu' (df 1, u 2 in; du 2 out)": (5, 4),
-    "fc1 weight gradient (du 2, a2 1)": (3, 4), "fc1 data gradient (du 2 in; da2 1 out)": (3, 4),
-    "LN2 backward + attention-branch gate backward (da 1, x 2, dx 2, p 1 in; dx 2, dp 1 out)": (9, 4),
+    "fc1 weight gradient (du 2, a2 1)": (3, 4),
+    "fc1 data gradient with LN2 backward + attention-branch gate backward as its epilogue (du 2, x 2, dx 2, p 1 in; dx 2, dp 1 out)": (10, 4),
     "proj weight gradient (dp 1, o 1)": (2, 4), "proj data gradient": (2, 4),
     "attention D_i (o 1, do 1)": (2, 4), "attention dQ (q,k,v,do in; dq out)": (5, 4), "attention dK,dV (q,k,v,do in; dk,dv out)": (6, 4),
-    "qkv weight gradient (dqkv 3, a1 1)": (4, 4), "qkv data gradient (dqkv 3 in; da1 1 out)": (4, 4),
-    "LN1 backward + next gate backward": (9, 4),
+    "qkv weight gradient (dqkv 3, a1 1)": (4, 4),
+    "qkv data gradient with LN1 backward + next gate backward as its epilogue (dqkv 3, x 2, dx 2, f 1 in; dx 2, df 1 out)": (11, 4),
+    "  ... block 0 has no gate to differentiate next (no f in, no df out)": (-2, 1),
+    "column-sum partials of the two fused LayerNorm backwards (M/32 x 384 fp32 written + re-read)": (0.375, 8),
     "weight-gradient partial tiles written + re-read (4 gradients)": (2.6, 4),
     "MLP gate backward of the last block": (4, 1),
     # tails
