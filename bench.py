@@ -266,7 +266,6 @@ TRAIN_U = {
     "proj GEMM": (2, 4),
     "fc1 GEMM, LN prologue fused with the attention gate/residual add (x 2 + p 1 in; x_mid 2 + a2 1 + u 2 out)": (8, 4),
     "fc2 GEMM, GELU prologue (u 2 in; f 1 out)": (3, 4),
-    "last gate/residual add (feeds the final layer)": (5, 1),
     # backward, per block
     "fc2 weight gradient (df 1, u 2)": (3, 4), "fc2 data gradient x gelu' (df 1, u 2 in; du 2 out)": (5, 4),
     "fc1 weight gradient (du 2, a2 1)": (3, 4),
@@ -278,9 +277,9 @@ TRAIN_U = {
     "  ... block 0 has no gate to differentiate next (no f in, no df out)": (-2, 1),
     "column-sum partials of the two fused LayerNorm backwards (M/32 x 384 fp32 written + re-read)": (0.375, 8),
     "weight-gradient partial tiles written + re-read (4 gradients)": (2.6, 4),
-    "MLP gate backward of the last block": (4, 1),
     # tails
-    "patchify + final layer forward": (4, 1), "final layer + patchify backward": (6, 1),
+    "patchify (x 2 out) + final layer forward (x_mid 2 + f 1 in: the last gate/residual add is formed in the kernel)": (5, 1),
+    "final layer backward with the last MLP gate backward (x_mid 2 + f 1 in; dx 2 + df 1 out) + patchify backward (dx 2 in)": (8, 1),
 }
 
 

@@ -299,14 +299,14 @@ struct TailDst { float* p[4]; int n[4]; };   // consecutive column ranges of a p
 // grid = cols / 32 workgroups of 32 columns x 8 row slices: slice j adds partial rows j, j+8, ... (independent loads, many in
 // flight), then the 8 slice sums are added in slice order.  (One thread per column walking all ~1000 rows serially paid a
 // full memory latency per row: 260 us.)
-__global__ __launch_bounds__(256) void tail_reduce_kernel(const float* __restrict__ part, int n_wg, int cols, const TailDst d) {
+__global__ __launch_bounds__(256) void tail_reduce_kernel(const float* __restrict__ part, int n_wg, int cols, int stride, const TailDst d) {
     __shared__ float red[8][32];
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
     if (c < cols) {
 #pragma unroll 8
-        for (int w = sl; w < n_wg; w += 8) s += part[(size_t)w * cols + c];
+        for (int w = sl; w < n_wg; w += 8) s += part[(size_t)w * stride + c];
     }
     red[sl][cl] = s;
     __syncthreads();
@@ -321,13 +321,27 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(const float* __restric
     }
 }
 
+// dgate of the last block's MLP branch from the fused final-layer backward: three workgroup partials per sequence
+__global__ void final_gate_reduce_kernel(const float* __restrict__ part, int stride, float* __restrict__ dmod, int gate_off) {
+    const int seq = blockIdx.x, f = threadIdx.x;
+    const float* p = part + (size_t)seq * 3 * stride + FINAL_COLS + f;
+    dmod[(size_t)seq * MODROW + gate_off + f] = (p[0] + p[stride]) + p[2 * stride];
+}
+
 // final layer backward (transformer.py:182-191): dout (S,64,30) -> dx (M,128) and grads of
 // ln.weight, ln.bias, linear_emb_to_patch.{weight,bias}.  32 lanes per token row.
+// FUSED (bf16 training): the layer input x_mid + gate * f of the last block is formed here instead of being read back
+// (the forward never writes it), and the gate backward of that MLP branch runs on the dx just produced: t = gate * dx
+// (bf16 rows), dgate partial = sum over this workgroup's rows of dx * f in columns FINAL_COLS.. of its partial row.
+// FUSED workgroups own ROWS = 160 rows = a third of a sequence, so three consecutive partial rows make one sequence.
+template <bool FUSED, int ROWS>
 __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout,
                                                         const float* __restrict__ lng, const float* __restrict__ lnb,
                                                         const float* __restrict__ ow, float* __restrict__ dx,
-                                                        float* __restrict__ part, int M) {
-    __shared__ f32x4 red[6][8][32];
+                                                        float* __restrict__ part, int M, const __bf16* __restrict__ f,
+                                                        const float* __restrict__ mod, int gate_off, __bf16* __restrict__ t) {
+    constexpr int PCOLS = FUSED ? FINAL_COLS + D : FINAL_COLS;
+    __shared__ f32x4 red[FUSED ? 7 : 6][8][32];
     __shared__ float redb[8][4];
     const int c4 = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const f32x4 gam = *reinterpret_cast<const f32x4*>(lng + c4 * 4);
@@ -337,9 +351,12 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
     for (int p = 0; p < 4; ++p) w[p] = *reinterpret_cast<const f32x4*>(ow + p * D + c4 * 4);
     f32x4 a_g = {0, 0, 0, 0}, a_b = {0, 0, 0, 0}, a_w[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     float a_ob[4] = {0.f, 0.f, 0.f, 0.f};
-    const int row0 = blockIdx.x * TAIL_ROWS;
-    for (int it0 = 0; it0 < TAIL_ROWS / 8; it0 += 4) {      // 4 rows per 32-lane group in flight: loads first, then the chains
-        f32x4 xv4[4];
+    f32x4 a_gt = {0, 0, 0, 0}, gt = {0, 0, 0, 0};
+    const int row0 = blockIdx.x * ROWS;
+    if constexpr (FUSED) gt = *reinterpret_cast<const f32x4*>(mod + (size_t)(row0 / NTOK) * MODROW + gate_off + c4 * 4);
+    static_assert(ROWS % 32 == 0, "8 row groups x 4 rows in flight");
+    for (int it0 = 0; it0 < ROWS / 8; it0 += 4) {      // 4 rows per 32-lane group in flight: loads first, then the chains
+        f32x4 xv4[4], fv4[4];
         float dl4[4][4];
         bool valid4[4];
         size_t idx4[4];
@@ -350,6 +367,10 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
             const int row = valid4[u] ? row0 + rr : M - 1;
             idx4[u] = (size_t)row * 32 + c4;
             xv4[u] = reinterpret_cast<const f32x4*>(x)[idx4[u]];
+            if constexpr (FUSED) {
+                fv4[u] = ld4(f, idx4[u]);
+                xv4[u] = xv4[u] + gt * fv4[u];              // the expression of gate_res_kernel
+            }
             // gather d(lin)[p] from the unpatchified output gradient
             const int seq = row / NTOK, tok = row - seq * NTOK;
             const int hh = tok >> 5, ww = tok & 31;
@@ -391,13 +412,19 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
             }
             m1 *= (1.0f / 128.0f);
             m2 *= (1.0f / 128.0f);
-            if (valid4[u]) reinterpret_cast<f32x4*>(dx)[idx4[u]] = (dn - m1 - n * m2) * rstd;
+            const f32x4 r = (dn - m1 - n * m2) * rstd;
+            if (valid4[u]) reinterpret_cast<f32x4*>(dx)[idx4[u]] = r;
+            if constexpr (FUSED) {
+                if (valid4[u]) st4(t, idx4[u], gt * r);
+                a_gt += (valid4[u] ? 1.f : 0.f) * (r * fv4[u]);
+            }
         }
     }
     red[0][rg][c4] = a_g;
     red[1][rg][c4] = a_b;
 #pragma unroll
     for (int p = 0; p < 4; ++p) red[2 + p][rg][c4] = a_w[p];
+    if constexpr (FUSED) red[6][rg][c4] = a_gt;
     if (c4 == 0)
 #pragma unroll
         for (int p = 0; p < 4; ++p) redb[rg][p] = a_ob[p];
@@ -406,11 +433,18 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
         f32x4 s = red[rg][0][c4];
 #pragma unroll
         for (int i = 1; i < 8; ++i) s += red[rg][i][c4];
-        *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * FINAL_COLS + rg * D + c4 * 4) = s;   // lnw | lnb | ow[p]
-    } else if (rg == 6 && c4 < 4) {
-        float s = 0.f;
-        for (int i = 0; i < 8; ++i) s += redb[i][c4];
-        part[(size_t)blockIdx.x * FINAL_COLS + 6 * D + c4] = s;
+        *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * PCOLS + rg * D + c4 * 4) = s;   // lnw | lnb | ow[p]
+    } else if (rg == 6) {
+        if (c4 < 4) {
+            float s = 0.f;
+            for (int i = 0; i < 8; ++i) s += redb[i][c4];
+            part[(size_t)blockIdx.x * PCOLS + 6 * D + c4] = s;
+        }
+    } else if constexpr (FUSED) {
+        f32x4 s = red[6][0][c4];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) s += red[6][i][c4];
+        *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * PCOLS + FINAL_COLS + c4 * 4) = s;   // dgate partial
     }
 }
 
@@ -616,9 +650,11 @@ __global__ __launch_bounds__(256) void patchify_rows_kernel(const float* __restr
 }
 
 // final layer, row-major input (transformer.py:182-191)
+// f != NULL (bf16 training): the layer input is x_mid + gate * f of the last block, formed here (gate_res_kernel's expression)
 __global__ __launch_bounds__(256) void final_rows_kernel(const float* __restrict__ h, int S, const float* __restrict__ lnw,
                                                          const float* __restrict__ lnb, const float* __restrict__ ow,
-                                                         const float* __restrict__ ob, float* __restrict__ out) {
+                                                         const float* __restrict__ ob, float* __restrict__ out,
+                                                         const __bf16* __restrict__ f, const float* __restrict__ mod, int gate_off) {
     // 32 lanes per token row, FOUR rows per group in flight: a row is 3 dependent butterfly reductions (mean, variance,
     // the four output dots) and one row per group left the kernel latency-bound at 2.7 TB/s
     constexpr int RPG = 4;
@@ -634,7 +670,12 @@ __global__ __launch_bounds__(256) void final_rows_kernel(const float* __restrict
 #pragma unroll
     for (int u = 0; u < RPG; ++u) {
         tok[u] = grp * RPG + u;
-        v[u] = reinterpret_cast<const f32x4*>(h)[(size_t)(tok[u] < M ? tok[u] : M - 1) * 32 + c4];
+        const int tk = tok[u] < M ? tok[u] : M - 1;
+        v[u] = reinterpret_cast<const f32x4*>(h)[(size_t)tk * 32 + c4];
+        if (f != nullptr) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(mod + (size_t)(tk / NTOK) * MODROW + gate_off + c4 * 4);
+            v[u] = v[u] + g * ld4(f, (size_t)tk * 32 + c4);
+        }
     }
 #pragma unroll
     for (int u = 0; u < RPG; ++u) {
@@ -978,11 +1019,7 @@ int t2s_dit_train_forward(t2s_dit* h, const t2s_dit_weights* w, const float* x, 
         { TimeScope ts(h, TC_TR_GEMM, st);
         if ((rc = bgemm<256, 128, BPRO_GELU, BEPI_BF16>(ws->uh[i], ws->fc2_f16[i], h->fc2_b[i], ws->fh[i], M, D, st))) return rc;
         }
-        if (i == NBLK - 1) {   // the final layer reads the stream itself: x_in[NBLK] = x_mid + g2 * f
-            TimeScope ts(h, TC_TR_ELEM, st);
-            gate_res_kernel<<<(M * 32 + 255) / 256, 256, 0, st>>>(ws->x_mid[i], ws->fh[i], ws->mod, base + 5 * D, ws->x_in[i + 1], M);
-            T2S_LAUNCH_CHECK();
-        }
+        // (the last block's x_mid + g2 * f is formed inside the final-layer kernels, forward and backward: never written)
     }
     for (int i = 0; i < NBLK && !bf; ++i) {
         const int base = i * MODW;
@@ -1017,7 +1054,12 @@ int t2s_dit_train_forward(t2s_dit* h, const t2s_dit_weights* w, const float* x, 
         }
     }
     { TimeScope ts(h, TC_TR_TAIL, st);
-    final_rows_kernel<<<((M + 3) / 4 * 32 + 255) / 256, 256, 0, st>>>(ws->x_in[NBLK], S, h->ln_w, h->ln_b, h->out_w, h->out_b, out);
+    if (bf)
+        final_rows_kernel<<<((M + 3) / 4 * 32 + 255) / 256, 256, 0, st>>>(ws->x_mid[NBLK - 1], S, h->ln_w, h->ln_b, h->out_w, h->out_b, out,
+                                                                           ws->fh[NBLK - 1], ws->mod, (NBLK - 1) * MODW + 5 * D);
+    else
+        final_rows_kernel<<<((M + 3) / 4 * 32 + 255) / 256, 256, 0, st>>>(ws->x_in[NBLK], S, h->ln_w, h->ln_b, h->out_w, h->out_b, out,
+                                                                           nullptr, nullptr, 0);
     T2S_LAUNCH_CHECK();
     }
     return T2S_OK;
@@ -1052,16 +1094,28 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
         i = k;
     }
     // ---- final layer
+    const bool bf = ws->dtype == T2S_TRAIN_BF16;
     const int tail_wgs = (M + TAIL_ROWS - 1) / TAIL_ROWS;
-    T2S_REQUIRE((size_t)tail_wgs * FINAL_COLS <= ws->wg_scratch_floats, "t2s_dit_train_backward: scratch too small for the tail partials");
+    constexpr int FUSED_ROWS = NTOK / 3;                       // 160: three workgroups per sequence
+    const int final_wgs = bf ? M / FUSED_ROWS : tail_wgs, final_stride = bf ? FINAL_COLS + D : FINAL_COLS;
+    T2S_REQUIRE((size_t)final_wgs * final_stride <= ws->wg_scratch_floats && (size_t)tail_wgs * PATCH_COLS <= ws->wg_scratch_floats,
+                "t2s_dit_train_backward: scratch too small for the tail partials");
     { TimeScope ts(h, TC_TR_TAIL, st);
-    final_bwd_kernel<<<tail_wgs, 256, 0, st>>>(ws->x_in[NBLK], dout, h->ln_w, h->ln_b, h->out_w, ws->dx, ws->wg_scratch, M);
+    if (bf) {   // + the gate backward of the last block's MLP branch: t1 = df = g2 * dx, dgate2
+        const int goff = (NBLK - 1) * MODW + 5 * D;
+        final_bwd_kernel<true, FUSED_ROWS><<<final_wgs, 256, 0, st>>>(ws->x_mid[NBLK - 1], dout, h->ln_w, h->ln_b, h->out_w, ws->dx, ws->wg_scratch, M,
+                                                                      ws->fh[NBLK - 1], ws->mod, goff, ws->t1h);
+        T2S_LAUNCH_CHECK();
+        final_gate_reduce_kernel<<<S, D, 0, st>>>(ws->wg_scratch, final_stride, ws->dmod, goff);
+    } else {
+        final_bwd_kernel<false, TAIL_ROWS><<<final_wgs, 256, 0, st>>>(ws->x_in[NBLK], dout, h->ln_w, h->ln_b, h->out_w, ws->dx, ws->wg_scratch, M,
+                                                                      nullptr, nullptr, 0, nullptr);
+    }
     T2S_LAUNCH_CHECK();
-    tail_reduce_kernel<<<(FINAL_COLS + 31) / 32, 256, 0, st>>>(ws->wg_scratch, tail_wgs, FINAL_COLS,
+    tail_reduce_kernel<<<(FINAL_COLS + 31) / 32, 256, 0, st>>>(ws->wg_scratch, final_wgs, FINAL_COLS, final_stride,
                                                                  TailDst{{g->ln_w, g->ln_b, g->out_w, g->out_b}, {D, D, 4 * D, 4}});
     T2S_LAUNCH_CHECK();
     }
-    const bool bf = ws->dtype == T2S_TRAIN_BF16;
     // (Measured and dropped in round 2: the four weight gradients of a block on a side stream.  Issued as soon as their
     // operands exist they only share the HBM bandwidth with the GEMM / LayerNorm kernels they run beside (13.42 ms per step,
     // the same as in order); issued beside the VALU-bound attention backward they slow it by more than they take alone
@@ -1069,14 +1123,8 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
     for (int i = NBLK - 1; i >= 0 && bf; --i) {
         const int base = i * MODW;
         const t2s_dit_block_grads& b = g->blk[i];
-        // ---- MLP branch: x_out = x_mid + g2 * f.  t1 = df = g2 * dx and dgate2 come from the previous block's
-        // LN1 backward (merged gate backward) except for the last block
-        if (i == NBLK - 1) {
-            { TimeScope ts(h, TC_TR_ELEM, st);
-            gate_bwd_kernel<<<S, 256, 0, st>>>(ws->dx, ws->fh[i], ws->mod, base + 5 * D, ws->t1h, ws->dmod);
-            T2S_LAUNCH_CHECK();
-            }
-        }
+        // ---- MLP branch: x_out = x_mid + g2 * f.  t1 = df = g2 * dx and dgate2 come from the kernel that produced dx: the
+        // next block's LN1 backward epilogue, or the final-layer backward for the last block
         { TimeScope ts(h, TC_TR_WGRAD, st);     // dW2 = df^T gelu(u): gelu applied to the fetched u chunks (not saved)
         if ((rc = launch_wgrad16<true>(ws->t1h, ws->uh[i], b.fc2_w, b.fc2_b, M, D, 2 * D, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st))) return rc;
         }
@@ -1180,7 +1228,7 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
     { TimeScope ts(h, TC_TR_TAIL, st);
     patchify_bwd_kernel<<<tail_wgs, 256, 0, st>>>(ws->dx, ws->lat, S, h->conv_w, h->conv_b, h->patch_w, ws->wg_scratch, M);
     T2S_LAUNCH_CHECK();
-    tail_reduce_kernel<<<(PATCH_COLS + 31) / 32, 256, 0, st>>>(ws->wg_scratch, tail_wgs, PATCH_COLS,
+    tail_reduce_kernel<<<(PATCH_COLS + 31) / 32, 256, 0, st>>>(ws->wg_scratch, tail_wgs, PATCH_COLS, PATCH_COLS,
                                                                  TailDst{{g->patch_w, g->patch_b, g->conv_w, g->conv_b}, {4 * D, D, 16, 4}});
     T2S_LAUNCH_CHECK();
     }
