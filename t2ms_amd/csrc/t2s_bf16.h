@@ -346,7 +346,19 @@ __global__ __launch_bounds__(bg_threads(EPI)) void bgemm_kernel(const BGemmArgs 
                 const f32x4 sh0 = *reinterpret_cast<const f32x4*>(mrow + a.shift_off + 16 * t);
                 const f32x4 sh1 = *reinterpret_cast<const f32x4*>(mrow + a.shift_off + 16 * t + 4);
                 xf[t] = pack8((v[t][0] * rstd) * (1.0f + sc0) + sh0, (v[t][1] * rstd) * (1.0f + sc1) + sh1);
-                if (a.save_A != nullptr) *reinterpret_cast<bf16x8*>(a.save_A + row * K + 16 * t + 8 * h) = xf[t];
+                if (a.save_A != nullptr) {
+                    // saved for the weight gradient: through the staging tile, four k-steps = 64 features = one 128-byte
+                    // line per row (the lane's own 16-byte pieces would reach HBM as partial lines)
+                    *reinterpret_cast<bf16x8*>(stage + i * BG_STAGE_STRIDE + (t & 3) * 32 + 16 * h) = xf[t];
+                    if ((t & 3) == 3) {
+                        char* dst = reinterpret_cast<char*>(a.save_A + (size_t)tile * 32 * K + (t >> 2) * 64);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int r = 8 * u + (lane >> 3), c16 = lane & 7;
+                            *reinterpret_cast<bf16x8*>(dst + (size_t)r * K * 2 + c16 * 16) = *reinterpret_cast<const bf16x8*>(stage + r * BG_STAGE_STRIDE + c16 * 16);
+                        }
+                    }
+                }
             }
         } else {
             const __bf16* ar = reinterpret_cast<const __bf16*>(a.A) + row * K + 8 * h;
