@@ -16,6 +16,13 @@
 #pragma once
 #include "t2s_gemm.h"
 
+// see t2s_x3.h: packed fp32 VALU instructions serialise with bf16 MFMAs on gfx950
+#if defined(__HIP_DEVICE_COMPILE__)
+#define T2S_NO_PK_F32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define T2S_NO_PK_F32
+#endif
+
 namespace t2s {
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -261,7 +268,7 @@ __device__ __forceinline__ void lnbwd_epilogue(f32x16 (&acc)[4], const float* __
 }
 
 template <int K, int N, int PRO, int EPI>
-__global__ __launch_bounds__(bg_threads(EPI)) void bgemm_kernel(const BGemmArgs a) {
+__global__ __launch_bounds__(bg_threads(EPI)) T2S_NO_PK_F32 void bgemm_kernel(const BGemmArgs a) {
     constexpr int KS = K / 16, NT = N / 32, THREADS = bg_threads(EPI);
     static_assert((PRO != BPRO_LN && PRO != BPRO_LN_RES) || K == 128, "LayerNorm prologue is over d_model = 128");
     extern __shared__ __attribute__((aligned(16))) char wl[];

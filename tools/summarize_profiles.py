@@ -123,5 +123,30 @@ if os.path.exists(tb_path):
         lines += [f"HBM bytes per step from the PMC passes: **{per_step / 1e9:.1f} GB** (design count {t['hbm_bytes_per_step_model'] / 1e9:.1f} GB) "
                   f"= {per_step / (t['ms_per_step'] * 1e-3) / 1e12:.2f} TB/s over the whole step.", ""]
     lines += [f"rocprofv3 kernel stats (`{tag}_train_bf16_kernel_stats.csv`; 1 warm-up + 3 timed + 3 event-timed steps):", "", table(kt, 26), ""]
+    # per-kernel HBM roofline: bytes by design per launch (units u of bench.py's TRAIN_U: one bf16 (M,128) tensor) / average duration
+    u_mb = t["per_gpu_batch"] * 480 * 128 * 2 / 1e6
+    per_launch_u = [("bgemm_kernel<128, 384, 1, 1>", 6, "qkv GEMM + LN prologue, block 0"),
+                    ("bgemm_kernel<128, 384, 3, 1>", 9, "qkv GEMM, LN prologue + previous gate/residual add"),
+                    ("attn16_fwd_kernel", 4, "attention forward (VALU-bound)"),
+                    ("bgemm_kernel<128, 128, 0, 0>", 2, "proj GEMM / proj data gradient"),
+                    ("bgemm_kernel<128, 256, 3, 0>", 8, "fc1 GEMM, LN prologue + attention gate/residual add"),
+                    ("bgemm_kernel<256, 128, 2, 0>", 3, "fc2 GEMM, GELU prologue"),
+                    ("wgrad16_kernel<true>", 4, "fc2 weight gradient (df read twice)"),
+                    ("bgemm_kernel<128, 256, 0, 2>", 5, "fc2 data gradient x gelu'"),
+                    ("wgrad16_kernel<false>", 11.0 / 3, "fc1 / proj / qkv weight gradients (average; X of fc1 read twice, of qkv three times)"),
+                    ("bgemm_kernel<256, 128, 0, 3>", 10, "fc1 data gradient + LN2 backward + gate backward"),
+                    ("bgemm_kernel<384, 128, 0, 3>", 10.5, "qkv data gradient + LN1 backward + gate backward (block 0: 9 u)"),
+                    ("attn16_bwd_dq_kernel", 6, "attention dQ + D_i (VALU-bound)"),
+                    ("attn16_bwd_dkv_kernel", 6, "attention dK, dV (VALU-bound)")]
+    lines += ["Per kernel against the HBM roof (bytes by design per launch, `TRAIN_U` in bench.py, u = %.1f MB; 8 TB/s peak, ~6 TB/s is what a plain copy reaches):" % u_mb,
+              "", "| kernel | what | u per launch | avg us | TB/s | of 8 TB/s |", "|---|---|---|---|---|---|"]
+    for pat, uu, what in per_launch_u:
+        r = next((r for r in kt if pat in r["Name"]), None)
+        if r is None:
+            continue
+        us = float(r["AverageNs"]) / 1e3
+        tbs = uu * u_mb * 1e6 / (us * 1e-6) / 1e12
+        lines.append("| `%s` | %s | %.1f | %.1f | %.2f | %.2f |" % (pat, what, uu, us, tbs, tbs / 8.0))
+    lines.append("")
 open(os.path.join(P, f"{tag}_summary.md"), "w").write("\n".join(lines))
 print("\n".join(lines[:16]))
