@@ -337,3 +337,39 @@ def test_model_pickles_after_a_training_step(dev):
         mm.zero_grad()
         mse_loss(mm(input=x, t=t, text_input=None), x).backward()
         torch.testing.assert_close(mm.layers[0].attn.qkv.weight.grad, m.layers[0].attn.qkv.weight.grad, rtol=1e-5, atol=1e-9)
+
+
+def test_drop_in_chain_vae_pickle_train_infer_metrics(dev, tmp_path, monkeypatch, capsys):
+    """The reference's whole flow through the drop-in entry points, nothing seeded behind its back: a whole-module LA-VAE
+    pickle where train.py / infer.py look for it (train.py:22,156; infer.py:39), train.py from `initialize_weights` in bf16
+    -> checkpoint dict (train.py:94) -> infer.py loads THAT checkpoint by --checkpoint_id (infer.py:48,145) and writes the four
+    .npy files -> the GPU metrics CLI reads them (what evaluation.py:285-297 reads)."""
+    import types
+    import infer as infer_drv
+    import train as train_drv
+    from model.pretrained.vqvae import vqvae
+    from t2ms_amd import metrics
+    monkeypatch.chdir(tmp_path)
+    vae = vqvae(types.SimpleNamespace(block_hidden_size=128, num_residual_layers=2, res_hidden_size=256, embedding_dim=64))
+    vae.load_state_dict(synth.make_vae_state_dict(2025), strict=True)
+    os.makedirs("results/saved_pretrained_models/datasetETTh1_epoch2000")
+    torch.save(vae, "results/saved_pretrained_models/datasetETTh1_epoch2000/final_model.pth")
+    save = str(tmp_path / "results" / "denoiser_results")
+    targv = ["--dataset_name", "ETTh1", "--backbone", "ddpm", "--denoiser", "DiT", "--total_step", "100", "--batch_size", "12",
+             "--epochs", "3", "--save_path", save, "--synthetic", "24", "--checkpoint_path", "", "--bf16", "--seed", "5"]
+    monkeypatch.setattr("sys.argv", ["train.py"] + targv)
+    losses = train_drv.train(train_drv.get_args(targv))
+    assert np.isfinite(losses).all() and len(losses) >= 6
+    ck = os.path.join(save, "checkpoints", "ddpm_DiT_ETTh1", "model_2.pth")
+    assert os.path.exists(ck)
+    trained = torch.load(ck, map_location="cpu")["model"]
+    assert float(trained["layers.0.adaLN_modulation.1.weight"].abs().max()) > 0.0      # adaLN-Zero has left zero: it trained
+    infer_drv.main(["--dataset_name", "ETTh1_24", "--backbone", "ddpm", "--denoiser", "DiT", "--total_step", "4", "--cfg_scale", "7",
+                    "--batch_size", "4", "--save_path", save, "--synthetic", "9", "--checkpoint_id", "2", "--seed", "3"])
+    out = os.path.join(save, "generation", "ddpm_DiT_ETTh1_24_7.0_4")
+    gen = np.load(os.path.join(out, "x_t.npy"))
+    assert gen.shape == (8, 24, 1) and np.isfinite(gen).all()
+    capsys.readouterr()
+    metrics.main([out])
+    line = capsys.readouterr().out
+    assert "MSE" in line and "WAPE" in line and "DTW" in line and "nan" not in line.lower(), line
