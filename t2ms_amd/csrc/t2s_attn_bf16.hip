@@ -113,11 +113,11 @@ __device__ __forceinline__ bf16x8 col_frag(const char* img, int base, int lane, 
 // ------------------------------------------------------------------ forward with lse
 __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_fwd_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
                                                          const __bf16* __restrict__ v, __bf16* __restrict__ o_rows,
-                                                         float* __restrict__ lse) {
+                                                         float* __restrict__ lse, int reverse) {
     __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
     char* Ks = smem;
     char* Vs = smem + IMG;
-    const int bh = blockIdx.x, tid = threadIdx.x;
+    const int bh = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, half = lane >> 5, i = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int seq = bh / NH, head = bh % NH;
@@ -210,11 +210,11 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_bwd_dq_kernel(const 
                                                             const __bf16* __restrict__ v, const __bf16* __restrict__ o_rows,
                                                             const __bf16* __restrict__ do_rows,
                                                             const float* __restrict__ lse, float* __restrict__ dsum,
-                                                            __bf16* __restrict__ dqkv) {
+                                                            __bf16* __restrict__ dqkv, int reverse) {
     __shared__ __attribute__((aligned(16))) char smem[2 * IMG];
     char* Ks = smem;
     char* Vs = smem + IMG;
-    const int bh = blockIdx.x, tid = threadIdx.x;
+    const int bh = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, half = lane >> 5, i = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int seq = bh / NH, head = bh % NH;
@@ -271,13 +271,13 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_bwd_dq_kernel(const 
 __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_bwd_dkv_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
                                                              const __bf16* __restrict__ v, const __bf16* __restrict__ do_rows,
                                                              const float* __restrict__ lse, const float* __restrict__ dsum,
-                                                             __bf16* __restrict__ dqkv) {
+                                                             __bf16* __restrict__ dqkv, int reverse) {
     __shared__ __attribute__((aligned(16))) char smem[2 * IMG + 2 * NTOK * 4];
     char* Qs = smem;                                              // Q image
     char* Os = smem + IMG;                                        // dO image (this head)
     float* Ls = reinterpret_cast<float*>(smem + 2 * IMG);         // lse (log2 domain)
     float* Ds = Ls + NTOK;                                        // D_i
-    const int bh = blockIdx.x, tid = threadIdx.x;
+    const int bh = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, half = lane >> 5, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int seq = bh / NH, head = bh % NH;
@@ -339,16 +339,16 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_bwd_dkv_kernel(const
 }
 
 int attn16_train_fwd(const __bf16* q, const __bf16* k, const __bf16* v, __bf16* o_rows, float* lse, int BH, hipStream_t st) {
-    attn16_fwd_kernel<<<BH, 512, 0, st>>>(q, k, v, o_rows, lse);
+    attn16_fwd_kernel<<<BH, 512, 0, st>>>(q, k, v, o_rows, lse, next_tile_dir());
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }
 
 int attn16_bwd(const __bf16* q, const __bf16* k, const __bf16* v, const __bf16* o_rows, const __bf16* do_rows,
                const float* lse, float* dsum, __bf16* dqkv_rows, int BH, hipStream_t st) {
-    attn16_bwd_dq_kernel<<<BH, 512, 0, st>>>(q, k, v, o_rows, do_rows, lse, dsum, dqkv_rows);   // also writes D_i -> dsum
+    attn16_bwd_dq_kernel<<<BH, 512, 0, st>>>(q, k, v, o_rows, do_rows, lse, dsum, dqkv_rows, next_tile_dir());   // also writes D_i -> dsum
     T2S_LAUNCH_CHECK();
-    attn16_bwd_dkv_kernel<<<BH, 512, 0, st>>>(q, k, v, do_rows, lse, dsum, dqkv_rows);
+    attn16_bwd_dkv_kernel<<<BH, 512, 0, st>>>(q, k, v, do_rows, lse, dsum, dqkv_rows, next_tile_dir());
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }

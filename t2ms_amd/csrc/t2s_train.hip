@@ -928,6 +928,7 @@ int t2s_dit_set_train_dtype(t2s_dit* h, int dtype) {
 
 int t2s_dit_train_forward(t2s_dit* h, const t2s_dit_weights* w, const float* x, const float* temb, int temb_rows,
                           const float* text, float* out, int B, void* stream) {
+    t2s::reset_tile_dir();
     T2S_REQUIRE(h && w && x && temb && out, "t2s_dit_train_forward: NULL argument");
     T2S_REQUIRE(B > 0 && B <= h->max_seqs, "t2s_dit_train_forward: B=%d exceeds max_seqs=%d", B, h->max_seqs);
     T2S_REQUIRE(temb_rows == 1 || temb_rows == B, "t2s_dit_train_forward: temb_rows=%d", temb_rows);
@@ -1066,6 +1067,7 @@ int t2s_dit_train_forward(t2s_dit* h, const t2s_dit_weights* w, const float* x, 
 }
 
 int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g, int B, void* stream) {
+    t2s::reset_tile_dir();
     T2S_REQUIRE(h && dout && g, "t2s_dit_train_backward: NULL argument");
     T2S_REQUIRE(h->train && h->train->S == B, "t2s_dit_train_backward: no matching t2s_dit_train_forward (B=%d)", B);
     T2S_REQUIRE(h->train->dtype == h->train_dtype, "t2s_dit_train_backward: training dtype changed since the forward");
