@@ -49,6 +49,25 @@ def _load_vae(args, device):
     return vae.float().to(device).eval()
 
 
+_SIDE = {}
+
+
+def _h2d(t, device):
+    """CPU -> device on a side stream: a pageable copy makes the host wait for everything queued on ITS stream, which on the
+    compute stream means a drained GPU at every step boundary; the side stream is empty, the compute stream waits for its event."""
+    if torch.device(device).type != "cuda" or os.environ.get("T2S_SYNC_H2D"):
+        return t.to(device)
+    side = _SIDE.get(str(device))
+    if side is None:
+        side = _SIDE[str(device)] = torch.cuda.Stream(device)
+    with torch.cuda.stream(side):
+        out = t.to(device)
+    cur = torch.cuda.current_stream(device)
+    cur.wait_stream(side)
+    out.record_stream(cur)
+    return out
+
+
 def train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world, latents=None, idx=None, step_no=0):
     """One optimisation step on this rank's slice of the batch (train.py:103-127 / 60-87).
 
@@ -68,19 +87,19 @@ def train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world, 
     opt.zero_grad()
     loss = None
     if n > 0:
-        emb = emb[lo:hi].float().to(device)
+        emb = _h2d(emb[lo:hi].float(), device)
         if latents is not None and idx is not None:
-            z = latents[idx[lo:hi].to(device)]                                         # pre-encoded rows (latent cache)
+            z = latents[_h2d(idx[lo:hi], device)]                                      # pre-encoded rows (latent cache)
         else:
             with torch.no_grad():
-                z, _ = model.encoder(x_1[lo:hi].float().to(device).contiguous())      # frozen LA-VAE (train.py:31-33,106)
+                z, _ = model.encoder(_h2d(x_1[lo:hi].float(), device).contiguous())    # frozen LA-VAE (train.py:31-33,106)
         noise = philox_normal(n, z[0].numel(), args.seed ^ 0x7261696E, step_no, lo, device).view_as(z)
         if args.backbone == "flowmatching":
-            t = (torch.round(u * args.total_step) / args.total_step)[lo:hi].to(device)
+            t = _h2d((torch.round(u * args.total_step) / args.total_step)[lo:hi], device)
             x_t, x_0 = backbone.create_flow(z, t, x_0=noise)
             target = z - x_0
         elif args.backbone == "ddpm":
-            t = torch.floor(u * args.total_step).long()[lo:hi].to(device)
+            t = _h2d(torch.floor(u * args.total_step).long()[lo:hi], device)
             target = noise
             x_t, _ = backbone.q_sample(z, t, target)
         else:
@@ -150,6 +169,13 @@ def train(args):
     model.train()
     t0, seen = time.time(), 0
     step_no = len(loss_list)                  # global optimisation-step counter (keys the noise stream; survives resume)
+    pending = []                              # losses of the steps since the last flush, still on the device
+
+    def flush():
+        if pending:
+            loss_list.extend(torch.stack(pending).tolist())
+            pending.clear()
+
     for epoch in range(start_epoch, args.epochs):
         for batch, data in enumerate(dataloader):
             groups = data if args.mix_train else [data]
@@ -160,7 +186,9 @@ def train(args):
                                   cache.get(int(x_1.shape[1])) if cache else None, idx, step_no)
                 step_no += 1
                 seen += x_1.shape[0]
-                loss_list.append(loss.item())
+                pending.append(loss.detach())           # .item() here (train.py:126) would drain the GPU at every step
+                if batch % 100 == 0:
+                    flush()
                 if batch % 100 == 0 and rank == 0:
                     print(f"[Epoch {epoch}] [batch {batch}] loss: {loss_list[-1]:.6f}  "
                           f"({seen / (time.time() - t0):.1f} samples/s)")
@@ -168,10 +196,12 @@ def train(args):
                 sched.step()
         if not args.mix_train:
             sched.step()
+        flush()
         if (epoch % 1000 == 0 or epoch == args.epochs - 1) and rank == 0:
             print(f"Saving model {epoch} to {args.save_path}...")
             torch.save(dict(model=model.state_dict(), optimizer=opt.state_dict(), epoch=epoch, loss_list=loss_list),
                        os.path.join(args.save_path, f"model_{epoch}.pth"))
+    flush()
     tdist.barrier(dist, device)
     return loss_list
 
