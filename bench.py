@@ -96,8 +96,8 @@ def usable_cores() -> int:
     return max(1, min(n, int(os.environ.get("T2S_CPU_BASELINE_THREADS", "16"))))
 
 
-def _cpu_cfg_steps(O, sd, x, text, tab, diff_steps, cfg, n_steps, g):
-    """Wall time per CFG step (2 DiT forwards + DDPM update) of the oracle, after one warm step."""
+def _cpu_cfg_steps(O, sd, x, text, tab, diff_steps, cfg, n_steps, g, n_warm=1):
+    """Wall time per CFG step (2 DiT forwards + DDPM update) of the oracle, after n_warm warm steps."""
     batch = x.shape[0]
 
     def one_step(x, j):
@@ -107,16 +107,18 @@ def _cpu_cfg_steps(O, sd, x, text, tab, diff_steps, cfg, n_steps, g):
         return O.ddpm_p_sample(tab, x, u + cfg * (c - u), t, torch.randn(x.shape, generator=g))
 
     with torch.no_grad():
-        x = one_step(x, 0)  # warm
+        for j in range(n_warm):
+            x = one_step(x, j)
         t0 = time.perf_counter()
-        for j in range(1, 1 + n_steps):
+        for j in range(n_warm, n_warm + n_steps):
             x = one_step(x, j)
         return (time.perf_counter() - t0) / n_steps, x
 
 
-def cpu_baseline(batch, diff_steps, cfg, length, n_cfg_steps=4, one_thread_batch=16):
-    """The CPU oracle (torch fp32) on a bounded sample of the same workload: n_cfg_steps CFG steps at the full batch
-    on this job's host cores + one decode, extrapolated to diff_steps steps (every step costs the same); plus the
+def cpu_baseline(batch, diff_steps, cfg, length, n_cfg_steps=10, n_warm=3, one_thread_batch=16):
+    """The CPU oracle (torch fp32) on a bounded sample of the same workload, as SURVEY.md section 8(d) words it: n_warm
+    warm + n_cfg_steps measured CFG steps at the full batch on this job's host cores + one decode, extrapolated to
+    diff_steps steps (every step costs the same); plus the
     single-thread figure BASELINE.md section 3 asks for, on a smaller batch (series/s on a CPU is flat in the batch:
     SURVEY.md section 6 measured 0.110 at B=32 and 0.114 at B=256).  Attention runs as F.scaled_dot_product_attention --
     what timm 1.0.11's Attention.forward (fused_attn) executes in the reference -- not the oracle's explicit softmax."""
@@ -131,7 +133,8 @@ def cpu_baseline(batch, diff_steps, cfg, length, n_cfg_steps=4, one_thread_batch
     O.set_attention_impl("sdpa")
     try:
         torch.set_num_threads(cores)
-        t_step, x = _cpu_cfg_steps(O, sd, synth.make_latents(2025, batch), text, tab, diff_steps, cfg, n_cfg_steps, g)
+        t_step, x = _cpu_cfg_steps(O, sd, synth.make_latents(2025, batch), text, tab, diff_steps, cfg, n_cfg_steps, g,
+                                   n_warm=n_warm)
         with torch.no_grad():
             t0 = time.perf_counter()
             O.vae_decode(vsd, x, length)
@@ -156,7 +159,7 @@ def cpu_baseline(batch, diff_steps, cfg, length, n_cfg_steps=4, one_thread_batch
     except OSError:
         pass
     return {"value": batch / total, "unit": "series/s", "cores": cores, "kind": "port",
-            "sample": f"{n_cfg_steps} CFG steps (2 DiT forwards + DDPM update) at B={batch} + 1 decode on {cores} threads, "
+            "sample": f"{n_warm} warm + {n_cfg_steps} measured CFG steps (2 DiT forwards + DDPM update) at B={batch} + 1 decode on {cores} threads, "
                       f"extrapolated x{diff_steps}/{n_cfg_steps}; {t_step:.3f} s/step; attention = "
                       f"F.scaled_dot_product_attention (the reference's timm fused_attn path); CPU: {cpu_model}",
             "one_thread": {"value": b1 / (t1_step * diff_steps + t1_dec), "unit": "series/s", "cores": 1,
@@ -221,7 +224,7 @@ def train_leg(dev, dist, rank, world, batch=1152, length=96, steps=30, warmup=4,
            "value": n_global * steps / el, "unit": "samples/s", "ms_per_step": el / steps * 1e3, "steps": steps,
            "warmup": warmup, "per_gpu_batch": batch, "global_batch": n_global, "dtype": dtype,
            "tflops_algorithmic": FLOP_TRAIN_PER_SAMPLE * n_global * steps / el / 1e12,
-           "loss": float(loss), "optimizer": "fused AdamW lr 1e-4 (t2s_adamw_step_multi)", "data": "synthetic"}
+           "loss": float(loss.detach()), "optimizer": "fused AdamW lr 1e-4 (t2s_adamw_step_multi)", "data": "synthetic"}
     if dist is not None:        # the same steps with the collective skipped: its share of the step
         tdist.barrier(dist, dev)
         t0 = time.perf_counter()
@@ -251,6 +254,8 @@ def train_leg(dev, dist, rank, world, batch=1152, length=96, steps=30, warmup=4,
                            "achieved": bytes_model["total"] / (kernel_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                            "frac": bytes_model["total"] / (kernel_ms * 1e-3) / 1e9 / 8000.0,
                            "traffic": _train_traffic_from_profile(batch),
+                           "traffic_source": {"file": "profiles/train_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                      "passes of tools/bench_train.py)", "measured_by_this_run": False},
                            "timing": f"sum of HIP-event launch durations over {n_t} eager steps = {kernel_ms:.2f} ms/step"}
     return out
 
@@ -300,6 +305,61 @@ def _train_traffic_from_profile(batch):
         return None
 
 
+def strong_shards(model, vae, args, dev, rate_full):
+    """BASELINE's metric read literally is B = 256 series at 1/2/4/8 GPUs ("256 total for strong
+    scaling -- report both").  Sampling has no collective, so the strong curve is decided by how fast ONE GPU samples its
+    shard of 256/N series: the same workload at B = 128, 64, 32 (one timed batch each after a warm / capture batch).
+    predicted_strong_efficiency[N] = rate(256/N) / rate(256) (series/s per GPU relative to the full batch);
+    predicted_strong_speedup[N] = N x that."""
+    from t2ms_amd import synth
+    from t2ms_amd.sampler import Sampler
+    rates = {args.batch: rate_full}
+    out = {"shards": {}}
+    for world in (2, 4, 8):
+        n = args.batch // world
+        s = Sampler(model, vae.decoder, args.backbone, args.diffusion_steps, args.cfg_scale, n, args.length, dev,
+                    use_graph=not args.no_graph, seed=2025, row0=0, lanes=args.lanes)
+        s.run(synth.make_text_embeddings(2025, n).to(dev), decode=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        s.run_inplace(decode=True)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        rates[n] = n / el
+        out["shards"][str(n)] = {"series_per_s": n / el, "ms_per_batch": el * 1e3, "gpus_for_256_total": world}
+        del s
+    out["predicted_strong_efficiency"] = {str(w): rates[args.batch // w] / rate_full for w in (2, 4, 8)}
+    out["predicted_strong_speedup"] = {str(w): w * rates[args.batch // w] / rate_full for w in (2, 4, 8)}
+    out["predicted_strong_series_per_s"] = {str(w): w * rates[args.batch // w] for w in (2, 4, 8)}
+    out["note"] = ("one GPU, the per-GPU shard of a 256-series job at N GPUs; no data-path collective, so N x rate(256/N) is "
+                   "the N-GPU strong-scaling rate up to launch skew between ranks")
+    return out
+
+
+def strong_leg(model, vae, args, dev, dist, rank, world):
+    """N > 1: the SAME 256 series as the one-GPU headline, split over the ranks (rows [lo, hi) of the global Philox
+    stream, so the union equals the N = 1 batch bit for bit) -- strong scaling next to the weak `value`."""
+    from t2ms_amd import dist as tdist
+    from t2ms_amd import synth
+    from t2ms_amd.sampler import Sampler
+    lo, hi = tdist.shard_rows(args.batch, rank, world)
+    n = hi - lo
+    s = Sampler(model, vae.decoder, args.backbone, args.diffusion_steps, args.cfg_scale, max(n, 1), args.length, dev,
+                use_graph=not args.no_graph, seed=2025, row0=lo, lanes=args.lanes)
+    text = synth.make_text_embeddings(2025, args.batch)[lo:hi].contiguous().to(dev)
+    if n:
+        s.run(text, decode=True)
+    tdist.barrier(dist, dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if n:
+            s.run_inplace(decode=True)
+    tdist.barrier(dist, dev)
+    el = tdist.max_over_ranks(dist, time.perf_counter() - t0, dev)
+    return {"value": args.batch * args.steps / el, "unit": "series/s", "scaling": "strong", "global_batch": args.batch,
+            "per_gpu_batch": args.batch // world, "ms_per_step": el / args.steps * 1e3, "steps": args.steps}
+
+
 def alt_math_run(model, vae, args, dev, text):
     """One extra batch of the same workload in bf16x3 arithmetic (include/t2s.h T2S_MATH_BF16X3: fp32-accurate,
     six bf16 MFMAs per product, attention and row chain).  Reported NEXT TO the headline, never as it."""
@@ -339,6 +399,9 @@ def main():
                     help="sampler lanes: 0 = the library's default (two half-batch chains on two streams from B >= 128), 1, 2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training leg reported as `train`")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="skip the strong-scaling figures (N = 1: `strong_shards`, the per-GPU shards 128 / 64 / 32 of a "
+                         "256-series job timed on this GPU; N > 1: `strong`, the 256 series split over the ranks)")
     ap.add_argument("--train-batch", type=int, default=1152, help="per-GPU batch of the training leg")
     ap.add_argument("--train-steps", type=int, default=30)
     ap.add_argument("--no-alt-math", action="store_true", help="skip the extra bf16x3 measurement reported as alt_math")
@@ -396,6 +459,9 @@ def main():
                    "global_batch": B * world, "diffusion_steps": args.diffusion_steps, "parallelism": f"batch-shard x{world}",
                    "sampler_lanes": lanes_used},
     }
+    strong = None
+    if dist is not None and not args.no_strong:
+        strong = strong_leg(model, vae, args, dev, dist, rank, world)
     train = None
     if not args.no_train:
         try:
@@ -440,6 +506,10 @@ def main():
         step_flops = FLOP_FORWARD_PER_SEQ * 2 * B * args.diffusion_steps * args.steps
         out["whole_path_tflops"] = step_flops / elapsed / 1e12
         out["whole_path_frac_of_fp32_mfma_peak"] = out["whole_path_tflops"] / PEAK_FP32_MFMA_TFLOPS
+        if strong is not None:
+            out["strong"] = strong
+        if world == 1 and not args.no_strong and B % 8 == 0 and B >= 64:
+            out["strong_shards"] = strong_shards(model, vae, args, dev, value)
         if world == 1 and args.math == "f32" and not args.no_alt_math:
             out["alt_math"] = alt_math_run(model, vae, args, dev, text)
         if world == 1 and not args.no_cpu_baseline:

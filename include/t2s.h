@@ -235,15 +235,17 @@ int t2s_ddpm_step(float* x, const float* eps_u, const float* eps_c, const float*
                   uint32_t row0, int B, void* stream);
 /* DDPM.p_sample as the class exposes it (DDPM.py:28-36): per-row timestep t (B) int32,
  * injected draws `noise` (B,64,30) (the host mirror supplies torch.randn like DDPM.py:35),
- * out of place. */
+ * out of place.  n_steps = T, the length of the coefficient tables: a row whose t is outside [0,T) (the reference's
+ * `gather` raises for it, DDPM.py:7-9) reads no table entry and comes out as NaN -- memory-safe and loud, without a
+ * host sync in the sampling loop. */
 int t2s_ddpm_p_sample(const float* xt, const float* eps_hat, const int32_t* t, const float* noise,
-                      const float* coef, float* out, int B, void* stream);
+                      const float* coef, float* out, int B, int n_steps, void* stream);
 /* The same two class methods on latents of another size, rows of `row_elems` floats (a multiple of 4): the MLP denoiser
  * of BASELINE configs[0] runs on the (B,64,L/4) pre-interpolation latent, not on (B,64,30). */
 int t2s_ddpm_p_sample_n(const float* xt, const float* eps_hat, const int32_t* t, const float* noise,
-                        const float* coef, float* out, int B, int row_elems, void* stream);
+                        const float* coef, float* out, int B, int row_elems, int n_steps, void* stream);
 int t2s_ddpm_q_sample_n(const float* x0, const float* eps, const int32_t* t, const float* sqrt_ab,
-                        const float* sqrt_1mab, float* out, int B, int row_elems, void* stream);
+                        const float* sqrt_1mab, float* out, int B, int row_elems, int n_steps, void* stream);
 /* DDPM.loss / RectifiedFlow.loss = F.mse_loss(a, b) (DDPM.py:37-38, rectified_flow.py:13-16):
  * mean over n elements into out[0]; fixed summation order (deterministic). */
 int t2s_mse(const float* a, const float* b, float* out, uint64_t n, void* stream);
@@ -252,9 +254,9 @@ int t2s_mse(const float* a, const float* b, float* out, uint64_t n, void* stream
 int t2s_rf_step(float* x, const float* v_u, const float* v_c, float cfg, float dt, int B,
                 void* stream);
 /* DDPM.q_sample (DDPM.py:19-27): out = sqrt_ab[t[b]]*x0 + sqrt_1mab[t[b]]*eps.
- * sqrt_ab, sqrt_1mab: (T) host-built tables; t: (B) int32. */
+ * sqrt_ab, sqrt_1mab: (T) host-built tables, T = n_steps; t: (B) int32 (out of range -> NaN row, see p_sample). */
 int t2s_ddpm_q_sample(const float* x0, const float* eps, const int32_t* t, const float* sqrt_ab,
-                      const float* sqrt_1mab, float* out, int B, void* stream);
+                      const float* sqrt_1mab, float* out, int B, int n_steps, void* stream);
 /* RectifiedFlow.create_flow (rectified_flow.py:8-12): out = t*x1 + (1-t)*x0, t: (B) fp32. */
 int t2s_rf_create_flow(const float* x1, const float* x0, const float* t, float* out, int B,
                        void* stream);
@@ -348,6 +350,10 @@ void t2s_sampler_destroy(t2s_sampler* s);
  *   noise  (steps,B,64,30) injected per-step draws (parity mode) or NULL (Philox, perf mode)
  *   series (B,L) decoded output, or NULL
  *   trace0 (steps,L) or NULL: decode of row 0 after every step (infer.py:90-93)
+ *   stream NULL = the default stream.  With use_graph = 1 the graphs are then captured and replayed on a stream
+ *          the sampler owns (the default stream cannot be captured), ordered after everything queued on the default
+ *          stream before the call and joined back to it before the call returns -- same semantics, never an eager
+ *          fallback.  trace0 runs are eager by design (a decode between the steps).
  */
 int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, const float* noise,
                     float* series, float* trace0, void* stream);
@@ -361,6 +367,9 @@ int t2s_sampler_set_lanes(t2s_sampler* s, int lanes);
  * row0 + r).  Takes effect at the next t2s_sampler_run; the captured hipGraphs are kept (the kernels read the
  * value from device memory next to the step counter).  infer.py:66 loops over batches with one sampler. */
 int t2s_sampler_set_row0(t2s_sampler* s, uint32_t row0);
+/* Number of lanes the sampler currently holds an instantiated hipGraph for (0: the last run was eager / nothing run
+ * yet).  Lets a caller (and tests/test_hip_parity.py) check that use_graph = 1 really replays a graph. */
+int t2s_sampler_graph_lanes(const t2s_sampler* s);
 
 /* ------------------------------------------------------------------------ *
  * Evaluation metrics: evaluation.py:166-206 (calculate_mse, calculate_wape), :21-45 (calculate_mrr)

@@ -111,13 +111,13 @@ SYMBOLS = {
     "t2s_attn_fwd": (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_attn_fwd_packed": (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_ddpm_step": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _F, _U64, _U32, _U32, _I, _VP]),
-    "t2s_ddpm_p_sample": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
-    "t2s_ddpm_p_sample_n": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP]),
-    "t2s_ddpm_q_sample_n": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP]),
+    "t2s_ddpm_p_sample": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP]),
+    "t2s_ddpm_p_sample_n": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
+    "t2s_ddpm_q_sample_n": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
     "t2s_vae_decode_w": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
     "t2s_mse": (_I, [_VP, _VP, _VP, _U64, _VP]),
     "t2s_rf_step": (_I, [_VP, _VP, _VP, _F, _F, _I, _VP]),
-    "t2s_ddpm_q_sample": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
+    "t2s_ddpm_q_sample": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP]),
     "t2s_rf_create_flow": (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_philox_normal": (_I, [_VP, _U64, _U32, _U32, _I, _I, _VP]),
     "t2s_vae_create": (_I, [C.POINTER(VaeWeights), C.POINTER(_VP)]),
@@ -129,6 +129,7 @@ SYMBOLS = {
     "t2s_sampler_run": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "t2s_sampler_set_lanes": (_I, [_VP, _I]),
     "t2s_sampler_set_row0": (_I, [_VP, _U32]),
+    "t2s_sampler_graph_lanes": (_I, [_VP]),
 }
 
 _lib: Optional[C.CDLL] = None

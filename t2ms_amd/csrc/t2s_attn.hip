@@ -21,6 +21,8 @@
 // one's softmax (VALU) overlaps another's MFMAs.
 //
 // attn_fwd_plain_kernel: same math on plain (BH,480,32) tensors for the standalone C-ABI entry.
+#include <stdlib.h>
+
 #include "t2s_common.h"
 
 namespace t2s {
@@ -79,8 +81,8 @@ constexpr int NKB = NTOK / 32;                          // 15 key blocks / query
 // free), then 16 v_exp + a 16-term sum; no per-block max, no output rescale.  m_ref is the true
 // running max as of the last re-reference; a block is re-referenced (classic online-softmax
 // step, recomputed from raw scores) only when its exponentials show that m_ref is stale by
-// more than 2^60 -- detected a posteriori from the row sum, wave-uniformly.  Block 0 always
-// re-references (m_ref starts at -inf, so its common-path sum is +inf).
+// more than 2^60 -- detected a posteriori from the row sum, wave-uniformly.  Block 0 has no reference
+// (m_ref = -inf): it enters the reference-setting path directly, skipping the common path.
 constexpr float SM_BIG = 1.152921504606847e18f;   // 2^60
 
 
@@ -172,20 +174,27 @@ __device__ __forceinline__ void attn_packed_body(f32x4* ring, const f32x4* qg, c
 #pragma unroll
         for (int g = 0; g < 4; ++g) vf[g] = slot[256 + g * 64];
 
-        // scores relative to the sticky reference (C operand of the first MFMA, kept in its own registers)
-        f32x16 sta = mfma32_from(kf[0][0], qa[0][0], ta.negm);
-        f32x16 stb = (NT == 2) ? mfma32_from(kf[0][0], qb[0][0], tb.negm) : tb.negm;
+        // scores relative to the sticky reference (C operand of the first MFMA, kept in its own registers).
+        // Block 0 has no reference yet: it goes straight to the reference-setting path (one QK pass, not two).
+        f32x16 sta = ta.negm, stb = tb.negm;
+        float psa = 0.f, psb = 0.f;
+        bool redo = jb == 0;                                  // scalar
+        if (!redo) {
+            sta = mfma32_from(kf[0][0], qa[0][0], ta.negm);
+            if (NT == 2) stb = mfma32_from(kf[0][0], qb[0][0], tb.negm);
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int e = (g == 0 ? 1 : 0); e < 4; ++e) {
-                sta = mfma32(kf[g][e], qa[g][e], sta);
-                if (NT == 2) stb = mfma32(kf[g][e], qb[g][e], stb);
-            }
-        float psa = exp_sum(sta);
-        float psb = (NT == 2) ? exp_sum(stb) : 0.f;
-        const bool stale = !(psa < SM_BIG) || !(psb < SM_BIG);
-        if (__builtin_amdgcn_ballot_w64(stale) != 0) {   // wave-uniform, rare
+                for (int e = (g == 0 ? 1 : 0); e < 4; ++e) {
+                    sta = mfma32(kf[g][e], qa[g][e], sta);
+                    if (NT == 2) stb = mfma32(kf[g][e], qb[g][e], stb);
+                }
+            psa = exp_sum(sta);
+            if (NT == 2) psb = exp_sum(stb);
+            const bool stale = !(psa < SM_BIG) || !(psb < SM_BIG);
+            redo = __builtin_amdgcn_ballot_w64(stale) != 0;   // wave-uniform, rare
+        }
+        if (redo) {
             psa = rereference(kf, qa, sta, oa, ta);
             if (NT == 2) psb = rereference(kf, qb, stb, ob, tb);
         }
@@ -339,19 +348,26 @@ __device__ __forceinline__ void attn_persistent_body(f32x4* ring, const f32x4* q
             f32x4 vf[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) vf[g] = slot[256 + g * 64];
-            f32x16 sta = mfma32_from(kf[0][0], qa[0][0], ta.negm);
-            f32x16 stb = (NT == 2) ? mfma32_from(kf[0][0], qb[0][0], tb.negm) : tb.negm;
+            // block 0 of a head has no reference yet: straight to the reference-setting path (one QK pass, not two)
+            f32x16 sta = ta.negm, stb = tb.negm;
+            float psa = 0.f, psb = 0.f;
+            bool redo = jb == 0;                                  // scalar
+            if (!redo) {
+                sta = mfma32_from(kf[0][0], qa[0][0], ta.negm);
+                if (NT == 2) stb = mfma32_from(kf[0][0], qb[0][0], tb.negm);
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int e = (g == 0 ? 1 : 0); e < 4; ++e) {
-                    sta = mfma32(kf[g][e], qa[g][e], sta);
-                    if (NT == 2) stb = mfma32(kf[g][e], qb[g][e], stb);
-                }
-            float psa = exp_sum(sta);
-            float psb = (NT == 2) ? exp_sum(stb) : 0.f;
-            const bool stale = !(psa < SM_BIG) || !(psb < SM_BIG);
-            if (__builtin_amdgcn_ballot_w64(stale) != 0) {   // wave-uniform, rare
+                    for (int e = (g == 0 ? 1 : 0); e < 4; ++e) {
+                        sta = mfma32(kf[g][e], qa[g][e], sta);
+                        if (NT == 2) stb = mfma32(kf[g][e], qb[g][e], stb);
+                    }
+                psa = exp_sum(sta);
+                if (NT == 2) psb = exp_sum(stb);
+                const bool stale = !(psa < SM_BIG) || !(psb < SM_BIG);
+                redo = __builtin_amdgcn_ballot_w64(stale) != 0;   // wave-uniform, rare
+            }
+            if (redo) {
                 psa = rereference(kf, qa, sta, oa, ta);
                 if (NT == 2) psb = rereference(kf, qb, stb, ob, tb);
             }
@@ -440,7 +456,11 @@ int launch_attn_packed(const float* q, const float* k, const float* vT, float* o
         else
             n_cu = 256;
     }
-    if (BH >= 2 * n_cu) {
+    // persistent from one head per CU on (32 series per GPU in a CFG pass = 256 heads: the shard size of an 8-GPU
+    // strong-scaling run); below that the two-workgroups-per-head kernel spreads a head over two CUs.
+    // T2S_ATTN_PERSIST_MIN=<heads> moves the switch point (A/B runs).
+    static const int persist_min = getenv("T2S_ATTN_PERSIST_MIN") ? atoi(getenv("T2S_ATTN_PERSIST_MIN")) : 0;
+    if (BH >= (persist_min > 0 ? persist_min : n_cu)) {
         // persistent: one 8-wave workgroup per CU walks the heads
         attn_fwd_persistent_kernel<<<n_cu, PERSIST_THREADS, ATT_LDS_BYTES, st>>>(q, k, vT, o, BH);
     } else {

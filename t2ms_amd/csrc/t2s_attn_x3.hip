@@ -188,9 +188,13 @@ __device__ __forceinline__ void attn_x3_body(bf16x8* ring, const f32x4* qall, co
 #pragma unroll 1
         for (int jb = 0; jb < NKB; ++jb, ++gb) {
             // ---- QK^T (MFMA)
-            f32x16 sta = scores_from(kf, qa, ta.negm);
-            f32x16 stb = tb.negm;
-            if (NT == 2) stb = scores_from(kf, qb, tb.negm);
+            // block 0 of a head has no reference yet: straight to the reference-setting path (one QK pass, not two)
+            const bool first = jb == 0;                           // scalar
+            f32x16 sta = ta.negm, stb = tb.negm;
+            if (!first) {
+                sta = scores_from(kf, qa, ta.negm);
+                if (NT == 2) stb = scores_from(kf, qb, tb.negm);
+            }
             if (STAG) {
                 wait_but(1);
                 __builtin_amdgcn_s_barrier();
@@ -205,10 +209,15 @@ __device__ __forceinline__ void attn_x3_body(bf16x8* ring, const f32x4* qall, co
                 vf[s].l = slot[(6 + 4 + s) * 64];
             }
             // ---- softmax + split of P^T (VALU)
-            float psa = exp_sum(sta);
-            float psb = (NT == 2) ? exp_sum(stb) : 0.f;
-            const bool stale = !(psa < SM_BIG) || !(psb < SM_BIG);
-            if (__builtin_amdgcn_ballot_w64(stale) != 0) {   // wave-uniform, rare
+            float psa = 0.f, psb = 0.f;
+            bool redo = first;
+            if (!first) {
+                psa = exp_sum(sta);
+                if (NT == 2) psb = exp_sum(stb);
+                const bool stale = !(psa < SM_BIG) || !(psb < SM_BIG);
+                redo = __builtin_amdgcn_ballot_w64(stale) != 0;   // wave-uniform, rare
+            }
+            if (redo) {
                 psa = rereference(kf, qa, sta, oa, ta);
                 if (NT == 2) psb = rereference(kf, qb, stb, ob, tb);
             }

@@ -30,14 +30,15 @@ namespace t2s {
 // read -- last, which is what the 256 MB Infinity Cache still holds (a tensor is 142-283 MB).  Results do not depend on
 // the order (tiles are independent, partial-sum slots keep their slab index).  T2S_TILE_FLIP=0 switches it off for A/B:
 // 11.7-11.8 vs 12.0-12.1 ms per step on one box, weight gradients 2.03 -> 1.91 ms.
-inline int g_tile_flip_enabled = -1;
-inline unsigned g_tile_flip = 0;
+// The parity counter is per host thread (a handle is driven by one thread at a time; two models training from two
+// threads keep their own patterns) and restarts at the top of every training forward / backward.
+inline thread_local unsigned g_tile_flip = 0;
 // at the top of the training forward / backward: the same pattern every step, starting DESCENDING (the patchify and
 // final-layer kernels in front of the first GEMM / weight gradient write ascending)
 inline void reset_tile_dir() { g_tile_flip = 1; }
 inline int next_tile_dir() {
-    if (g_tile_flip_enabled < 0) g_tile_flip_enabled = getenv("T2S_TILE_FLIP") ? atoi(getenv("T2S_TILE_FLIP")) : 1;
-    return g_tile_flip_enabled ? (int)(g_tile_flip++ & 1) : 0;
+    static const int enabled = getenv("T2S_TILE_FLIP") ? atoi(getenv("T2S_TILE_FLIP")) : 1;   // read once
+    return enabled ? (int)(g_tile_flip++ & 1) : 0;
 }
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -501,7 +502,6 @@ inline int launch_bgemm(const BGemmArgs& a, hipStream_t st) {
     }
     const int tiles = a.M / 32, per_wg = THREADS / 64;
     int grid = (tiles + per_wg - 1) / per_wg < n_cu ? (tiles + per_wg - 1) / per_wg : n_cu;
-    if (const char* e = getenv("T2S_BG_GRID")) grid = (tiles + per_wg - 1) / per_wg < atoi(e) ? (tiles + per_wg - 1) / per_wg : atoi(e);
     BGemmArgs a2 = a;
     a2.reverse = next_tile_dir();
     bgemm_kernel<K, N, PRO, EPI><<<grid, THREADS, lds, st>>>(a2);

@@ -89,19 +89,55 @@ __global__ void time_embedding_kernel(const float* __restrict__ t, const float* 
     out[b * D + 64 + i] = cosf(arg);
 }
 
-// c = t_emb (+ text) (transformer.py:176-178).  Rows [0,uncond_rows) get no text.
-// With step_ptr != NULL, temb is a (steps,128) table and row *step_ptr is used for every sequence
-// (the sampling loop: t is shared by the batch, infer.py:78,84).
-__global__ void cond_kernel(float* __restrict__ c, const float* __restrict__ temb, int temb_rows,
-                            const int* __restrict__ step_ptr, const float* __restrict__ text,
-                            int uncond_rows, int S) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= S * D) return;
-    const int s = idx >> 7, d = idx & 127;
-    const int trow = step_ptr ? *step_ptr : (temb_rows == 1 ? 0 : s);
-    float val = temb[(size_t)trow * D + d];
-    if (s >= uncond_rows) val += text[(size_t)(s - uncond_rows) * D + d];
-    c[idx] = val;
+// adaLN modulation of all 4 blocks (transformer.py:106-109,115,176-178) in ONE launch:
+//   mod[s][:] = silu(c[s]) @ W_ada^T + b,   c[s] = t_emb (+ text[s - uncond_rows] for s >= uncond_rows).
+// With step_ptr != NULL, temb is a (steps,128) table and row *step_ptr is used for every sequence (the sampling
+// loop: t is shared by the batch, infer.py:78,84).
+// This is a latency problem, not a throughput one (S x 3072 x 128: 0.05-0.4 GFLOP): one wave per (32 sequences,
+// 32 outputs) tile = 64 MFMAs, the A operand (silu(c)) built straight in registers, the packed weights read from
+// L2 -- 384 waves at S = 64, 1536 at S = 512.  (The generic gemm_rows_kernel ran it as 8 workgroups of 384 MFMAs per
+// wave at S = 64: 29 us of a 690 us sampling step.)
+__global__ __launch_bounds__(256) void adaln_kernel(float* __restrict__ mod, const float* __restrict__ temb,
+                                                    int temb_rows, const int* __restrict__ step_ptr,
+                                                    const float* __restrict__ text, int uncond_rows, int S,
+                                                    const f32x4* __restrict__ Wp, const float* __restrict__ bias) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int nt = blockIdx.y * 4 + wave;                 // 32-output tile, 0..95
+    const int row = blockIdx.x * 32 + j;
+    const int rl = row < S ? row : S - 1;                 // clamped for the loads
+    const int trow = step_ptr ? *step_ptr : (temb_rows == 1 ? 0 : rl);
+    const f32x4* tp = reinterpret_cast<const f32x4*>(temb + (size_t)trow * D) + half;
+    const f32x4* xp = rl >= uncond_rows ? reinterpret_cast<const f32x4*>(text + (size_t)(rl - uncond_rows) * D) + half
+                                        : nullptr;
+    const f32x4* wp = Wp + (size_t)nt * 16 * 64 + lane;
+    f32x4 a[16], b[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) b[g] = wp[g * 64];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        f32x4 v = tp[2 * g];
+        if (xp) v += xp[2 * g];
+        v.x = v.x / (1.0f + __expf(-v.x));
+        v.y = v.y / (1.0f + __expf(-v.y));
+        v.z = v.z / (1.0f + __expf(-v.z));
+        v.w = v.w / (1.0f + __expf(-v.w));
+        a[g] = v;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma32(a[g][e], b[g][e], acc);
+    const int col = nt * 32 + j;
+    const float bv = bias[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int grow = blockIdx.x * 32 + acc_row(r, half);
+        if (grow < S) mod[(size_t)grow * MODROW + col] = acc[r] + bv;
+    }
 }
 
 // patchify (transformer.py:166-172): token n = hh*32 + ww reads the 2x2 patch
@@ -248,20 +284,13 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
     float* const w_ao = h->ao + tok0;
     float* const w_h0 = h->h0 + tok0 / 2;                      // one slot per PAIR of sequences (CFG pass)
     float* const w_mod = h->mod + (size_t)ws_seq0 * MODROW;
-    float* const w_c = h->c + (size_t)ws_seq0 * D;
     __bf16* const w_k3 = h->k3 ? h->k3 + tok0 * 3 : nullptr;
     __bf16* const w_v3 = h->v3 ? h->v3 + tok0 * 3 : nullptr;
-    {
+    {   // adaLN for all 4 blocks at once: mod = silu(c) @ W_ada^T + b, c = t_emb (+ text)
         TimeScope ts(h, TC_OTHER, st);
-        cond_kernel<<<(S * D + 255) / 256, 256, 0, st>>>(w_c, temb, temb_rows, step_ptr, text,
-                                                         uncond_rows, S);
-    }
-    T2S_LAUNCH_CHECK();
-    {   // adaLN for all 4 blocks at once: mod = silu(c) @ W_ada^T + b   (transformer.py:106-109,115)
-        GemmArgs a{};
-        a.A = w_c; a.Wp = h->ada_p; a.bias = h->ada_b; a.out = w_mod; a.M = S; a.N = MODROW;
-        TimeScope ts(h, TC_OTHER, st);
-        if ((rc = launch_gemm_rows<128, 3, PRO_SILU, EPI_BIAS>(a, st)) != T2S_OK) return rc;
+        adaln_kernel<<<dim3((S + 31) / 32, MODROW / 128), 256, 0, st>>>(w_mod, temb, temb_rows, step_ptr, text,
+                                                                       uncond_rows, S, h->ada_p, h->ada_b);
+        T2S_LAUNCH_CHECK();
     }
     // patchify: the two branches of a CFG pass (S == 2B) see the same tokens, so only B sequences are
     // computed, into their own buffer; block 0's kernels read sequence s % B from it (in place would race:
@@ -395,9 +424,9 @@ int t2s_dit_create(const t2s_dit_weights* w, int max_seqs, t2s_dit** out) {
         h->fc2_c[i] = reinterpret_cast<f32x4*>(A + o_fc2_c[i]);
     }
     const size_t S = (size_t)max_seqs, tokD = S * NTOK * D;
-    float** bufs[] = {&h->h, &h->q, &h->k, &h->v, &h->ao, &h->mod, &h->c, &h->h0};
-    const size_t sizes[] = {tokD, tokD, tokD, tokD, tokD, S * MODROW, S * D, (S / 2 + 1) * NTOK * D};
-    for (int i = 0; i < 8; ++i) {
+    float** bufs[] = {&h->h, &h->q, &h->k, &h->v, &h->ao, &h->mod, &h->h0};
+    const size_t sizes[] = {tokD, tokD, tokD, tokD, tokD, S * MODROW, (S / 2 + 1) * NTOK * D};
+    for (int i = 0; i < 7; ++i) {
         e = hipMalloc(bufs[i], sizes[i] * sizeof(float));
         if (e != hipSuccess) {
             set_error("t2s_dit_create: hipMalloc(workspace %d, %zu B) failed: %s", i,
@@ -464,7 +493,7 @@ void t2s_dit_destroy(t2s_dit* h) {
     if (h->k3) (void)hipFree(h->k3);
     if (h->v3) (void)hipFree(h->v3);
     if (h->w3) (void)hipFree(h->w3);
-    float* bufs[] = {h->arena, h->h, h->q, h->k, h->v, h->ao, h->mod, h->c, h->h0};
+    float* bufs[] = {h->arena, h->h, h->q, h->k, h->v, h->ao, h->mod, h->h0};
     for (float* b : bufs)
         if (b) (void)hipFree(b);
     delete h;

@@ -16,7 +16,7 @@ struct t2s_dit {
     // workspace (device), activations fragment-major
     float *h = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *ao = nullptr;
     float* h0 = nullptr;         // patchified tokens of the B distinct sequences of a CFG pass (both branches share them)
-    float *mod = nullptr, *c = nullptr;
+    float* mod = nullptr;        // (S, MODROW) adaLN modulation of all blocks (adaln_kernel)
     // T2S_MATH_BF16X3: k and V^T of the running block as split bf16 planes (t2s_x3.h), allocated on first use
     int math = 0;
     __bf16 *k3 = nullptr, *v3 = nullptr;

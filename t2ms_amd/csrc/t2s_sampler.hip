@@ -84,60 +84,83 @@ struct StepArgs {
     uint32_t row0;
     int B;
     int noise_rows;       // rows per step of the injected-noise array (>= B: a lane steps a row range of the batch)
+    int* advance;         // sampling loop: device {loop index, row0, arrival counter}; the last workgroup increments the index
 };
+
+// Last workgroup to finish advances the device loop index (step[0]; step[2] is the arrival counter): every
+// workgroup has read step[0] before it arrives, so the increment cannot overtake a reader, and the stand-alone
+// one-thread set_step launch per step (4 us of a 690 us step at 32 series) is gone.
+__device__ __forceinline__ void advance_step_when_last(int* step) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&step[2], 1) == (int)gridDim.x - 1) {
+            step[2] = 0;
+            step[0] += 1;
+        }
+    }
+}
 
 __global__ __launch_bounds__(256) void ddpm_step_kernel(const StepArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one float4 (quad) per thread
     constexpr int QPR = LAT / 4;
-    if (idx >= a.B * QPR) return;
-    int t = a.t_index;
-    uint32_t sid = a.stream_id, row0 = a.row0;
-    const float* noise = a.noise;
-    if (a.step_ptr) {
-        const int j = a.step_ptr[0];
-        row0 = (uint32_t)a.step_ptr[1];   // read on the device so a captured graph serves every shard position
-        t = a.steps - 1 - j;
-        sid = (uint32_t)j;
-        if (noise) noise += (size_t)j * a.noise_rows * LAT;
+    if (idx < a.B * QPR) {
+        int t = a.t_index;
+        uint32_t sid = a.stream_id, row0 = a.row0;
+        const float* noise = a.noise;
+        if (a.step_ptr) {
+            const int j = a.step_ptr[0];
+            row0 = (uint32_t)a.step_ptr[1];   // read on the device so a captured graph serves every shard position
+            t = a.steps - 1 - j;
+            sid = (uint32_t)j;
+            if (noise) noise += (size_t)j * a.noise_rows * LAT;
+        }
+        const float c0 = a.coef[t * 3 + 0], c1 = a.coef[t * 3 + 1], c2 = a.coef[t * 3 + 2];
+        const f32x4 x = reinterpret_cast<const f32x4*>(a.x)[idx];
+        const f32x4 u = reinterpret_cast<const f32x4*>(a.eps_u)[idx];
+        f32x4 pred = u;
+        if (a.eps_c) {
+            const f32x4 c = reinterpret_cast<const f32x4*>(a.eps_c)[idx];
+            pred = u + a.cfg * (c - u);
+        }
+        f32x4 z;
+        if (noise) {
+            z = reinterpret_cast<const f32x4*>(noise)[idx];
+        } else {
+            const int row = idx / QPR, quad = idx - row * QPR;
+            z = normal4(a.seed, sid, row0 + (uint32_t)row, (uint32_t)quad);
+        }
+        const f32x4 mean = c0 * (x - c1 * pred);
+        reinterpret_cast<f32x4*>(a.x)[idx] = mean + c2 * z;
     }
-    const float c0 = a.coef[t * 3 + 0], c1 = a.coef[t * 3 + 1], c2 = a.coef[t * 3 + 2];
-    const f32x4 x = reinterpret_cast<const f32x4*>(a.x)[idx];
-    const f32x4 u = reinterpret_cast<const f32x4*>(a.eps_u)[idx];
-    f32x4 pred = u;
-    if (a.eps_c) {
-        const f32x4 c = reinterpret_cast<const f32x4*>(a.eps_c)[idx];
-        pred = u + a.cfg * (c - u);
-    }
-    f32x4 z;
-    if (noise) {
-        z = reinterpret_cast<const f32x4*>(noise)[idx];
-    } else {
-        const int row = idx / QPR, quad = idx - row * QPR;
-        z = normal4(a.seed, sid, row0 + (uint32_t)row, (uint32_t)quad);
-    }
-    const f32x4 mean = c0 * (x - c1 * pred);
-    reinterpret_cast<f32x4*>(a.x)[idx] = mean + c2 * z;
+    if (a.advance) advance_step_when_last(a.advance);
 }
 
 __global__ __launch_bounds__(256) void rf_step_kernel(float* __restrict__ x, const float* __restrict__ vu,
                                                       const float* __restrict__ vc, float cfg, float dt,
-                                                      int n4) {
+                                                      int n4, int* advance) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n4) return;
-    const f32x4 u = reinterpret_cast<const f32x4*>(vu)[idx];
-    f32x4 pred = u;
-    if (vc) pred = u + cfg * (reinterpret_cast<const f32x4*>(vc)[idx] - u);
-    f32x4 xv = reinterpret_cast<f32x4*>(x)[idx];
-    reinterpret_cast<f32x4*>(x)[idx] = xv + pred * dt;
+    if (idx < n4) {
+        const f32x4 u = reinterpret_cast<const f32x4*>(vu)[idx];
+        f32x4 pred = u;
+        if (vc) pred = u + cfg * (reinterpret_cast<const f32x4*>(vc)[idx] - u);
+        f32x4 xv = reinterpret_cast<f32x4*>(x)[idx];
+        reinterpret_cast<f32x4*>(x)[idx] = xv + pred * dt;
+    }
+    if (advance) advance_step_when_last(advance);
 }
 
 __global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ eps,
                                                        const int32_t* __restrict__ t, const float* __restrict__ sab,
                                                        const float* __restrict__ s1m, float* __restrict__ out, int B,
-                                                       int QPR) {
+                                                       int QPR, int T) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * QPR) return;
     const int tt = t[idx / QPR];
+    if (tt < 0 || tt >= T) {      // the reference's gather raises (DDPM.py:7-9): no table read, a loud NaN row
+        reinterpret_cast<f32x4*>(out)[idx] = f32x4{NAN, NAN, NAN, NAN};
+        return;
+    }
     const f32x4 a = reinterpret_cast<const f32x4*>(x0)[idx];
     const f32x4 e = reinterpret_cast<const f32x4*>(eps)[idx];
     reinterpret_cast<f32x4*>(out)[idx] = sab[tt] * a + s1m[tt] * e;
@@ -158,10 +181,14 @@ __global__ __launch_bounds__(256) void create_flow_kernel(const float* __restric
 __global__ __launch_bounds__(256) void p_sample_rows_kernel(const float* __restrict__ xt, const float* __restrict__ eh,
                                                             const int32_t* __restrict__ t, const float* __restrict__ noise,
                                                             const float* __restrict__ coef, float* __restrict__ out, int B,
-                                                            int QPR) {
+                                                            int QPR, int T) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * QPR) return;
     const int tt = t[idx / QPR];
+    if (tt < 0 || tt >= T) {
+        reinterpret_cast<f32x4*>(out)[idx] = f32x4{NAN, NAN, NAN, NAN};
+        return;
+    }
     const float c0 = coef[tt * 3 + 0], c1 = coef[tt * 3 + 1], c2 = coef[tt * 3 + 2];
     const f32x4 x = reinterpret_cast<const f32x4*>(xt)[idx];
     const f32x4 e = reinterpret_cast<const f32x4*>(eh)[idx];
@@ -220,15 +247,13 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, c
     }
 }
 
-// step[0] = loop index, step[1] = global row index of the lane's first series (Philox key)
-__global__ void set_step_kernel(int* step, int value, int delta, uint32_t row0) {
+// step[0] = loop index, step[1] = global row index of the lane's first series (Philox key), step[2] = arrival counter
+// of the update kernel (advance_step_when_last)
+__global__ void set_step_kernel(int* step, int value, uint32_t row0) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        if (delta) {
-            step[0] += delta;
-        } else {
-            step[0] = value;
-            step[1] = (int)row0;
-        }
+        step[0] = value;
+        step[1] = (int)row0;
+        step[2] = 0;
     }
 }
 
@@ -266,39 +291,39 @@ extern "C" int t2s_ddpm_step(float* x, const float* eps_u, const float* eps_c, c
 extern "C" int t2s_rf_step(float* x, const float* v_u, const float* v_c, float cfg, float dt, int B, void* stream) {
     T2S_REQUIRE(x && v_u && B > 0, "t2s_rf_step: bad argument");
     const int n4 = B * (LAT / 4);
-    rf_step_kernel<<<(n4 + 255) / 256, 256, 0, (hipStream_t)stream>>>(x, v_u, v_c, cfg, dt, n4);
+    rf_step_kernel<<<(n4 + 255) / 256, 256, 0, (hipStream_t)stream>>>(x, v_u, v_c, cfg, dt, n4, nullptr);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }
 
 extern "C" int t2s_ddpm_q_sample_n(const float* x0, const float* eps, const int32_t* t, const float* sqrt_ab,
-                                   const float* sqrt_1mab, float* out, int B, int row_elems, void* stream) {
-    T2S_REQUIRE(x0 && eps && t && sqrt_ab && sqrt_1mab && out && B > 0, "t2s_ddpm_q_sample: bad argument");
+                                   const float* sqrt_1mab, float* out, int B, int row_elems, int n_steps, void* stream) {
+    T2S_REQUIRE(x0 && eps && t && sqrt_ab && sqrt_1mab && out && B > 0 && n_steps > 0, "t2s_ddpm_q_sample: bad argument");
     T2S_REQUIRE(row_elems > 0 && row_elems % 4 == 0, "t2s_ddpm_q_sample: row_elems=%d must be a positive multiple of 4", row_elems);
     const int total = B * (row_elems / 4);
-    q_sample_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(x0, eps, t, sqrt_ab, sqrt_1mab, out, B, row_elems / 4);
+    q_sample_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(x0, eps, t, sqrt_ab, sqrt_1mab, out, B, row_elems / 4, n_steps);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }
 
 extern "C" int t2s_ddpm_q_sample(const float* x0, const float* eps, const int32_t* t, const float* sqrt_ab,
-                                 const float* sqrt_1mab, float* out, int B, void* stream) {
-    return t2s_ddpm_q_sample_n(x0, eps, t, sqrt_ab, sqrt_1mab, out, B, LAT, stream);
+                                 const float* sqrt_1mab, float* out, int B, int n_steps, void* stream) {
+    return t2s_ddpm_q_sample_n(x0, eps, t, sqrt_ab, sqrt_1mab, out, B, LAT, n_steps, stream);
 }
 
 extern "C" int t2s_ddpm_p_sample_n(const float* xt, const float* eps_hat, const int32_t* t, const float* noise,
-                                   const float* coef, float* out, int B, int row_elems, void* stream) {
-    T2S_REQUIRE(xt && eps_hat && t && noise && coef && out && B > 0, "t2s_ddpm_p_sample: bad argument");
+                                   const float* coef, float* out, int B, int row_elems, int n_steps, void* stream) {
+    T2S_REQUIRE(xt && eps_hat && t && noise && coef && out && B > 0 && n_steps > 0, "t2s_ddpm_p_sample: bad argument");
     T2S_REQUIRE(row_elems > 0 && row_elems % 4 == 0, "t2s_ddpm_p_sample: row_elems=%d must be a positive multiple of 4", row_elems);
     const int total = B * (row_elems / 4);
-    p_sample_rows_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(xt, eps_hat, t, noise, coef, out, B, row_elems / 4);
+    p_sample_rows_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(xt, eps_hat, t, noise, coef, out, B, row_elems / 4, n_steps);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }
 
 extern "C" int t2s_ddpm_p_sample(const float* xt, const float* eps_hat, const int32_t* t, const float* noise,
-                                 const float* coef, float* out, int B, void* stream) {
-    return t2s_ddpm_p_sample_n(xt, eps_hat, t, noise, coef, out, B, LAT, stream);
+                                 const float* coef, float* out, int B, int n_steps, void* stream) {
+    return t2s_ddpm_p_sample_n(xt, eps_hat, t, noise, coef, out, B, LAT, n_steps, stream);
 }
 
 extern "C" int t2s_mse(const float* a, const float* b, float* out, uint64_t n, void* stream) {
@@ -340,6 +365,10 @@ struct t2s_sampler {
     hipGraphExec_t exec[2] = {nullptr, nullptr};
     hipStream_t side = nullptr;   // lane 1
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // stream == NULL at the C ABI means the default stream, which cannot be captured: graph runs then go through a
+    // stream the sampler owns, forked from and joined to the default stream by events inside the call
+    hipStream_t own = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
     // pointers the captured graphs were built for
     float* g_x = nullptr;
     const float* g_text = nullptr;
@@ -362,16 +391,14 @@ int enqueue_step(t2s_sampler* s, float* x, const float* text, const float* noise
         StepArgs a{};
         a.x = xl; a.eps_u = eu; a.eps_c = ec; a.noise = noise ? noise + (size_t)r0 * LAT : nullptr; a.coef = s->coef;
         a.step_ptr = step; a.steps = c.steps; a.cfg = c.cfg_scale; a.seed = c.seed; a.row0 = c.row0 + (uint32_t)r0;
-        a.B = n; a.noise_rows = c.batch;
+        a.B = n; a.noise_rows = c.batch; a.advance = step;
         const int total = n * (LAT / 4);
         ddpm_step_kernel<<<(total + 255) / 256, 256, 0, st>>>(a);
     } else {
         const int n4 = n * (LAT / 4);
-        rf_step_kernel<<<(n4 + 255) / 256, 256, 0, st>>>(xl, eu, ec, c.cfg_scale, 1.0f / (float)c.steps, n4);
+        rf_step_kernel<<<(n4 + 255) / 256, 256, 0, st>>>(xl, eu, ec, c.cfg_scale, 1.0f / (float)c.steps, n4, step);
     }
-    T2S_LAUNCH_CHECK();
-    set_step_kernel<<<1, 64, 0, st>>>(step, 0, 1, 0u);
-    T2S_LAUNCH_CHECK();
+    T2S_LAUNCH_CHECK();   // (the update kernel's last workgroup advanced the lane's loop index)
     return T2S_OK;
 }
 
@@ -455,12 +482,17 @@ extern "C" int t2s_sampler_set_row0(t2s_sampler* s, uint32_t row0) {
     return T2S_OK;
 }
 
+extern "C" int t2s_sampler_graph_lanes(const t2s_sampler* s) { return (s && s->exec[0]) ? s->lanes_cap : 0; }
+
 extern "C" void t2s_sampler_destroy(t2s_sampler* s) {
     if (!s) return;
     drop_graph(s);
     if (s->side) (void)hipStreamDestroy(s->side);
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+    if (s->own) (void)hipStreamDestroy(s->own);
+    if (s->ev_in) (void)hipEventDestroy(s->ev_in);
+    if (s->ev_out) (void)hipEventDestroy(s->ev_out);
     void* bufs[] = {s->temb_table, s->coef, s->eps_u, s->eps_c, s->tvals, s->step};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -478,6 +510,18 @@ extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, cons
     const t2s_sample_config& c = s->cfg;
     int rc;
     const int lanes = pick_lanes(s, trace0 != nullptr);
+    const bool graph_ok = c.use_graph && !trace0;
+    const bool via_own = graph_ok && st == nullptr;   // the default stream cannot be captured: never a silent eager run
+    if (via_own) {
+        if (!s->own) {
+            T2S_HIP_CHECK(hipStreamCreateWithFlags(&s->own, hipStreamNonBlocking));
+            T2S_HIP_CHECK(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
+            T2S_HIP_CHECK(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
+        }
+        T2S_HIP_CHECK(hipEventRecord(s->ev_in, nullptr));
+        T2S_HIP_CHECK(hipStreamWaitEvent(s->own, s->ev_in, 0));
+        st = s->own;
+    }
     if (lanes == 2 && !s->side) {
         T2S_HIP_CHECK(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
         T2S_HIP_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
@@ -496,7 +540,6 @@ extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, cons
     const int r0[2] = {0, cut};
     const int nr[2] = {r0[1], c.batch - r0[1]};
     hipStream_t lst[2] = {st, s->side};
-    const bool graph_ok = c.use_graph && !trace0 && st != nullptr;
     if (graph_ok && (!s->exec[0] || s->lanes_cap != lanes || s->g_x != x || s->g_text != text || s->g_noise != noise)) {
         drop_graph(s);
         for (int l = 0; l < lanes; ++l) {
@@ -522,7 +565,7 @@ extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, cons
         T2S_HIP_CHECK(hipStreamWaitEvent(s->side, s->ev_fork, 0));
     }
     for (int l = 0; l < lanes; ++l) {
-        set_step_kernel<<<1, 64, 0, lst[l]>>>(s->step + 16 * l, 0, 0, c.row0 + (uint32_t)r0[l]);
+        set_step_kernel<<<1, 64, 0, lst[l]>>>(s->step + 16 * l, 0, c.row0 + (uint32_t)r0[l]);
         T2S_LAUNCH_CHECK();
     }
     for (int j = 0; j < c.steps; ++j) {
@@ -545,6 +588,10 @@ extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, cons
     }
     if (series) {
         if ((rc = t2s_vae_decode(s->vae, x, series, nullptr, c.batch, c.length, st)) != T2S_OK) return rc;
+    }
+    if (via_own) {      // whatever the caller queues on the default stream next sees the results
+        T2S_HIP_CHECK(hipEventRecord(s->ev_out, st));
+        T2S_HIP_CHECK(hipStreamWaitEvent(nullptr, s->ev_out, 0));
     }
     return T2S_OK;
 }

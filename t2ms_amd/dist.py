@@ -8,10 +8,11 @@ torch.distributed (backend "nccl" = RCCL over xGMI on GPUs, "gloo" on CPU for te
 barrier, the max-over-ranks wall time, the seed broadcast, that gradient all-reduce and the
 optional final gather of the (B, L) series.
 
-Two environment overrides exist for rehearsing the N>1 code on ONE GPU (tests/test_two_ranks_one_gpu.py):
-T2S_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one device; device tensors are then
-staged through host memory by the helpers below), and T2S_SHARE_GPU=1 maps LOCAL_RANK onto the
-visible devices modulo their count.
+Three environment overrides exist for rehearsing the N>1 code on ONE GPU: T2S_DIST_BACKEND=gloo replaces
+RCCL (which refuses two ranks on one device; device tensors are then staged through host memory by the
+helpers below) and T2S_SHARE_GPU=1 maps LOCAL_RANK onto the visible devices modulo their count
+(tests/test_two_ranks_one_gpu.py); T2S_FORCE_DIST=1 builds the process group at world size 1, so the same
+collectives run through RCCL itself on one rank (tests/test_rccl_one_rank.py).
 """
 from __future__ import annotations
 
@@ -41,13 +42,17 @@ def local_device_index() -> int:
 
 
 def init(backend: Optional[str] = None, device: Optional[torch.device] = None):
-    """Initialise torch.distributed when WORLD_SIZE > 1; returns the module or None."""
+    """Initialise torch.distributed when WORLD_SIZE > 1; returns the module or None.
+    T2S_FORCE_DIST=1 initialises the process group at WORLD_SIZE = 1 too: a one-rank RCCL communicator is legal, and
+    it is how the collectives of the N > 1 code (device-side all-reduce of the gradient bucket, all_gather, barrier,
+    object broadcast) run through RCCL itself on a one-GPU box (tests/test_rccl_one_rank.py)."""
     rank, _, world = env_world()
-    if world == 1:
+    if world == 1 and os.environ.get("T2S_FORCE_DIST", "0") in ("", "0"):
         return None
     import torch.distributed as dist
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
     if backend is None:
         backend = "nccl" if (device is not None and device.type == "cuda") else "gloo"
     backend = os.environ.get("T2S_DIST_BACKEND", backend)

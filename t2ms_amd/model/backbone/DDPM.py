@@ -44,7 +44,13 @@ class DDPM:
         self._sqrt_ab = tab["sqrt_ab"].to(device)
         self._sqrt_1mab = tab["sqrt_1mab"].to(device)
 
-    def _rows(self, x: torch.Tensor, t: torch.Tensor):
+    def _rows(self, x: torch.Tensor, t: torch.Tensor, **same_shape):
+        """Checks before raw device pointers reach the kernels: x (B,C,W) on the GPU, t (B,), and every tensor in
+        `same_shape` shaped like x (a (B,64,30) DiT prediction against a (B,64,6) MLP latent would otherwise be read
+        out of bounds).  The VALUES of t are checked on the device (a row outside [0,T) comes out NaN)."""
+        for name, v in same_shape.items():
+            if v is not None and tuple(v.shape) != tuple(x.shape):
+                raise L.T2SError(f"DDPM: {name} must have the latent's shape {tuple(x.shape)}, got {tuple(v.shape)}")
         if not x.is_cuda:
             raise L.T2SError("DDPM: tensors must live on a GPU; the HIP path has no CPU fallback")
         if x.dim() != 3 or (x.shape[1] * x.shape[2]) % 4 != 0:
@@ -64,7 +70,7 @@ class DDPM:
 
     def q_sample(self, x0: torch.Tensor, t: torch.Tensor, eps: Optional[torch.Tensor] = None):
         """DDPM.py:23-27: x_t = sqrt(ab_t) x0 + sqrt(1-ab_t) eps."""
-        ti = self._rows(x0, t)
+        ti = self._rows(x0, t, eps=eps)
         if eps is None:
             eps = torch.randn_like(x0)
         x0c, epsc = L.as_f32(x0), L.as_f32(eps)
@@ -73,13 +79,14 @@ class DDPM:
             L.check(L.lib().t2s_ddpm_q_sample_n(L.dev_ptr(x0c, "x0"), L.dev_ptr(epsc, "eps"),
                                                 L.dev_ptr(ti, "t", torch.int32), L.dev_ptr(self._sqrt_ab),
                                                 L.dev_ptr(self._sqrt_1mab), L.dev_ptr(out), x0.shape[0],
-                                                x0.shape[1] * x0.shape[2], L.stream_ptr(x0.device)), "t2s_ddpm_q_sample")
+                                                x0.shape[1] * x0.shape[2], int(self.total_steps),
+                                                L.stream_ptr(x0.device)), "t2s_ddpm_q_sample")
         return out, eps
 
     def p_sample(self, xt: torch.Tensor, n_xt: torch.Tensor, t: torch.Tensor, eps: Optional[torch.Tensor] = None):
         """DDPM.py:28-36.  ``eps`` (optional, extension) injects the Gaussian draw; by default it is
         drawn with torch.randn on xt's device like the reference (noise is added at t=0 too)."""
-        ti = self._rows(xt, t)
+        ti = self._rows(xt, t, n_xt=n_xt, eps=eps)
         if eps is None:
             eps = torch.randn(xt.shape, device=xt.device)
         x, e, z = L.as_f32(xt), L.as_f32(n_xt), L.as_f32(eps)
@@ -88,7 +95,8 @@ class DDPM:
             L.check(L.lib().t2s_ddpm_p_sample_n(L.dev_ptr(x, "xt"), L.dev_ptr(e, "n_xt"),
                                                 L.dev_ptr(ti, "t", torch.int32), L.dev_ptr(z, "eps"),
                                                 L.dev_ptr(self._coef), L.dev_ptr(out), xt.shape[0],
-                                                xt.shape[1] * xt.shape[2], L.stream_ptr(xt.device)), "t2s_ddpm_p_sample")
+                                                xt.shape[1] * xt.shape[2], int(self.total_steps),
+                                                L.stream_ptr(xt.device)), "t2s_ddpm_p_sample")
         return out
 
     def loss(self, n_gt: torch.Tensor, n_xt: torch.Tensor):

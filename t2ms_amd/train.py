@@ -236,6 +236,16 @@ class T2SAdamW(torch.optim.Optimizer):
                 torch.autograd.graph.increment_version(p)
         return loss
 
+    def load_state_dict(self, state_dict):
+        """torch.optim.Optimizer.load_state_dict leaves `step` on whatever device torch.load(map_location=...) put it
+        (it is moved only for fused / capturable optimizers): a resumed run would then bump 48 one-element GPU tensors
+        and read them back with .item() -- 48 host syncs -- on every step.  `step` is host bookkeeping here, as in a
+        fresh run (torch.tensor(0.0)): keep it on the CPU."""
+        super().load_state_dict(state_dict)
+        for st in self.state.values():
+            if torch.is_tensor(st.get("step")) and st["step"].device.type != "cpu":
+                st["step"] = st["step"].detach().to("cpu", torch.float32)
+
     def state_dict(self):
         sd = super().state_dict()
         for g in sd["param_groups"]:

@@ -782,3 +782,57 @@ def test_sampler_set_row0_keeps_graph_and_matches_fresh_sampler(dev, vae):
     lat_c, ser_c, _ = fresh.run(text[3:].contiguous())
     assert torch.equal(lat_b, lat_c) and torch.equal(ser_b, ser_c)
     assert torch.equal(torch.cat([lat_a, lat_b]), lat_big) and torch.equal(torch.cat([ser_a, ser_b]), ser_big)
+
+
+# ---------------------------------------------------------------- strong-scaling shards (256 series over 1/2/4/8 GPUs)
+def test_strong_scaling_shards_equal_the_full_batch_bitwise(dev, dit, vae):
+    """BASELINE's metric is B = 256 at 1/2/4/8 GPUs: a strong-scaling rank samples 128 / 64 / 32 of the 256 series.  Those
+    shard sizes take other launch shapes than the full batch (one sampler lane below 128 series, the persistent
+    attention kernel at exactly one head per CU at 32, a row chain that no longer fills every SIMD) -- the rows a rank
+    produces must still be bit for bit the rows of the one-GPU batch (Philox keyed by the global row; batch-invariant
+    kernels).  12 steps of the headline schedule shape (DDPM, cfg 9)."""
+    from t2ms_amd.sampler import Sampler
+    steps, B = 12, 256
+    text = synth.make_text_embeddings(2025, B)
+    full = Sampler(dit, vae.decoder, "ddpm", steps, 9.0, B, 96, dev, use_graph=True, seed=2025, row0=0)
+    lat, ser, _ = full.run(text)
+    assert bool(torch.isfinite(ser).all())
+    for world in (2, 4, 8):
+        n = B // world
+        s = Sampler(dit, vae.decoder, "ddpm", steps, 9.0, n, 96, dev, use_graph=True, seed=2025, row0=0)
+        for rank in sorted({0, world // 2, world - 1}):
+            s.set_row0(rank * n)
+            la, sa, _ = s.run(text[rank * n:(rank + 1) * n].contiguous())
+            assert torch.equal(la, lat[rank * n:(rank + 1) * n]), (world, rank)
+            assert torch.equal(sa, ser[rank * n:(rank + 1) * n]), (world, rank)
+
+
+def test_sampler_null_stream_with_graph_is_not_an_eager_fallback(dev, vae):
+    """Direct C-ABI caller: stream = NULL ("default stream", include/t2s.h) with use_graph = 1.
+    The default stream cannot be captured, so the sampler must capture / replay on a stream of its own, ordered after
+    and joined back to the default stream -- and report that it holds a graph; the result equals a run on an explicit
+    stream bit for bit."""
+    m, Sampler, xT, text, noises = _chain_setup(dev, vae)
+    lib = L.lib()
+    ref_s = Sampler(m, vae.decoder, "ddpm", 20, 7.0, 4, 96, dev, use_graph=True, lanes=1)
+    ref_lat, ref_ser, _ = ref_s.run(text, x_T=xT, noise=noises)
+    assert lib.t2s_sampler_graph_lanes(ref_s.ptr) == 1
+    for lanes in (1, 2):
+        s = Sampler(m, vae.decoder, "ddpm", 20, 7.0, 4, 96, dev, use_graph=True, lanes=lanes)
+        assert lib.t2s_sampler_graph_lanes(s.ptr) == 0          # nothing captured yet
+        x = xT.to(dev).clone()
+        td, nd = text.to(dev).contiguous(), noises.to(dev).contiguous()
+        series = torch.empty(4, 96, device=dev)
+        torch.cuda.synchronize(dev)
+        with torch.cuda.device(dev):
+            for _ in range(2):                                  # second call replays the kept graph
+                x.copy_(xT.to(dev))
+                torch.cuda.synchronize(dev)
+                L.check(lib.t2s_sampler_run(s.ptr, x.data_ptr(), td.data_ptr(), nd.data_ptr(), series.data_ptr(), None,
+                                            None), "t2s_sampler_run(NULL stream)")
+                # joined back to the default stream: waiting for THAT stream alone (torch's default stream is the
+                # NULL stream) must be enough to see the result
+                assert torch.cuda.default_stream(dev).cuda_stream == 0
+                torch.cuda.default_stream(dev).synchronize()
+                assert lib.t2s_sampler_graph_lanes(s.ptr) == lanes
+                assert torch.equal(x, ref_lat) and torch.equal(series, ref_ser)

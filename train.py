@@ -55,7 +55,7 @@ _SIDE = {}
 def _h2d(t, device):
     """CPU -> device on a side stream: a pageable copy makes the host wait for everything queued on ITS stream, which on the
     compute stream means a drained GPU at every step boundary; the side stream is empty, the compute stream waits for its event."""
-    if torch.device(device).type != "cuda" or os.environ.get("T2S_SYNC_H2D"):
+    if torch.device(device).type != "cuda" or os.environ.get("T2S_SYNC_H2D", "0") not in ("", "0"):
         return t.to(device)
     side = _SIDE.get(str(device))
     if side is None:
