@@ -103,4 +103,19 @@ __device__ __forceinline__ void glds16(const f32x4* gsrc_lane, f32x4* lds_wave_b
         (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// The same LDS-DMA hidden from hipcc's s_waitcnt bookkeeping (inline asm; M0 = wave-uniform LDS byte address, saved and
+// restored inside the statement: it is compiler-reserved).  Why: while a TRACKED LDS-DMA is pending hipcc treats lgkmcnt
+// as out of order and turns every counted wait of the ds_read -> MFMA pipelines into `s_waitcnt lgkmcnt(0)`, i.e. it
+// also waits for the fragment it has just requested (seen in the ISA of t2s_rows.h: lgkmcnt(1) in the one k-loop that
+// runs with no DMA in flight, lgkmcnt(0) everywhere else).  The caller owns the synchronisation: `s_waitcnt vmcnt(N)`
+// of its own, then a barrier, before any ds_read of the destination (__syncthreads() alone does NOT wait for it).
+__device__ __forceinline__ void glds16_asm(const f32x4* gsrc_lane, f32x4* lds_wave_base) {
+    unsigned keep;
+    const unsigned dst = (unsigned)(size_t)((__attribute__((address_space(3))) char*)lds_wave_base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc_lane), "s"(dst)
+                 : "memory");
+}
+
 }  // namespace t2s

@@ -37,11 +37,28 @@ constexpr int ROWS_CHUNK_F4 = 1024;                       // float4 per chunk (1
 // its use by the compiler and waits with vmcnt(0) -- a full memory round trip, draining the
 // weight DMA and all stores, once per 64 MFMAs (seen in the ISA; cost ~15 %).
 constexpr int ROWS_CB_FLOATS = 896;
-constexpr int ROWS_CM_FLOATS = 1024;                      // per wave
+constexpr int ROWS_CM_FLOATS = 1024;                      // per wave (bf16x3 kernel, t2s_rows_x3.h)
 #ifndef T2S_ROWS_NW
 #define T2S_ROWS_NW 4
 #endif
-constexpr int ROWS_LDS_BYTES = 2 * ROWS_CHUNK_F4 * 16 + (ROWS_CB_FLOATS + T2S_ROWS_NW * ROWS_CM_FLOATS) * 4;
+// f32 kernel: a THREE-slot ring, the DMA ROWS_DIST = 2 chunks ahead behind COUNTED vmcnt waits, and 768 adaLN floats
+// per wave (the MLP phase never reads shift_msa / scale_msa of its block: those two slots hold the qkv block's shift /
+// scale) -- 49,152 + 3,584 + 12,288 = 65,024 B.  With the two-slot ring every chunk ended in `vmcnt(0)`: a weight chunk
+// had one chunk time (1.7 us) to arrive, which a lone wave per SIMD (the 32-series shard of an 8-GPU strong-scaling
+// run: 960 tiles for 1024 SIMDs) cannot hide.  Same-box A/B (tools/ab_sample.sh, series/s at B = 256 / 128, two sampler
+// lanes): two slots 61.6 / 61.0, three slots 62.2 / 61.9, FOUR slots (81,408 B) 61.4 / 58.2 -- the larger footprint
+// keeps the other lane's kernels off the CU, so the ring stays as small as the distance allows.
+#ifndef T2S_ROWS_SLOTS
+#define T2S_ROWS_SLOTS 3
+#endif
+constexpr int ROWS_SLOTS = T2S_ROWS_SLOTS;
+#ifndef T2S_ROWS_DIST
+#define T2S_ROWS_DIST 2
+#endif
+constexpr int ROWS_DIST = T2S_ROWS_DIST;                  // chunks the DMA runs ahead (< ROWS_SLOTS)
+static_assert(ROWS_DIST >= 1 && ROWS_DIST < ROWS_SLOTS, "the DMA may run at most ROWS_SLOTS - 1 chunks ahead");
+constexpr int ROWS_CMF = 768;                             // per-wave adaLN floats of the f32 kernel
+constexpr int ROWS_LDS_BYTES = ROWS_SLOTS * ROWS_CHUNK_F4 * 16 + (ROWS_CB_FLOATS + T2S_ROWS_NW * ROWS_CMF) * 4;
 
 struct RowArgs {
     float* x;          // (M,128) residual stream, fragment-major, in place
@@ -100,6 +117,11 @@ __device__ __forceinline__ void ln_modulate(const f32x16 (&x)[4], f32x16 (&y)[4]
         }
     ss += xhalf(ss);
     const float rstd = rsqrtf(ss * (1.0f / 128.0f) + eps);
+    // The second pass recomputes x - mean from x: hipcc otherwise keeps the 64 differences of the variance pass alive
+    // next to x and y (192 registers) and spills some of them -- and every scratch reload waits vmcnt(0), draining
+    // the weight DMA and the parking stores.  The empty asm makes `mean` opaque so the subtraction is not CSE'd.
+    float mean2 = mean;
+    asm volatile("" : "+v"(mean2));
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -108,8 +130,43 @@ __device__ __forceinline__ void ln_modulate(const f32x16 (&x)[4], f32x16 (&y)[4]
             const f32x4 sh = ldc4(shift, nt, g, half);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                y[nt][4 * g + e] = (x[nt][4 * g + e] - mean) * rstd * (1.0f + sc[e]) + sh[e];
+                y[nt][4 * g + e] = (x[nt][4 * g + e] - mean2) * rstd * (1.0f + sc[e]) + sh[e];
         }
+}
+
+
+// One 32-output x K=128 weight tile (16 fragments at wb[G * 64]) against a B operand in registers, software-pipelined:
+// fragment G+1 is fetched from LDS BEFORE the four MFMAs of fragment G are issued.  hipcc otherwise emits
+// `ds_read_b128 ; s_waitcnt lgkmcnt(0) ; 4 x v_mfma` with ONE fragment register: the read is issued when the previous
+// group's last MFMA issues (~192 cycles into a 256-cycle group) and returns ~120 cycles later, i.e. the matrix pipe idles
+// ~20 % of every group unless a second wave on the SIMD covers it -- which a 32-series shard (960 tiles for 1024 SIMDs)
+// does not have.  sched_barrier pins the order; the waitcnt pass then emits the counted lgkmcnt(1).
+#ifndef T2S_ROWS_PIPE
+#define T2S_ROWS_PIPE 1
+#endif
+#define T2S_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+template <bool SWAP, typename BOP>
+__device__ __forceinline__ void ktile_mfma(const f32x4* __restrict__ wb, BOP&& bop, f32x16& acc) {
+#if T2S_ROWS_PIPE
+    f32x4 w = wb[0];
+#pragma unroll
+    for (int G = 0; G < 16; ++G) {
+        f32x4 wn = w;
+        if (G + 1 < 16) wn = wb[(G + 1) * 64];
+        T2S_SCHED_FENCE();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = SWAP ? mfma32(bop(G, e), w[e], acc) : mfma32(w[e], bop(G, e), acc);
+        T2S_SCHED_FENCE();
+        w = wn;
+    }
+#else
+#pragma unroll
+    for (int G = 0; G < 16; ++G) {
+        const f32x4 w = wb[G * 64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = SWAP ? mfma32(bop(G, e), w[e], acc) : mfma32(w[e], bop(G, e), acc);
+    }
+#endif
 }
 
 
@@ -120,9 +177,18 @@ __device__ __forceinline__ void ln_modulate(const f32x16 (&x)[4], f32x16 (&y)[4]
 #define T2S_ROWS_NW 4
 #endif
 constexpr int ROWS_NW = T2S_ROWS_NW;
+// chunk barrier of the row kernels: the weight DMA is issued by inline asm (glds16_asm: invisible to hipcc's waitcnt
+// pass, so that the ds_read -> MFMA pipelines keep their counted lgkmcnt waits), hence the explicit vmcnt(0) in front of
+// __syncthreads(), which by itself only covers what the compiler tracks
+#define ROWS_SYNC()                                          \
+    do {                                                     \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     \
+        __syncthreads();                                     \
+    } while (0)
+
 template <bool DO_MLP, bool DO_QKV>
 __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(const RowArgs a) {
-    extern __shared__ __attribute__((aligned(16))) f32x4 wring[];  // [2][1024]
+    extern __shared__ __attribute__((aligned(16))) f32x4 wring[];  // [ROWS_SLOTS][1024]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: scalar addressing
     const int half = lane >> 5;
@@ -148,28 +214,51 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
     // each wave DMAs fragments {wave, wave+4, wave+8, wave+12} of the chunk
     auto fill = [&](int ci) {
         const f32x4* src = chunk_src(ci) + lane;
-        f32x4* dst = wring + (ci & 1) * ROWS_CHUNK_F4;
+        f32x4* dst = wring + (ci % ROWS_SLOTS) * ROWS_CHUNK_F4;
 #pragma unroll
-        for (int p = 0; p < 16 / ROWS_NW; ++p) glds16(src + (wave + ROWS_NW * p) * 64, dst + (wave + ROWS_NW * p) * 64);
+        for (int p = 0; p < 16 / ROWS_NW; ++p) glds16_asm(src + (wave + ROWS_NW * p) * 64, dst + (wave + ROWS_NW * p) * 64);
+    };
+    // start of chunk ci: keep the DMA ROWS_DIST chunks ahead.  Slot (ci + DIST) % SLOTS held chunk ci + DIST - SLOTS,
+    // whose reads every wave finished before the barrier that ended chunk ci - 1 (DIST < SLOTS).
+    auto prefetch = [&](int ci) {
+        if (ci + ROWS_DIST < N_CHUNKS) fill(ci + ROWS_DIST);
+    };
+    // end of chunk ci: chunk ci + 1 must have landed for every wave -> counted wait (the DIST - 1 younger chunks, 16 /
+    // NW pieces each, stay in flight; any younger stores only make the wait stricter), then the workgroup barrier.
+    // `own_stores` = VM ops this wave issued after the youngest DMA that may stay in flight too (the qkv epilogue's).
+    auto chunk_done = [&](int ci, int own_stores) {
+        constexpr int PER = 16 / ROWS_NW;
+        if (ci + ROWS_DIST < N_CHUNKS) {
+            if (own_stores > 0)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ROWS_DIST - 1) * PER + ROWS_DIST * 4) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ROWS_DIST - 1) * PER) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
     };
 
-    fill(0);
+#pragma unroll
+    for (int c0 = 0; c0 < ROWS_DIST; ++c0) fill(c0);
 
     // ---- stage the per-feature constants in LDS (visible after the first barrier) ----
-    float* cb = reinterpret_cast<float*>(wring + 2 * ROWS_CHUNK_F4);
-    float* cm = cb + ROWS_CB_FLOATS + wave * ROWS_CM_FLOATS;
+    float* cb = reinterpret_cast<float*>(wring + ROWS_SLOTS * ROWS_CHUNK_F4);
+    // per wave: [0,256) shift_msa | scale_msa of the QKV block, [256,768) gate_msa | shift_mlp | scale_mlp | gate_mlp
+    // of the MLP block (whose own shift_msa / scale_msa were consumed by the previous kernel)
+    float* cm = cb + ROWS_CB_FLOATS + wave * ROWS_CMF;
     if constexpr (DO_MLP) {
         for (int i = threadIdx.x; i < 512; i += 64 * ROWS_NW)
             cb[i] = i < 128 ? a.bp[i] : (i < 384 ? a.b1[i - 128] : a.b2[i - 384]);
         const float* src = modrow + a.blk * MODW;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 1; i < 3; ++i)
             *reinterpret_cast<f32x4*>(cm + (i * 64 + lane) * 4) = *reinterpret_cast<const f32x4*>(src + (i * 64 + lane) * 4);
     }
     if constexpr (DO_QKV) {
         for (int i = threadIdx.x; i < 384; i += 64 * ROWS_NW) cb[512 + i] = a.bq[i];
         const float* src = modrow + a.qkv_blk * MODW;   // shift_msa | scale_msa
-        *reinterpret_cast<f32x4*>(cm + 768 + lane * 4) = *reinterpret_cast<const f32x4*>(src + lane * 4);
+        *reinterpret_cast<f32x4*>(cm + lane * 4) = *reinterpret_cast<const f32x4*>(src + lane * 4);
     }
     const float* c_bp = cb;
     const float* c_b1 = cb + 128;
@@ -202,20 +291,15 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bop[G >> 2][4 * (G & 3) + e] = t[e];
             }
-            __syncthreads();  // chunk 0 landed (vmcnt(0) + barrier)
+            ROWS_SYNC();  // chunk 0 landed (vmcnt(0) + barrier)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                fill(ci + 1);
-                const f32x4* wb = wring + (ci & 1) * ROWS_CHUNK_F4 + lane;
+                prefetch(ci);
+                const f32x4* wb = wring + (ci % ROWS_SLOTS) * ROWS_CHUNK_F4 + lane;
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-                for (int G = 0; G < 16; ++G) {
-                    const f32x4 w = wb[G * 64];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = mfma32(w[e], bop[G >> 2][4 * (G & 3) + e], acc);
-                }
+                ktile_mfma<false>(wb, [&](int G, int e) { return bop[G >> 2][4 * (G & 3) + e]; }, acc);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 bias = ldc4(c_bp, nt, g, half);
@@ -223,7 +307,7 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[nt][4 * g + e] += gate[e] * (acc[4 * g + e] + bias[e]);
                 }
-                __syncthreads();
+                chunk_done(ci, 0);
                 ++ci;
             }
         }
@@ -250,18 +334,13 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 #pragma unroll 1
             for (int c = 0; c < 8; ++c) {  // 32 hidden units per chunk; ci = 4 + 2c (even) here
-                fill(ci + 1);
+                prefetch(ci);
                 f32x16 hT;
                 {
-                    const f32x4* wb = wring + lane;  // ci even -> ring slot 0
+                    const f32x4* wb = wring + (ci % ROWS_SLOTS) * ROWS_CHUNK_F4 + lane;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) hT[r] = 0.f;
-#pragma unroll
-                    for (int G = 0; G < 16; ++G) {
-                        const f32x4 w = wb[G * 64];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) hT = mfma32(w[e], xm[G >> 2][4 * (G & 3) + e], hT);
-                    }
+                    ktile_mfma<false>(wb, [&](int G, int e) { return xm[G >> 2][4 * (G & 3) + e]; }, hT);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 bias = *reinterpret_cast<const f32x4*>(c_b1 + 32 * c + 8 * g + 4 * half);
@@ -269,11 +348,25 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
                         for (int e = 0; e < 4; ++e) hT[4 * g + e] = gelu_tanh_f(hT[4 * g + e] + bias[e]);
                     }
                 }
-                __syncthreads();
+                chunk_done(ci, 0);
                 ++ci;
-                if (ci + 1 < N_CHUNKS) fill(ci + 1);
+                prefetch(ci);
                 {   // fc2 partial over k-groups 4c..4c+3 of K=256; fragments ordered [nt][g]
-                    const f32x4* wb = wring + ROWS_CHUNK_F4 + lane;  // ci odd -> ring slot 1
+                    const f32x4* wb = wring + (ci % ROWS_SLOTS) * ROWS_CHUNK_F4 + lane;
+#if T2S_ROWS_PIPE
+                    f32x4 w = wb[0];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {      // i = 4 g + nt: same order of additions as before
+                        const int g = i >> 2, nt = i & 3;
+                        f32x4 wn = w;
+                        if (i + 1 < 16) wn = wb[(((i + 1) & 3) * 4 + ((i + 1) >> 2)) * 64];
+                        T2S_SCHED_FENCE();
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[nt] = mfma32(w[e], hT[4 * g + e], acc[nt]);
+                        T2S_SCHED_FENCE();
+                        w = wn;
+                    }
+#else
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -283,28 +376,43 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
                             for (int e = 0; e < 4; ++e) acc[nt] = mfma32(w[e], hT[4 * g + e], acc[nt]);
                         }
                     }
+#endif
                 }
-                __syncthreads();
+                chunk_done(ci, 0);
                 ++ci;
             }
+            // the parked residual comes back in ONE batch of 16 loads; with the (wave-uniform) store condition inside
+            // the element loop hipcc branched around every store and waited vmcnt(0) after every load: 16 dependent
+            // L2 round trips per tile, which also drained the weight DMA each time
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 xo = xw[(nt * 4 + g) * 64];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[nt][4 * g + e] = xo[e];
+                }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 bias = ldc4(c_b2, nt, g, half);
                     const f32x4 gate = ldc4(mb + 5 * D, nt, g, half);
-                    const f32x4 xo = xw[(nt * 4 + g) * 64];   // the parked residual
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[nt][4 * g + e] += gate[e] * (acc[nt][4 * g + e] + bias[e]);
+                }
+            if (active && (DO_QKV || a.out0 == nullptr || a.keep_x)) {   // final residual stream of this block
+#pragma unroll
+                for (int G = 0; G < 16; ++G) {
                     f32x4 t;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        t[e] = xo[e] + gate[e] * (acc[nt][4 * g + e] + bias[e]);
-                        x[nt][4 * g + e] = t[e];
-                    }
-                    if (active && (DO_QKV || a.out0 == nullptr || a.keep_x)) xw[(nt * 4 + g) * 64] = t;   // final residual stream of this block
+                    for (int e = 0; e < 4; ++e) t[e] = x[G >> 2][4 * (G & 3) + e];
+                    xw[G * 64] = t;
                 }
+            }
         }
     } else {
-        __syncthreads();  // chunk 0 landed
+        ROWS_SYNC();  // chunk 0 landed
     }
 
     // ---- fused final layer of the LAST block (transformer.py:182-191): affine LayerNorm (eps 1e-5),
@@ -349,28 +457,27 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
                         fa[p] += (y.x * w.x + y.y * w.y) + (y.z * w.z + y.w * w.w);
                     }
                 }
-#pragma unroll
-            for (int p = 0; p < 4; ++p) fa[p] += xhalf(fa[p]);
+            const float f0 = fa[0] + xhalf(fa[0]), f1 = fa[1] + xhalf(fa[1]);
+            const float f2 = fa[2] + xhalf(fa[2]), f3 = fa[3] + xhalf(fa[3]);
             if (active) {   // lane half 0 writes patch outputs p = 0,1; half 1 writes p = 2,3
                 const int n = (tile - seq * (NTOK / 32)) * 32 + (lane & 31);
                 const int hh = n >> 5, ww = n & 31;
                 float* dst = (seq < a.split) ? a.out0 + (size_t)seq * LAT : a.out1 + (size_t)(seq - a.split) * LAT;
-#pragma unroll
-                for (int q2 = 0; q2 < 2; ++q2) {
-                    const int p = 2 * half + q2;
-                    dst[(2 * ww + (p & 1)) * LATW + 2 * hh + (p >> 1)] = (half ? fa[2 + q2] : fa[q2]) + a.f_ob[p];
-                }
+                // p = 2 half + q2 -> element (2 ww + q2, 2 hh + half); selects, not an indexed array (that went to scratch)
+                const float ob0 = half ? a.f_ob[2] : a.f_ob[0], ob1 = half ? a.f_ob[3] : a.f_ob[1];
+                dst[(2 * ww + 0) * LATW + 2 * hh + half] = (half ? f2 : f0) + ob0;
+                dst[(2 * ww + 1) * LATW + 2 * hh + half] = (half ? f3 : f1) + ob1;
             }
         }
     }
     if constexpr (DO_QKV) {
         f32x16 xm[4];
-        ln_modulate(x, xm, cm + 768, cm + 768 + D, half, 1e-6f);
+        ln_modulate(x, xm, cm, cm + D, half, 1e-6f);
         const int tile_in_seq = tile - seq * (NTOK / 32);
 #pragma unroll 1
         for (int t = 0; t < 12; ++t) {  // output tile t = which*4 + head
-            if (ci + 1 < N_CHUNKS) fill(ci + 1);
-            const f32x4* wb = wring + (ci & 1) * ROWS_CHUNK_F4 + lane;
+            prefetch(ci);
+            const f32x4* wb = wring + (ci % ROWS_SLOTS) * ROWS_CHUNK_F4 + lane;
             const int which = t >> 2, head = t & 3;
             float* base = which == 0 ? a.q : (which == 1 ? a.k : a.v);
             f32x4* dst = reinterpret_cast<f32x4*>(base) +
@@ -384,12 +491,7 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     bias[g] = *reinterpret_cast<const f32x4*>(c_bq + 32 * t + 8 * g + 4 * half);
-#pragma unroll
-                for (int G = 0; G < 16; ++G) {
-                    const f32x4 w = wb[G * 64];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = mfma32(w[e], xm[G >> 2][4 * (G & 3) + e], acc);
-                }
+                ktile_mfma<false>(wb, [&](int G, int e) { return xm[G >> 2][4 * (G & 3) + e]; }, acc);
                 if (active) {
                     {
 #pragma unroll
@@ -405,12 +507,7 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
                 // v tile with the MFMA operands swapped: lane = feature d, registers = tokens
                 // {8g+4half+e}: exactly the V^T fragment the attention kernel consumes
                 const float bias = c_bq[32 * t + (lane & 31)];
-#pragma unroll
-                for (int G = 0; G < 16; ++G) {
-                    const f32x4 w = wb[G * 64];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = mfma32(xm[G >> 2][4 * (G & 3) + e], w[e], acc);
-                }
+                ktile_mfma<true>(wb, [&](int G, int e) { return xm[G >> 2][4 * (G & 3) + e]; }, acc);
                 if (active) {
                     {
 #pragma unroll
@@ -423,14 +520,10 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
                     }
                 }
             }
-            // Counted wait + raw barrier: only the chunk's 4 DMA pieces must have landed; the 4
-            // q/k/v stores issued after them (the youngest VM ops) stay in flight across the
-            // barrier.  (__syncthreads() would drain them: vmcnt(0).)  Tail waves store nothing.
-            if (active)
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            // Counted wait + raw barrier: the next chunk's DMA pieces must have landed; the younger chunks and the
+            // q/k/v stores of the last ROWS_DIST tiles (4 each) stay in flight across the barrier.
+            // (__syncthreads() would drain them: vmcnt(0).)  Tail waves store nothing.
+            chunk_done(ci, active ? 4 : 0);
             ++ci;
         }
     }

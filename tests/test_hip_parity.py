@@ -672,7 +672,7 @@ def test_chain_1000_steps_reference(dev, vae, math, lanes):
     m = m.to(dev).eval().set_math(math)
     s = Sampler(m, vae.decoder, "ddpm", 1000, 9.0, 2, 96, dev, use_graph=True, lanes=lanes)
     lat, series, _ = s.run(text, x_T=xT, noise=noises)
-    check_chain1000(lat.cpu().numpy(), series.cpu().numpy(), {})
+    check_chain1000(lat.cpu().numpy(), series.cpu().numpy(), {}, label=f"fused sampler {math} lanes={lanes}")
 
 
 def test_chain_1000_steps_stepwise_taps(dev, vae):
@@ -697,7 +697,7 @@ def test_chain_1000_steps_stepwise_taps(dev, vae):
             if j in CHAIN_TAPS:
                 taps[j] = x.cpu().numpy()
         series, _ = vae.decoder(x, length=96)
-    check_chain1000(x.cpu().numpy(), series.cpu().numpy(), taps)
+    check_chain1000(x.cpu().numpy(), series.cpu().numpy(), taps, label="class API f32")
 
 
 # ---------------------------------------------------------------- evaluation metrics against the reference's own functions
