@@ -157,8 +157,8 @@ __device__ __forceinline__ void attn_packed_body(f32x4* ring, const f32x4* qg, c
     auto issue_clamped = [&](int jb) {
         const int src = jb < NKB ? jb : NKB - 1;
         f32x4* slot = ring + (jb & (ATT_SLOTS - 1)) * ATT_SLOT_F4;
-        glds16(kg + (src * 4 + wave) * 64 + lane, slot + wave * 64);
-        glds16(vg + (src * 4 + wave) * 64 + lane, slot + 256 + wave * 64);
+        glds16_asm(kg + (src * 4 + wave) * 64 + lane, slot + wave * 64);
+        glds16_asm(vg + (src * 4 + wave) * 64 + lane, slot + 256 + wave * 64);
     };
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -264,13 +264,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_packed_kernel(const float* __
     {
         f32x4* slot0 = ring;
         f32x4* slot1 = ring + ATT_SLOT_F4;
-        glds16(kg + (0 * 4 + wave) * 64 + lane, slot0 + wave * 64);
-        glds16(vg + (0 * 4 + wave) * 64 + lane, slot0 + 256 + wave * 64);
-        glds16(kg + (1 * 4 + wave) * 64 + lane, slot1 + wave * 64);
-        glds16(vg + (1 * 4 + wave) * 64 + lane, slot1 + 256 + wave * 64);
+        glds16_asm(kg + (0 * 4 + wave) * 64 + lane, slot0 + wave * 64);
+        glds16_asm(vg + (0 * 4 + wave) * 64 + lane, slot0 + 256 + wave * 64);
+        glds16_asm(kg + (1 * 4 + wave) * 64 + lane, slot1 + wave * 64);
+        glds16_asm(vg + (1 * 4 + wave) * 64 + lane, slot1 + 256 + wave * 64);
         f32x4* slot2 = ring + 2 * ATT_SLOT_F4;
-        glds16(kg + (2 * 4 + wave) * 64 + lane, slot2 + wave * 64);
-        glds16(vg + (2 * 4 + wave) * 64 + lane, slot2 + 256 + wave * 64);
+        glds16_asm(kg + (2 * 4 + wave) * 64 + lane, slot2 + wave * 64);
+        glds16_asm(vg + (2 * 4 + wave) * 64 + lane, slot2 + 256 + wave * 64);
     }
     const int t0 = part * 8 + wave * 2;       // query tiles t0, t0+1 (tile 15 does not exist)
     if (t0 + 1 < NKB)
@@ -303,7 +303,7 @@ __device__ __forceinline__ void attn_persistent_body(f32x4* ring, const f32x4* q
     auto issue_block = [&](int bh, int jb, int gslot) {
         if (jb >= NKB) { jb -= NKB; bh += stride; }
         if (bh >= BH) { bh -= stride; jb = NKB - 1; }   // past the end: harmless re-fetch
-        glds16(my_src + (size_t)bh * NKB * 256 + jb * 4 * 64,
+        glds16_asm(my_src + (size_t)bh * NKB * 256 + jb * 4 * 64,
                ring + (gslot & (ATT_SLOTS - 1)) * ATT_SLOT_F4 + my_dst);
     };
     int bh = blockIdx.x;
