@@ -6,10 +6,12 @@
 //   t2s_gemm.h  : the adaLN modulation GEMM (SiLU prologue)
 // Between kernels the residual stream, the attention output and q/k/v stay in the
 // fragment-major layout (t2s_common.h: frag_index).
+#include <stdlib.h>
 #include <vector>
 
 #include "t2s_gemm.h"
 #include "t2s_rows_x3.h"
+#include "t2s_rows16.h"
 
 namespace t2s {
 
@@ -31,13 +33,18 @@ void train_free(t2s_dit* h);
 // ------------------------------------------------------------------ small kernels
 // W (N,K) row-major -> MFMA-fragment order.  mode 0: packed_index (tile-major: [nt][G][lane][e]);
 // mode 1 (fc2, K=256): chunk order [c = G/4][nt][g = G%4][lane][e] so the 16 fragments one fc1
-// chunk feeds into fc2 are one contiguous 16 KiB (t2s_rows.h).
+// chunk feeds into fc2 are one contiguous 16 KiB (t2s_rows.h); modes 2 / 3: the same two orders for the
+// 16-token kernel's 16x16x4 fragments (t2s_rows16.h: packed16_index, packed16_fc2_index).
 __device__ __forceinline__ void pack_weight_elem(const float* __restrict__ W, float* __restrict__ P, int N, int K,
                                                  int n_offset, int mode, int idx) {
     if (idx >= N * K) return;
     const int n = idx / K + n_offset, k = idx - (idx / K) * K;
     if (mode == 0) {
         P[packed_index(n, k, K)] = W[idx];
+    } else if (mode == 2) {
+        P[packed16_index(n, k)] = W[idx];
+    } else if (mode == 3) {
+        P[packed16_fc2_index(n, k)] = W[idx];
     } else {
         const int nt = n >> 5, j = n & 31, G = k >> 3, h = (k >> 2) & 1, e = k & 3;
         const int c = G >> 2, g = G & 3;
@@ -52,7 +59,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, float* __restric
 
 // Every parameter refresh of a handle in TWO launches instead of 50 (30 device-to-device copies + 20 packs, 3-5 us
 // each: 0.25 ms of a 14.5 ms bf16 training step): the job tables travel as kernel arguments, blockIdx.y = job.
-constexpr int MULTI_JOBS = 32;
+constexpr int MULTI_JOBS = 48;
 struct PackJob {
     const float* W;
     float* P;
@@ -259,8 +266,12 @@ int upload_weights(t2s_dit* h, const t2s_dit_weights* w, hipStream_t st) {
         pk(b.fc1_w, h->fc1_p[i], 2 * D, D, 0, 0);
         pk(b.fc2_w, h->fc2_c[i], D, 2 * D, 0, 1);
         pk(b.ada_w, h->ada_p, MODW, D, i * MODW, 0);
+        pk(b.qkv_w, h->qkv_p16[i], 3 * D, D, 0, 2);
+        pk(b.proj_w, h->proj_p16[i], D, D, 0, 2);
+        pk(b.fc1_w, h->fc1_p16[i], 2 * D, D, 0, 2);
+        pk(b.fc2_w, h->fc2_c16[i], D, 2 * D, 0, 3);
     }
-    static_assert(10 + 5 * NBLK <= MULTI_JOBS && 5 * NBLK <= MULTI_JOBS, "job tables too small");
+    static_assert(10 + 5 * NBLK <= MULTI_JOBS && 9 * NBLK <= MULTI_JOBS, "job tables too small");
     copy_multi_kernel<<<dim3(16, nc), 256, 0, st>>>(ct);
     T2S_LAUNCH_CHECK();
     pack_weight_multi_kernel<<<dim3((max_pack + 255) / 256, np), 256, 0, st>>>(pt);
@@ -346,9 +357,23 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
         a.q = w_q; a.k3 = w_k3; a.v3 = w_v3;
         return a;
     };
+    // Small launches run the row chain on 16-token tiles (t2s_rows16.h; bit-identical results): up to 100 sequences, i.e.
+    // where the 32-token kernel has fewer than ~1.5 waves per SIMD.  Same-box series/s, 16- vs 32-token tiles: 8 series
+    // (16 sequences) +27 %, 16 +25 %, 24 +1 %, 32 (the 8-GPU strong-scaling shard) +1.2 %, 40 +7.5 %, 48 +7.7 %, 64 -2 %
+    // (gpurun_out -> profiles/r03_rows16_ab.txt).  The last block's kernel (fused final layer) stays on 32-token tiles.
+    // T2S_ROWS16_MAX_SEQS moves the switch point (A/B runs; 0 = never).
+    static const int rows16_max = getenv("T2S_ROWS16_MAX_SEQS") ? atoi(getenv("T2S_ROWS16_MAX_SEQS")) : 100;
+    const bool use16 = !x3 && S <= rows16_max;
+    auto rows_args16 = [&](int blk, int qkv_blk) {
+        RowArgs a = rows_args(blk, qkv_blk);
+        if (blk >= 0) { a.Wp = h->proj_p16[blk]; a.W1 = h->fc1_p16[blk]; a.W2c = h->fc2_c16[blk]; }
+        if (qkv_blk >= 0) a.Wq = h->qkv_p16[qkv_blk];
+        return a;
+    };
     {
         TimeScope ts(h, TC_ROWS, st);
-        rc = x3 ? launch_dit_rows_x3<false, true>(rows_args_x3(-1, 0), st) : launch_dit_rows<false, true>(rows_args(-1, 0), st);
+        rc = x3 ? launch_dit_rows_x3<false, true>(rows_args_x3(-1, 0), st)
+                : (use16 ? launch_dit_rows16<false, true>(rows_args16(-1, 0), st) : launch_dit_rows<false, true>(rows_args(-1, 0), st));
         if (rc != T2S_OK) return rc;
     }
     for (int i = 0; i < NBLK; ++i) {
@@ -360,7 +385,8 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
         }
         TimeScope ts(h, TC_ROWS, st);
         if (i + 1 < NBLK)
-            rc = x3 ? launch_dit_rows_x3<true, true>(rows_args_x3(i, i + 1), st) : launch_dit_rows<true, true>(rows_args(i, i + 1), st);
+            rc = x3 ? launch_dit_rows_x3<true, true>(rows_args_x3(i, i + 1), st)
+                    : (use16 ? launch_dit_rows16<true, true>(rows_args16(i, i + 1), st) : launch_dit_rows<true, true>(rows_args(i, i + 1), st));
         else
             rc = x3 ? launch_dit_rows_x3<true, false>(rows_args_x3(i, -1), st) : launch_dit_rows<true, false>(rows_args(i, -1), st);
         if (rc != T2S_OK) return rc;
@@ -398,11 +424,14 @@ int t2s_dit_create(const t2s_dit_weights* w, int max_seqs, t2s_dit** out) {
                  o_freqs = p.take(64), o_ada_b = p.take(MODROW), o_ada_p = p.take((size_t)MODROW * D);
     size_t o_qkv_b[NBLK], o_proj_b[NBLK], o_fc1_b[NBLK], o_fc2_b[NBLK];
     size_t o_qkv_p[NBLK], o_proj_p[NBLK], o_fc1_p[NBLK], o_fc2_c[NBLK];
+    size_t o_qkv_p16[NBLK], o_proj_p16[NBLK], o_fc1_p16[NBLK], o_fc2_c16[NBLK];
     for (int i = 0; i < NBLK; ++i) {
         o_qkv_b[i] = p.take(3 * D); o_proj_b[i] = p.take(D); o_fc1_b[i] = p.take(2 * D);
         o_fc2_b[i] = p.take(D);
         o_qkv_p[i] = p.take(3 * D * D); o_proj_p[i] = p.take(D * D);
         o_fc1_p[i] = p.take(2 * D * D); o_fc2_c[i] = p.take(2 * D * D);
+        o_qkv_p16[i] = p.take(3 * D * D); o_proj_p16[i] = p.take(D * D);
+        o_fc1_p16[i] = p.take(2 * D * D); o_fc2_c16[i] = p.take(2 * D * D);
     }
     hipError_t e = hipMalloc(&h->arena, p.off * sizeof(float));
     if (e != hipSuccess) {
@@ -422,6 +451,10 @@ int t2s_dit_create(const t2s_dit_weights* w, int max_seqs, t2s_dit** out) {
         h->proj_p[i] = reinterpret_cast<f32x4*>(A + o_proj_p[i]);
         h->fc1_p[i] = reinterpret_cast<f32x4*>(A + o_fc1_p[i]);
         h->fc2_c[i] = reinterpret_cast<f32x4*>(A + o_fc2_c[i]);
+        h->qkv_p16[i] = reinterpret_cast<f32x4*>(A + o_qkv_p16[i]);
+        h->proj_p16[i] = reinterpret_cast<f32x4*>(A + o_proj_p16[i]);
+        h->fc1_p16[i] = reinterpret_cast<f32x4*>(A + o_fc1_p16[i]);
+        h->fc2_c16[i] = reinterpret_cast<f32x4*>(A + o_fc2_c16[i]);
     }
     const size_t S = (size_t)max_seqs, tokD = S * NTOK * D;
     float** bufs[] = {&h->h, &h->q, &h->k, &h->v, &h->ao, &h->mod, &h->h0};
@@ -437,6 +470,7 @@ int t2s_dit_create(const t2s_dit_weights* w, int max_seqs, t2s_dit** out) {
     }
     int rc = attn_init();
     if (rc == T2S_OK) rc = dit_rows_init();
+    if (rc == T2S_OK) rc = dit_rows16_init();
     if (rc == T2S_OK) rc = upload_weights(h, w, nullptr);
     if (rc == T2S_OK && hipStreamSynchronize(nullptr) != hipSuccess) {
         set_error("t2s_dit_create: weight upload failed");

@@ -13,6 +13,8 @@ struct t2s_dit {
     float *conv_w, *conv_b, *patch_w, *patch_b, *pos, *ln_w, *ln_b, *out_w, *out_b, *freqs;
     float *qkv_b[t2s::NBLK], *proj_b[t2s::NBLK], *fc1_b[t2s::NBLK], *fc2_b[t2s::NBLK], *ada_b;
     t2s::f32x4 *qkv_p[t2s::NBLK], *proj_p[t2s::NBLK], *fc1_p[t2s::NBLK], *fc2_c[t2s::NBLK], *ada_p;
+    // the same row-chain weights in the 16-token kernel's fragment order (t2s_rows16.h; small launches)
+    t2s::f32x4 *qkv_p16[t2s::NBLK], *proj_p16[t2s::NBLK], *fc1_p16[t2s::NBLK], *fc2_c16[t2s::NBLK];
     // workspace (device), activations fragment-major
     float *h = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *ao = nullptr;
     float* h0 = nullptr;         // patchified tokens of the B distinct sequences of a CFG pass (both branches share them)

@@ -96,27 +96,52 @@ __device__ __forceinline__ f32x4 ldc4(const float* __restrict__ vec, int nt, int
     return *reinterpret_cast<const f32x4*>(vec + 32 * nt + 8 * g + 4 * half);
 }
 
+// ---- arithmetic shared by the 32-token kernel below and the 16-token kernel (t2s_rows16.h) --------------------------------
+// The two kernels must give a token the SAME BITS (a 32-series strong-scaling shard runs the 16-token kernel, the 256-series
+// batch the 32-token one, and the shard's rows have to equal the batch's): every fused multiply-add is spelled out, and the
+// LayerNorm sums use a reduction tree both lane layouts can follow -- four partial sums P0..P3 over the features a lane
+// group of the 16-token layout owns (t2s_rows16.h: feature 16 mt + pi(g, r)), each added up in ascending (mt, r) order, then
+// (P0 + P2) + (P1 + P3).  A lane half h of the 32-token layout owns P_h (its elements e = 0, 2) and P_{h+2} (e = 1, 3).
+__device__ __forceinline__ float res_gate(float x, float gate, float acc, float bias) {      // x + gate (acc + bias)
+    return __builtin_fmaf(gate, acc + bias, x);
+}
+__device__ __forceinline__ float ln_y(float x, float mean, float rstd, float sc, float sh) {   // modulate(LN(x))
+    return __builtin_fmaf((x - mean) * rstd, 1.0f + sc, sh);
+}
+__device__ __forceinline__ float ln_rstd(float ss_total, float eps) { return rsqrtf(ss_total * (1.0f / 128.0f) + eps); }
+
 // LayerNorm (no affine, eps) + modulate over the 128 features a lane pair holds
 __device__ __forceinline__ void ln_modulate(const f32x16 (&x)[4], f32x16 (&y)[4],
                                             const float* __restrict__ shift,
                                             const float* __restrict__ scale, int half, float eps) {
-    float s = 0.f;
+    float s0 = 0.f, s1 = 0.f;                       // P_half (e = 0, 2) and P_{half+2} (e = 1, 3)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s += x[nt][r];
+        for (int g = 0; g < 4; ++g) {
+            s0 += x[nt][4 * g + 0];
+            s1 += x[nt][4 * g + 1];
+            s0 += x[nt][4 * g + 2];
+            s1 += x[nt][4 * g + 3];
+        }
+    float s = s0 + s1;
     s += xhalf(s);
     const float mean = s * (1.0f / 128.0f);
-    float ss = 0.f;
+    float q0 = 0.f, q1 = 0.f;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float d = x[nt][r] - mean;
-            ss += d * d;
+        for (int g = 0; g < 4; ++g) {
+            const float d0 = x[nt][4 * g + 0] - mean, d1 = x[nt][4 * g + 1] - mean;
+            const float d2 = x[nt][4 * g + 2] - mean, d3 = x[nt][4 * g + 3] - mean;
+            q0 = __builtin_fmaf(d0, d0, q0);
+            q1 = __builtin_fmaf(d1, d1, q1);
+            q0 = __builtin_fmaf(d2, d2, q0);
+            q1 = __builtin_fmaf(d3, d3, q1);
         }
+    float ss = q0 + q1;
     ss += xhalf(ss);
-    const float rstd = rsqrtf(ss * (1.0f / 128.0f) + eps);
+    const float rstd = ln_rstd(ss, eps);
     // The second pass recomputes x - mean from x: hipcc otherwise keeps the 64 differences of the variance pass alive
     // next to x and y (192 registers) and spills some of them -- and every scratch reload waits vmcnt(0), draining
     // the weight DMA and the parking stores.  The empty asm makes `mean` opaque so the subtraction is not CSE'd.
@@ -129,18 +154,18 @@ __device__ __forceinline__ void ln_modulate(const f32x16 (&x)[4], f32x16 (&y)[4]
             const f32x4 sc = ldc4(scale, nt, g, half);
             const f32x4 sh = ldc4(shift, nt, g, half);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                y[nt][4 * g + e] = (x[nt][4 * g + e] - mean2) * rstd * (1.0f + sc[e]) + sh[e];
+            for (int e = 0; e < 4; ++e) y[nt][4 * g + e] = ln_y(x[nt][4 * g + e], mean2, rstd, sc[e], sh[e]);
         }
 }
 
 
 // One 32-output x K=128 weight tile (16 fragments at wb[G * 64]) against a B operand in registers, software-pipelined:
-// fragment G+1 is fetched from LDS BEFORE the four MFMAs of fragment G are issued.  hipcc otherwise emits
-// `ds_read_b128 ; s_waitcnt lgkmcnt(0) ; 4 x v_mfma` with ONE fragment register: the read is issued when the previous
-// group's last MFMA issues (~192 cycles into a 256-cycle group) and returns ~120 cycles later, i.e. the matrix pipe idles
-// ~20 % of every group unless a second wave on the SIMD covers it -- which a 32-series shard (960 tiles for 1024 SIMDs)
-// does not have.  sched_barrier pins the order; the waitcnt pass then emits the counted lgkmcnt(1).
+// fragment G+1 is fetched from LDS BEFORE the four MFMAs of fragment G are issued (hipcc otherwise emits
+// `ds_read_b128 ; s_waitcnt lgkmcnt(0) ; 4 x v_mfma` with ONE fragment register).  sched_barrier pins the order; with the
+// weight DMA hidden from the waitcnt pass (glds16_asm) the wait becomes the counted lgkmcnt(1).  Measured: the LDS round
+// trip was already covered by the dependent 64-cycle MFMA chain -- timing-only builds without the fragment reads, without the
+// DMA or without the chunk barriers are all within 3 % of the real kernel (profiles/r03_rows_ablations.txt); what a tile
+// pays beyond its MFMA + VALU time is its prologue (x / attention-output rows from HBM), launch and tail.
 #ifndef T2S_ROWS_PIPE
 #define T2S_ROWS_PIPE 1
 #endif
@@ -305,7 +330,7 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
                     const f32x4 bias = ldc4(c_bp, nt, g, half);
                     const f32x4 gate = ldc4(mb + 2 * D, nt, g, half);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x[nt][4 * g + e] += gate[e] * (acc[4 * g + e] + bias[e]);
+                    for (int e = 0; e < 4; ++e) x[nt][4 * g + e] = res_gate(x[nt][4 * g + e], gate[e], acc[4 * g + e], bias[e]);
                 }
                 chunk_done(ci, 0);
                 ++ci;
@@ -399,7 +424,7 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
                     const f32x4 bias = ldc4(c_b2, nt, g, half);
                     const f32x4 gate = ldc4(mb + 5 * D, nt, g, half);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x[nt][4 * g + e] += gate[e] * (acc[nt][4 * g + e] + bias[e]);
+                    for (int e = 0; e < 4; ++e) x[nt][4 * g + e] = res_gate(x[nt][4 * g + e], gate[e], acc[nt][4 * g + e], bias[e]);
                 }
             if (active && (DO_QKV || a.out0 == nullptr || a.keep_x)) {   // final residual stream of this block
 #pragma unroll
