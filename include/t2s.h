@@ -305,14 +305,16 @@ typedef struct t2s_vae_weights {
 int t2s_vae_create(const t2s_vae_weights* w, t2s_vae** out);
 void t2s_vae_destroy(t2s_vae* h);
 /* Decoder.forward, vqvae.py:97-105: z (B,64,30) -> recon (B,L), after (B,64,L/4) (may be NULL).
- * L in {4..128}, L % 4 == 0.  (The host mirror applies torch.squeeze's shape rule.) */
+ * Any L % 4 == 0: up to 128 a series is one LDS-resident tile, longer ones (the reference's SUSHI set is 2048 long) run
+ * as time tiles with recomputed halos -- the same values bit for bit.  (The host mirror applies torch.squeeze's rule.) */
 int t2s_vae_decode(t2s_vae* h, const float* z, float* recon, float* after, int B, int L,
                    void* stream);
 /* Decoder.forward on a latent of another width: z (B,64,latent_w), latent_w <= 32 (F.interpolate at vqvae.py:98 accepts any;
  * BASELINE configs[0] decodes the (B,64,L/4) latent of the MLP denoiser, for which the interpolation is the identity). */
 int t2s_vae_decode_w(t2s_vae* h, const float* z, float* recon, float* after, int B, int L, int latent_w,
                      void* stream);
-/* Encoder.forward, vqvae.py:57-71: x (B,L) -> z (B,64,30), before (B,64,L/4) (may be NULL). */
+/* Encoder.forward, vqvae.py:57-71: x (B,L) -> z (B,64,30), before (B,64,L/4) (may be NULL for L <= 128; for longer
+ * series the time tiles write `before` and a second launch interpolates it to the latent, so the buffer is required). */
 int t2s_vae_encode(t2s_vae* h, const float* x, float* z, float* before, int B, int L,
                    void* stream);
 

@@ -434,7 +434,7 @@ extern "C" int t2s_sampler_create(t2s_dit* dit, t2s_vae* vae, const t2s_sample_c
                 "t2s_sampler_create: batch=%d needs 2*batch <= dit max_seqs=%d", cfg->batch, t2s_dit_max_seqs(dit));
     T2S_REQUIRE(cfg->t_values, "t2s_sampler_create: t_values is NULL");
     T2S_REQUIRE(cfg->mode != T2S_MODE_DDPM || cfg->ddpm_coef, "t2s_sampler_create: DDPM needs ddpm_coef");
-    T2S_REQUIRE(!vae || (cfg->length >= 4 && cfg->length % 4 == 0 && cfg->length <= 128),
+    T2S_REQUIRE(!vae || (cfg->length >= 4 && cfg->length % 4 == 0 && cfg->length <= (1 << 20)),
                 "t2s_sampler_create: length=%d unsupported", cfg->length);
     t2s_sampler* s = new t2s_sampler();
     s->dit = dit; s->vae = vae; s->cfg = *cfg;

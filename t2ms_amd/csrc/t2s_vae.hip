@@ -1,9 +1,13 @@
 // LA-VAE codec (reference model/pretrained/vqvae.py:36-105) for MI355X.
 //
 // The codec runs once per batch (15-17 MFLOP per series against 1.95 TFLOP for the
-// 1000-step loop), so it is a single launch with ONE workgroup per series: the whole
-// activation stack of a series (<= 256 channels x <= 32 positions) stays in LDS from the
-// latent to the decoded samples, weights (2.7 MB fp32) stream from L2.  Exact fp32 VALU.
+// 1000-step loop), so it is a single launch with ONE workgroup per series and time tile: the
+// activation stack of a tile (<= 256 channels x <= 32 positions at the L/4 resolution) stays in
+// LDS from the latent to the decoded samples, weights (2.7 MB fp32) stream from L2.  Exact fp32 VALU.
+// L <= 128 (BASELINE configs: 24 / 48 / 96) is one tile = the whole series.  Longer series (vqvae.py accepts any L;
+// the reference's SUSHI set is 2048 long) are cut into tiles of 32 - 2 H core positions with a halo of H = the
+// convolutions' receptive radius on either side, recomputed per tile: every kept value sums the same terms in the
+// same order as the untiled computation, so the tiling is invisible in the results.
 #include "t2s_common.h"
 
 namespace t2s {
@@ -27,10 +31,13 @@ struct VaeDev {  // device copies in the reference layouts
 
 // out[co][t] (+)= b[co] + sum_{ci,kk} W[co][ci][kk] * in[ci][t*STRIDE + kk - pad]   (Conv1d)
 // Buffers are LDS, row stride `ld`.  RELU_OUT applies to the final value; ACCUM adds into out.
+// Windows: `in` holds global positions [in_g0, in_g0 + Tin), `out` global positions [out_g0, out_g0 + Tout); both are
+// clipped to the series, so "outside the input window" is either true zero padding or a position whose influence
+// stays inside the discarded halo.
 template <int KS, int STRIDE, bool RELU_OUT, bool ACCUM>
 __device__ void conv1d_lds(const float* in, int Cin, int Tin, float* out, int Cout, int Tout,
                            const float* __restrict__ W, const float* __restrict__ bias, int pad,
-                           int ld_in, int ld_out) {
+                           int ld_in, int ld_out, int in_g0 = 0, int out_g0 = 0) {
     // VAE_CO_PER_THREAD (8; measured 2: 21.3, 4: 19.1, 8: 17.9, 16: 17.8 ms per uncached bf16 train step) output channels per thread: the LDS activations are read once for four FMAs and four independent
     // accumulation chains are in flight (one chain per thread was latency-bound at 1.6 TFLOP/s); each output
     // still sums its (ci, kk) terms in the same order.  Cout is a multiple of 4 for every LA-VAE layer but the last.
@@ -47,7 +54,7 @@ __device__ void conv1d_lds(const float* in, int Cin, int Tin, float* out, int Co
             for (int ci = 0; ci < Cin; ++ci) {
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) {
-                    const int ti = t * STRIDE + kk - pad;
+                    const int ti = (out_g0 + t) * STRIDE + kk - pad - in_g0;
                     if (ti >= 0 && ti < Tin) {
                         const float a = in[ci * ld_in + ti];
 #pragma unroll
@@ -72,7 +79,7 @@ __device__ void conv1d_lds(const float* in, int Cin, int Tin, float* out, int Co
         for (int ci = 0; ci < Cin; ++ci) {
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
-                const int ti = t * STRIDE + kk - pad;
+                const int ti = (out_g0 + t) * STRIDE + kk - pad - in_g0;
                 if (ti >= 0 && ti < Tin) acc += w[ci * KS + kk] * in[ci * ld_in + ti];
             }
         }
@@ -108,12 +115,14 @@ __device__ void convT1d_k4s2_lds(const float* in, int Cin, int Tin, float* out, 
 }
 
 // F.interpolate(mode='linear', align_corners=True) along the last axis, [C][Tin] -> [C][Tout]
+// (`out` holds the global output positions [out_g0, out_g0 + Tw) of Tout)
 __device__ void interp_linear_ac(const float* in, int C, int Tin, int ld_in, float* out, int Tout,
-                                 int ld_out) {
+                                 int ld_out, int out_g0 = 0, int Tw = -1) {
     const float scale = Tout > 1 ? (float)(Tin - 1) / (float)(Tout - 1) : 0.f;
-    for (int o = threadIdx.x; o < C * Tout; o += VAE_THREADS) {
-        const int c = o / Tout, t = o - c * Tout;
-        const float real = scale * (float)t;
+    if (Tw < 0) Tw = Tout;
+    for (int o = threadIdx.x; o < C * Tw; o += VAE_THREADS) {
+        const int c = o / Tw, t = o - c * Tw;
+        const float real = scale * (float)(out_g0 + t);
         const int i0 = (int)real;
         const int i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
         const float l1 = real - (float)i0;
@@ -146,9 +155,28 @@ __device__ void residual_stack(float* x, float* tmp, int hidden, int res_hidden,
 }
 
 constexpr int LD = VAE_TMAX + 1;  // LDS row stride (floats)
-constexpr int VAE_LDS_FLOATS = 2 * VAE_CMAX * LD + 128 * 4 + 64 * 2 * VAE_TMAX;
+constexpr int VAE_WIDE_T = 2 * VAE_TMAX + 2;   // positions at the L/2 resolution a tile's stride-2 convolutions touch
+constexpr int VAE_LDS_FLOATS = 2 * VAE_CMAX * LD + 128 * 4 + 64 * VAE_WIDE_T;
 
-// Decoder.forward (vqvae.py:97-105)
+// Time tiling at the L/4 resolution: tile `ti` keeps core positions [c0, c1) and computes the window [w0, w1) =
+// core +- halo, clipped to [0, T).  One tile (T <= 32): the window is the series.
+struct VaeTile {
+    int c0, c1, w0, w1;
+};
+__host__ __device__ inline int vae_core(int T, int halo) { return T <= VAE_TMAX ? T : VAE_TMAX - 2 * halo; }
+__host__ __device__ inline int vae_tiles(int T, int halo) { const int c = vae_core(T, halo); return (T + c - 1) / c; }
+__device__ inline VaeTile vae_tile(int T, int halo, int ti) {
+    const int core = vae_core(T, halo);
+    VaeTile v;
+    v.c0 = ti * core;
+    v.c1 = v.c0 + core < T ? v.c0 + core : T;
+    v.w0 = v.c0 - halo > 0 ? v.c0 - halo : 0;
+    v.w1 = v.c1 + halo < T ? v.c1 + halo : T;
+    return v;
+}
+
+// Decoder.forward (vqvae.py:97-105).  Receptive radius at the L/4 resolution: conv_1 1 + residual stack n_res + the two
+// transposed convolutions 1 (the second one reads half a position beyond the first's window) = n_res + 2.
 __global__ __launch_bounds__(VAE_THREADS) void vae_decode_kernel(const VaeDev w,
                                                                  const float* __restrict__ z,
                                                                  float* __restrict__ recon,
@@ -156,42 +184,45 @@ __global__ __launch_bounds__(VAE_THREADS) void vae_decode_kernel(const VaeDev w,
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* bufA = smem;                   // [<=256][LD]
     float* bufB = smem + VAE_CMAX * LD;   // [<=256][LD]
-    float* wide = bufB + VAE_CMAX * LD;   // [hidden/2][2T] for the first transposed conv
+    float* wide = bufB + VAE_CMAX * LD;   // [hidden/2][2 Tw] for the first transposed conv
     const int b = blockIdx.x;
     const int T = L / 4;
+    const VaeTile tl = vae_tile(T, w.n_res + 2, blockIdx.y);
+    const int Tw = tl.w1 - tl.w0;
     // latent (64,W) -> bufB (row stride LD covers W <= 32; W = 30 on the DiT path, L/4 on the MLP-denoiser path)
     for (int o = threadIdx.x; o < w.emb * W; o += VAE_THREADS) {
         const int c = o / W, t = o - c * W;
         bufB[c * LD + t] = z[(size_t)b * w.emb * W + o];
     }
     __syncthreads();
-    interp_linear_ac(bufB, w.emb, W, LD, bufA, T, LD);
+    interp_linear_ac(bufB, w.emb, W, LD, bufA, T, LD, tl.w0, Tw);
     __syncthreads();
     if (after) {
-        for (int o = threadIdx.x; o < w.emb * T; o += VAE_THREADS) {
-            const int c = o / T, t = o - c * T;
-            after[(size_t)b * w.emb * T + o] = bufA[c * LD + t];
+        const int nc = tl.c1 - tl.c0;
+        for (int o = threadIdx.x; o < w.emb * nc; o += VAE_THREADS) {
+            const int c = o / nc, t = tl.c0 + (o - c * nc);
+            after[((size_t)b * w.emb + c) * T + t] = bufA[c * LD + (t - tl.w0)];
         }
     }
-    conv1d_lds<3, 1, false, false>(bufA, w.emb, T, bufB, w.hidden, T, w.dec_conv1_w, w.dec_conv1_b, 1,
+    conv1d_lds<3, 1, false, false>(bufA, w.emb, Tw, bufB, w.hidden, Tw, w.dec_conv1_w, w.dec_conv1_b, 1,
                                    LD, LD);
     __syncthreads();
-    residual_stack(bufB, bufA, w.hidden, w.res_hidden, w.n_res, T, w.dec_c3, w.dec_c1, LD);
-    const int ldw = 2 * T;
-    convT1d_k4s2_lds<true>(bufB, w.hidden, T, wide, w.hidden / 2, w.dec_ct1_w, w.dec_ct1_b, LD, ldw);
+    residual_stack(bufB, bufA, w.hidden, w.res_hidden, w.n_res, Tw, w.dec_c3, w.dec_c1, LD);
+    const int ldw = 2 * Tw;      // `wide` holds L/2-resolution positions [2 w0, 2 w1)
+    convT1d_k4s2_lds<true>(bufB, w.hidden, Tw, wide, w.hidden / 2, w.dec_ct1_w, w.dec_ct1_b, LD, ldw);
     __syncthreads();
-    // last transposed conv (hidden/2 -> 1) writes straight to global
+    // last transposed conv (hidden/2 -> 1) writes the core samples [4 c0, 4 c1) straight to global
     {
-        const int Tin = 2 * T, Cin = w.hidden / 2;
-        for (int t = threadIdx.x; t < L; t += VAE_THREADS) {
+        const int Tin = 2 * Tw, Cin = w.hidden / 2, i_g0 = 2 * tl.w0;
+        for (int t = 4 * tl.c0 + threadIdx.x; t < 4 * tl.c1; t += VAE_THREADS) {
             float acc = w.dec_ct2_b[0];
             const int k0 = (t + 1) & 1;
             for (int ci = 0; ci < Cin; ++ci) {
 #pragma unroll
                 for (int kk2 = 0; kk2 < 2; ++kk2) {
                     const int kk = k0 + 2 * kk2;
-                    const int i = (t + 1 - kk) >> 1;
-                    if (t + 1 - kk >= 0 && i < Tin) acc += wide[ci * ldw + i] * w.dec_ct2_w[ci * 4 + kk];
+                    const int i = ((t + 1 - kk) >> 1) - i_g0;
+                    if (t + 1 - kk >= 0 && i >= 0 && i < Tin) acc += wide[ci * ldw + i] * w.dec_ct2_w[ci * 4 + kk];
                 }
             }
             recon[(size_t)b * L + t] = acc;
@@ -199,7 +230,9 @@ __global__ __launch_bounds__(VAE_THREADS) void vae_decode_kernel(const VaeDev w,
     }
 }
 
-// Encoder.forward (vqvae.py:57-71)
+// Encoder.forward (vqvae.py:57-71).  Receptive radius at the L/4 resolution behind conv_2: conv_3 1 + residual stack n_res.
+// The final interpolation to 30 positions needs the WHOLE `before` row: fused here when the series is one tile, otherwise
+// vae_interp_z_kernel reads the rows the tiles wrote.
 __global__ __launch_bounds__(VAE_THREADS) void vae_encode_kernel(const VaeDev w,
                                                                  const float* __restrict__ x,
                                                                  float* __restrict__ z,
@@ -207,43 +240,67 @@ __global__ __launch_bounds__(VAE_THREADS) void vae_encode_kernel(const VaeDev w,
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* bufA = smem;
     float* bufB = smem + VAE_CMAX * LD;
-    float* wide = bufB + VAE_CMAX * LD;   // [hidden/2][L/2]
+    float* wide = bufB + VAE_CMAX * LD;   // [hidden/2][Tu]: conv_1 outputs at L/2-resolution positions [u0, u1)
     const int b = blockIdx.x;
     const int T2 = L / 2, T = L / 4;
     const int half_c = w.hidden / 2;
+    const VaeTile tl = vae_tile(T, w.n_res + 1, blockIdx.y);
+    const int Tw = tl.w1 - tl.w0;
+    // conv_2 (k4 s2 p1) output t reads conv_1 outputs 2t-1 .. 2t+2
+    const int u0 = 2 * tl.w0 - 1 > 0 ? 2 * tl.w0 - 1 : 0;
+    const int u1 = 2 * (tl.w1 - 1) + 3 < T2 ? 2 * (tl.w1 - 1) + 3 : T2;
+    const int Tu = u1 - u0;
     // conv_1: 1 -> hidden/2, k4 s2 p1, ReLU ; input straight from global
-    for (int o = threadIdx.x; o < half_c * T2; o += VAE_THREADS) {
-        const int co = o / T2, t = o - co * T2;
+    for (int o = threadIdx.x; o < half_c * Tu; o += VAE_THREADS) {
+        const int co = o / Tu, t = u0 + (o - co * Tu);
         float acc = w.enc_conv1_b[co];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int ti = 2 * t + kk - 1;
             if (ti >= 0 && ti < L) acc += w.enc_conv1_w[co * 4 + kk] * x[(size_t)b * L + ti];
         }
-        wide[co * T2 + t] = fmaxf(acc, 0.f);
+        wide[co * Tu + (t - u0)] = fmaxf(acc, 0.f);
     }
     __syncthreads();
-    conv1d_lds<4, 2, true, false>(wide, half_c, T2, bufA, w.hidden, T, w.enc_conv2_w, w.enc_conv2_b, 1,
-                                  T2, LD);
+    conv1d_lds<4, 2, true, false>(wide, half_c, Tu, bufA, w.hidden, Tw, w.enc_conv2_w, w.enc_conv2_b, 1,
+                                  Tu, LD, u0, tl.w0);
     __syncthreads();
-    conv1d_lds<3, 1, false, false>(bufA, w.hidden, T, bufB, w.hidden, T, w.enc_conv3_w, w.enc_conv3_b,
+    conv1d_lds<3, 1, false, false>(bufA, w.hidden, Tw, bufB, w.hidden, Tw, w.enc_conv3_w, w.enc_conv3_b,
                                    1, LD, LD);
     __syncthreads();
-    residual_stack(bufB, bufA, w.hidden, w.res_hidden, w.n_res, T, w.enc_c3, w.enc_c1, LD);
-    conv1d_lds<1, 1, false, false>(bufB, w.hidden, T, bufA, w.emb, T, w.enc_prevq_w, w.enc_prevq_b, 0,
+    residual_stack(bufB, bufA, w.hidden, w.res_hidden, w.n_res, Tw, w.enc_c3, w.enc_c1, LD);
+    conv1d_lds<1, 1, false, false>(bufB, w.hidden, Tw, bufA, w.emb, Tw, w.enc_prevq_w, w.enc_prevq_b, 0,
                                    LD, LD);
     __syncthreads();
     if (before) {
-        for (int o = threadIdx.x; o < w.emb * T; o += VAE_THREADS) {
-            const int c = o / T, t = o - c * T;
-            before[(size_t)b * w.emb * T + o] = bufA[c * LD + t];
+        const int nc = tl.c1 - tl.c0;
+        for (int o = threadIdx.x; o < w.emb * nc; o += VAE_THREADS) {
+            const int c = o / nc, t = tl.c0 + (o - c * nc);
+            before[((size_t)b * w.emb + c) * T + t] = bufA[c * LD + (t - tl.w0)];
         }
     }
+    if (gridDim.y > 1) return;            // tiled: vae_interp_z_kernel finishes from `before`
     interp_linear_ac(bufA, w.emb, T, LD, bufB, LATW, LD);
     __syncthreads();
     for (int o = threadIdx.x; o < w.emb * LATW; o += VAE_THREADS) {
         const int c = o / LATW, t = o - c * LATW;
         z[(size_t)b * w.emb * LATW + o] = bufB[c * LD + t];
+    }
+}
+
+// z = F.interpolate(before, 30, mode='linear', align_corners=True) (vqvae.py:70) from the (B,64,T) rows in global memory
+__global__ __launch_bounds__(VAE_THREADS) void vae_interp_z_kernel(const float* __restrict__ before, float* __restrict__ z,
+                                                                   int C, int T) {
+    const float scale = (float)(T - 1) / (float)(LATW - 1);
+    const float* in = before + (size_t)blockIdx.x * C * T;
+    for (int o = threadIdx.x; o < C * LATW; o += VAE_THREADS) {
+        const int c = o / LATW, t = o - c * LATW;
+        const float real = scale * (float)t;
+        const int i0 = (int)real;
+        const int i1 = i0 + (i0 < T - 1 ? 1 : 0);
+        const float l1 = real - (float)i0;
+        const float l0 = 1.0f - l1;
+        z[(size_t)blockIdx.x * C * LATW + o] = l0 * in[(size_t)c * T + i0] + l1 * in[(size_t)c * T + i1];
     }
 }
 
@@ -361,8 +418,9 @@ extern "C" int t2s_vae_decode(t2s_vae* h, const float* z, float* recon, float* a
     T2S_REQUIRE(h && z && recon, "t2s_vae_decode: NULL argument");
     T2S_REQUIRE(h->has_decoder, "t2s_vae_decode: handle was created without decoder weights");
     T2S_REQUIRE(B > 0, "t2s_vae_decode: B=%d", B);
-    T2S_REQUIRE(L >= 4 && L % 4 == 0 && L / 4 <= VAE_TMAX, "t2s_vae_decode: L=%d unsupported (multiple of 4, <= 128)", L);
-    vae_decode_kernel<<<B, VAE_THREADS, VAE_LDS_FLOATS * 4, (hipStream_t)stream>>>(h->dev, z, recon, after, L, LATW);
+    T2S_REQUIRE(L >= 4 && L % 4 == 0 && L <= (1 << 20), "t2s_vae_decode: L=%d unsupported (a multiple of 4)", L);
+    vae_decode_kernel<<<dim3(B, vae_tiles(L / 4, h->dev.n_res + 2)), VAE_THREADS, VAE_LDS_FLOATS * 4, (hipStream_t)stream>>>(
+        h->dev, z, recon, after, L, LATW);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }
@@ -372,9 +430,10 @@ extern "C" int t2s_vae_decode_w(t2s_vae* h, const float* z, float* recon, float*
     T2S_REQUIRE(h && z && recon, "t2s_vae_decode_w: NULL argument");
     T2S_REQUIRE(h->has_decoder, "t2s_vae_decode_w: handle was created without decoder weights");
     T2S_REQUIRE(B > 0, "t2s_vae_decode_w: B=%d", B);
-    T2S_REQUIRE(L >= 4 && L % 4 == 0 && L / 4 <= VAE_TMAX, "t2s_vae_decode_w: L=%d unsupported (multiple of 4, <= 128)", L);
+    T2S_REQUIRE(L >= 4 && L % 4 == 0 && L <= (1 << 20), "t2s_vae_decode_w: L=%d unsupported (a multiple of 4)", L);
     T2S_REQUIRE(latent_w >= 1 && latent_w <= VAE_TMAX, "t2s_vae_decode_w: latent width %d unsupported (1..%d)", latent_w, VAE_TMAX);
-    vae_decode_kernel<<<B, VAE_THREADS, VAE_LDS_FLOATS * 4, (hipStream_t)stream>>>(h->dev, z, recon, after, L, latent_w);
+    vae_decode_kernel<<<dim3(B, vae_tiles(L / 4, h->dev.n_res + 2)), VAE_THREADS, VAE_LDS_FLOATS * 4, (hipStream_t)stream>>>(
+        h->dev, z, recon, after, L, latent_w);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }
@@ -384,8 +443,13 @@ extern "C" int t2s_vae_encode(t2s_vae* h, const float* x, float* z, float* befor
     T2S_REQUIRE(h && x && z, "t2s_vae_encode: NULL argument");
     T2S_REQUIRE(h->has_encoder, "t2s_vae_encode: handle was created without encoder weights");
     T2S_REQUIRE(B > 0, "t2s_vae_encode: B=%d", B);
-    T2S_REQUIRE(L >= 4 && L % 4 == 0 && L / 4 <= VAE_TMAX, "t2s_vae_encode: L=%d unsupported (multiple of 4, <= 128)", L);
-    vae_encode_kernel<<<B, VAE_THREADS, VAE_LDS_FLOATS * 4, (hipStream_t)stream>>>(h->dev, x, z, before, L);
+    T2S_REQUIRE(L >= 4 && L % 4 == 0 && L <= (1 << 20), "t2s_vae_encode: L=%d unsupported (a multiple of 4)", L);
+    const int tiles = vae_tiles(L / 4, h->dev.n_res + 1);
+    T2S_REQUIRE(tiles == 1 || before, "t2s_vae_encode: L=%d > 128 runs in time tiles and needs the `before` output buffer "
+                                      "(the interpolation to the latent reads the whole row)", L);
+    vae_encode_kernel<<<dim3(B, tiles), VAE_THREADS, VAE_LDS_FLOATS * 4, (hipStream_t)stream>>>(h->dev, x, z, before, L);
+    T2S_LAUNCH_CHECK();
+    if (tiles > 1) vae_interp_z_kernel<<<B, VAE_THREADS, 0, (hipStream_t)stream>>>(before, z, h->dev.emb, L / 4);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }

@@ -340,6 +340,53 @@ def test_vae_golden(golden_dir, dev, vae, L_, B):
     assert _maxdiff(rec2, g[f"rec_rand_{L_}_{B}"]) < 2e-5
 
 
+@pytest.mark.parametrize("L_", [512, 2048])
+@pytest.mark.parametrize("B", [1, 3])
+def test_vae_long_series_reference_fixture(golden_dir, dev, vae, L_, B):
+    """LA-VAE beyond one LDS tile (L > 128: vqvae.py:57-71,97-105 accept any L; the reference's SUSHI set, dataloader.py:88-90,
+    is 2048 long): the time-tiled encoder / decoder kernels against the REFERENCE run at L = 512 and 2048
+    (tests/golden/vae_long.npz) -- z, recon in full, `before` / `after` at a stride coprime with the tile cores plus their
+    fp64 row sums (every position enters) -- and the decode of a random latent for B = 1 (torch.squeeze's (L,) shape)."""
+    g = _load(golden_dir, "vae_long")
+    xs = synth.make_series(100 + L_ + B, B, L_).to(dev)
+    st = 7 if L_ == 512 else 11
+    with torch.no_grad():
+        z, before = vae.encoder(xs)
+        rec, after = vae.decoder(z, length=L_)
+    assert tuple(rec.shape) == g[f"rec_{L_}_{B}"].shape
+    assert _maxdiff(z, g[f"z_{L_}_{B}"]) < 1e-5 and _maxdiff(rec, g[f"rec_{L_}_{B}"]) < 1e-5
+    assert _maxdiff(before[:, :, ::st], g[f"before_s{st}_{L_}_{B}"]) < 1e-5
+    assert _maxdiff(after[:, :, ::st], g[f"after_s{st}_{L_}_{B}"]) < 1e-5
+    for name, t in (("before", before), ("after", after)):
+        rs = t.double().sum(2).cpu().numpy()
+        assert np.abs(rs - g[f"{name}_rowsum_{L_}_{B}"]).max() < 1e-5 * (L_ // 4), name
+    if B == 1:
+        with torch.no_grad():
+            rec2, _ = vae.decoder(synth.make_latents(300 + L_, B).to(dev), length=L_)
+        assert _maxdiff(rec2, g[f"rec_rand_{L_}_{B}"]) < 2e-5
+
+
+def test_vae_time_tiles_are_invisible(dev, vae):
+    """Tiling at a length with ragged tiles (L = 260: 65 positions = 3 encoder / 3 decoder tiles, the last ones short)
+    against the oracle; and the C ABI's refusal of a tiled encode without the `before` buffer."""
+    L_, B = 260, 2
+    xs = synth.make_series(7, B, L_)
+    vsd = synth.make_vae_state_dict(2025)
+    with torch.no_grad():
+        z, before = vae.encoder(xs.to(dev))
+        rec, after = vae.decoder(z, length=L_)
+        zo, bo = O.vae_encode(vsd, xs)
+        ro, ao = O.vae_decode(vsd, zo, L_)
+    assert _maxdiff(z, zo) < 1e-5 and _maxdiff(before, bo) < 1e-5
+    assert _maxdiff(rec, ro) < 1e-5 and _maxdiff(after, ao) < 1e-5
+    # the C ABI refuses a tiled encode without the `before` buffer instead of skipping the interpolation
+    x = xs.to(dev).contiguous()
+    zz = torch.empty(B, 64, 30, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.lib().t2s_vae_encode(vae.encoder._handle(dev), x.data_ptr(), zz.data_ptr(), None, B, L_, L.stream_ptr(dev))
+    assert rc != 0 and b"before" in L.lib().t2s_last_error()
+
+
 def _chain_setup(dev, vae):
     from model.denoiser.transformer import Transformer
     from t2ms_amd.sampler import Sampler

@@ -18,6 +18,13 @@ def _t(a):
     return torch.from_numpy(np.asarray(a))
 
 
+def _maxdiff(a, b):
+    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().numpy() if torch.is_tensor(b) else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max())
+
+
 def _close(a, b, atol, rtol=0.0):
     a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
     np.testing.assert_allclose(a, b, atol=atol, rtol=rtol)
@@ -102,6 +109,26 @@ def test_vae(golden_dir, L, B):
     assert tuple(rec.shape) == g[f"rec_{L}_{B}"].shape == ((L,) if B == 1 else (B, L))
     _close(rec, g[f"rec_{L}_{B}"], atol=1e-6)
     _close(rec2, g[f"rec_rand_{L}_{B}"], atol=1e-5)
+
+
+@pytest.mark.parametrize("L", [512, 2048])
+@pytest.mark.parametrize("B", [1, 3])
+def test_vae_long_series(golden_dir, L, B):
+    """vqvae.py accepts any L (the reference's SUSHI set is 2048 long): the oracle against the reference run at L = 512 and
+    2048 (tests/golden/gen_golden_r3.py) -- what the GPU's time-tiled LA-VAE kernels are checked against."""
+    g = _load(golden_dir, "vae_long")
+    vsd = synth.make_vae_state_dict(2025)
+    xs = synth.make_series(100 + L + B, B, L)
+    st = 7 if L == 512 else 11
+    with torch.no_grad():
+        z, before = O.vae_encode(vsd, xs)
+        rec, after = O.vae_decode(vsd, z, L)
+    assert tuple(rec.shape) == g[f"rec_{L}_{B}"].shape
+    assert _maxdiff(z, g[f"z_{L}_{B}"]) < 1e-6 and _maxdiff(rec, g[f"rec_{L}_{B}"]) < 1e-6
+    assert _maxdiff(before[:, :, ::st], g[f"before_s{st}_{L}_{B}"]) < 1e-6
+    assert _maxdiff(after[:, :, ::st], g[f"after_s{st}_{L}_{B}"]) < 1e-6
+    assert np.allclose(before.double().sum(2).numpy(), g[f"before_rowsum_{L}_{B}"], rtol=0, atol=1e-9)
+
 
 
 def test_chains(golden_dir):
