@@ -254,6 +254,29 @@ class T2SAdamW(torch.optim.Optimizer):
 
 
 # ---------------------------------------------------------------------------- data parallel
+def allreduce_param_grads(params, dist, n_local: Optional[int] = None, n_global: Optional[int] = None,
+                          loss: Optional[torch.Tensor] = None):
+    """The same collective for a plain torch module (the MLP denoiser of BASELINE configs[0]: torch autograd, no persistent
+    bucket): the gradients of `params` are flattened into ONE message, weighted n_local / n_global, summed over the ranks
+    and scattered back; a parameter without a gradient (empty shard) contributes zeros.  Returns the global mean loss."""
+    if dist is None:
+        return loss
+    params = [p for p in params if p.requires_grad]
+    dev = params[0].device
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params] +
+                     [(loss.detach() if loss is not None else torch.zeros((), device=dev)).reshape(1).float()])
+    world = dist.get_world_size()
+    flat.mul_((float(n_local) / float(n_global)) if (n_local is not None and n_global) else 1.0 / world)
+    from . import dist as tdist
+    tdist.all_reduce_sum(dist, flat)
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.grad = flat[off:off + n].view_as(p).to(p.dtype)
+        off += n
+    return flat[off].clone()
+
+
 def allreduce_gradients(model, dist, n_local: Optional[int] = None, n_global: Optional[int] = None,
                         loss: Optional[torch.Tensor] = None):
     """Combine the DiT gradients of all ranks with ONE all-reduce of the flat 3.7 MB bucket (SURVEY.md 8e:

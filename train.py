@@ -35,7 +35,7 @@ from model.backbone.rectified_flow import RectifiedFlow      # noqa: E402
 from model.denoiser.transformer import Transformer            # noqa: E402
 from t2ms_amd import dist as tdist                            # noqa: E402
 from t2ms_amd import synth                                    # noqa: E402
-from t2ms_amd.train import T2SAdamW, allreduce_gradients      # noqa: E402
+from t2ms_amd.train import T2SAdamW, allreduce_gradients, allreduce_param_grads      # noqa: E402
 
 
 def _load_vae(args, device):
@@ -86,7 +86,24 @@ def train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world, 
     drop_text = bool(torch.rand(1) < 0.3)                      # classifier-free guidance coin (train.py:120-122)
     opt.zero_grad()
     loss = None
-    if n > 0:
+    is_mlp = getattr(args, "denoiser", "DiT") == "MLP"
+    if n > 0 and is_mlp:
+        # BASELINE configs[0] in the runnable form SURVEY.md 8(d) prescribes: the MLP denoiser (a torch module) diffuses
+        # the PRE-interpolation latent `before` (B,64,L/4 = 6); encoder, q_sample and the loss are the HIP kernels
+        emb = _h2d(emb[lo:hi].float(), device)
+        with torch.no_grad():
+            _, z = model.encoder(_h2d(x_1[lo:hi].float(), device).contiguous())
+        if z.shape[2] != 6:
+            raise ValueError(f"the MLP denoiser needs the 6-wide latent of L = 24 series (mlp.py:67), got L/4 = {z.shape[2]}")
+        if args.backbone != "ddpm":
+            raise ValueError("config 1 (MLP denoiser) is wired for --backbone ddpm")
+        noise = philox_normal(n, z[0].numel(), args.seed ^ 0x7261696E, step_no, lo, device).view_as(z)
+        t = _h2d(torch.floor(u * args.total_step).long()[lo:hi], device)
+        x_t, _ = backbone.q_sample(z.contiguous(), t, noise)
+        pred = model(x_t, t, None if drop_text else emb)
+        loss = backbone.loss(pred, noise)
+        loss.backward()
+    elif n > 0:
         emb = _h2d(emb[lo:hi].float(), device)
         if latents is not None and idx is not None:
             z = latents[_h2d(idx[lo:hi], device)]                                      # pre-encoded rows (latent cache)
@@ -109,7 +126,10 @@ def train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world, 
         loss.backward()
     elif args.backbone not in ("flowmatching", "ddpm"):
         raise ValueError(f"Unsupported backbone type: {args.backbone}")
-    if dist is not None:
+    if dist is not None and is_mlp:
+        loss = allreduce_param_grads([p for nm, p in model.named_parameters() if "encoder" not in nm], dist, n_local=n,
+                                     n_global=n_global, loss=loss)
+    elif dist is not None:
         _, loss = allreduce_gradients(model, dist, n_local=n, n_global=n_global,
                                       loss=loss if loss is not None else torch.zeros((), device=device))
     opt.step()
@@ -126,13 +146,19 @@ def train(args):
         os.makedirs(args.save_path, exist_ok=True)
     torch.manual_seed(args.seed)              # identical shuffles / t / CFG coin on every rank (CPU generator)
     dataset, dataloader = loader_provider(args, period="train")
-    model = {"DiT": Transformer}.get(args.denoiser)
+    from model.denoiser.mlp import MLP
+    model = {"DiT": Transformer, "MLP": MLP}.get(args.denoiser)                 # train.py:16
     if model is None:
-        raise ValueError("No denoiser found" if args.denoiser != "MLP" else
-                         "the MLP denoiser is config-1 plumbing (t2ms_amd.model.denoiser.mlp); train.py drives the DiT")
+        raise ValueError("No denoiser found")
+    if args.denoiser == "MLP":
+        # config 1 plumbing: the reference's MLP needs a 6-wide latent (mlp.py:55,67), i.e. fixed-length L = 24 data
+        if args.mix_train:
+            raise ValueError("--denoiser MLP needs fixed-length L = 24 series (its latent is (B,64,6)): use --split_train "
+                             "with a *_24 dataset")
+        args.cache_latents = False            # the cache holds the interpolated (B,64,30) latents of the DiT path
     model = model()
     if args.random_init:
-        sd = synth.make_dit_state_dict(args.seed)
+        sd = synth.make_dit_state_dict(args.seed) if args.denoiser == "DiT" else synth.make_mlp_state_dict(args.seed)
         model.load_state_dict(sd, strict=True)
     model = model.to(device)
     vae = _load_vae(args, device)
@@ -141,12 +167,17 @@ def train(args):
         raise ValueError("No backbone found")
     model.encoder = vae.encoder
     if args.bf16:
+        if args.denoiser != "DiT":
+            raise ValueError("--bf16 selects the DiT training kernels' arithmetic; the MLP denoiser is a torch module")
         model.set_train_dtype("bf16")
     for name, p in model.named_parameters():
         if "encoder" in name:
             p.requires_grad = not args.usepretrainedvae
     if not args.usepretrainedvae:
-        raise ValueError("training the LA-VAE encoder jointly is outside the accelerated path (frozen codec)")
+        # train.py:31-33 would un-freeze the grafted encoder: that needs the LA-VAE encoder's BACKWARD, which this build
+        # does not have (the codec is frozen in every script of the reference: scripts/*.sh never pass the flag)
+        raise ValueError("--usepretrainedvae False (training the LA-VAE encoder jointly) needs an encoder backward pass; "
+                         "this build trains the denoiser against the frozen codec only")
     if rank == 0:
         print(f"Total learnable parameters: {sum(p.numel() for p in model.parameters() if p.requires_grad)}")
     # every parameter, as the reference builds it (train.py:37): the optimizer state_dict then indexes the same 67
