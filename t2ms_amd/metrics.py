@@ -5,10 +5,10 @@ the run_0..run_k repetitions `--run_multi` writes, and the TS2Vec encoder forwar
 directory holding x_1.npy and x_t.npy ({save_path}/generation/{backbone}_{denoiser}_{dataset}_{cfg}_{steps}/[run_k/])
 and the run_* sub-directories.
 
-What stays with the reference: evaluation.py TRAINS the TS2Vec encoder at evaluation time (initialize_ts2vec, 200
-contrastive iterations from a random initialisation, :238); here `TS2VecEncoder` runs the forward of an encoder whose
-state dict the caller supplies (e.g. `fid_model.net.state_dict()`), so C-FID values are comparable only for the same
-trained encoder."""
+C-FID end to end: evaluation.py TRAINS the TS2Vec encoder at evaluation time (initialize_ts2vec, 200 contrastive
+iterations from a random initialisation, :238); `t2ms_amd.ts2vec` restates that training (torch autograd plumbing, pinned
+to the reference's loss curve) and `TS2VecEncoder` here runs the forward of the trained encoder on the HIP kernel, so the
+CLI prints C-FID from the .npy files alone.  (Values are comparable only for the same trained encoder / seeds.)"""
 from __future__ import annotations
 
 import os
@@ -213,6 +213,16 @@ def main(argv=None):
         gen = np.load(os.path.join(d, "x_t.npy"))
         mse, wape, _ = mse_wape(ori, gen)
         print(f"samples {ori.shape[0]}  MSE {mse:.6f}  WAPE {wape:.6f}  ED {ed(ori, gen)[0]:.6f}  DTW {dtw(ori, gen)[0]:.6f}")
+        if ori.shape[0] >= 8 and os.environ.get("T2S_METRICS_CFID", "1") not in ("", "0"):
+            # evaluation.py:238-243: train TS2Vec on the original series (200 contrastive iterations), encode both sets
+            # with it, FID of the representations.  The encoder is trained per call from a random initialisation, as in
+            # the reference, so the value varies from run to run unless torch / numpy are seeded by the caller.
+            from .ts2vec import initialize_ts2vec
+            o3 = ori if ori.ndim == 3 else ori[:, :, None]
+            g3 = gen if gen.ndim == 3 else gen[:, :, None]
+            model = initialize_ts2vec(o3.astype(np.float32), device="cuda")
+            print(f"samples {ori.shape[0]}  C-FID {fid(model.encode(o3, encoding_window='full_series'), model.encode(g3, encoding_window='full_series')):.6f}"
+                  f"  (TS2Vec trained {model.n_iters} iterations on the original series)")
     runs = sorted((r for r in os.listdir(d) if r.startswith("run_") and r[4:].isdigit()), key=lambda r: int(r[4:]))
     if runs:
         ori = np.load(os.path.join(d, runs[-1], "x_1.npy"))                                  # evaluation.py:304-314

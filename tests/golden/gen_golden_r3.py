@@ -68,6 +68,33 @@ def main():
                     out[f"{name}_rowsum_{key}"] = t.double().sum(dim=2)
     save("vae_long", **out)
 
+    # TS2Vec.fit (evaluate/ts2vec.py:73-160) as evaluation.py:238 configures it, on the CPU: per-iteration losses of the
+    # first 12 iterations under fixed seeds, the averaged encoder's full-series representations, and the FID they give
+    from evaluate.ts2vec import TS2Vec
+    assert sys.modules["evaluate.ts2vec"].__file__.startswith(REF + os.sep)
+    rs = np.random.RandomState(77)
+    tt = np.linspace(0, 1, 24)[None, :, None]
+    ori = (np.sin(2 * np.pi * (rs.uniform(1, 3, (24, 1, 1)) * tt + rs.uniform(0, 1, (24, 1, 1)))) * rs.uniform(0.3, 1, (24, 1, 1))
+           + 0.05 * rs.randn(24, 24, 1)).astype(np.float32)
+    gen = (ori + 0.15 * rs.randn(24, 24, 1)).astype(np.float32)
+    torch.manual_seed(7)
+    np.random.seed(7)
+    losses = []
+    m = TS2Vec(input_dims=1, device="cpu", batch_size=8, lr=0.001, output_dims=100, max_train_length=3000,
+               after_iter_callback=lambda model, loss: losses.append(loss))
+    log = m.fit(ori.copy(), n_iters=12, verbose=False)
+    r_ori = m.encode(ori.copy(), encoding_window="full_series")
+    r_gen = m.encode(gen.copy(), encoding_window="full_series")
+    # the default n_iters = 200 run evaluation.py performs: only its end state (loss of the last iterations)
+    torch.manual_seed(8)
+    np.random.seed(8)
+    losses200 = []
+    m2 = TS2Vec(input_dims=1, device="cpu", batch_size=8, lr=0.001, output_dims=100, max_train_length=3000,
+                after_iter_callback=lambda model, loss: losses200.append(loss))
+    m2.fit(ori.copy(), verbose=False)
+    save("ts2vec_fit", ori=ori, gen=gen, losses=np.asarray(losses), epoch_log=np.asarray(log), repr_ori=r_ori, repr_gen=r_gen,
+         losses200=np.asarray(losses200), n_iters200=np.asarray([m2.n_iters, m2.n_epochs]))
+
 
 if __name__ == "__main__":
     main()

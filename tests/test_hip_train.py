@@ -407,3 +407,4 @@ def test_drop_in_chain_vae_pickle_train_infer_metrics(dev, tmp_path, monkeypatch
     metrics.main([out])
     line = capsys.readouterr().out
     assert "MSE" in line and "WAPE" in line and "DTW" in line and "nan" not in line.lower(), line
+    assert "C-FID" in line and "200 iterations" in line, line      # TS2Vec trained + encoded on the GPU: C-FID from the .npy files alone
