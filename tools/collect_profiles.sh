@@ -11,7 +11,7 @@ mkdir -p $out
 git_rev=$(cat .git_rev 2>/dev/null || echo unknown)
 echo "== bench"; timeout -k 10 600 python bench.py --gpus 1 --steps 3 --warmup 1 > $out/${tag}_bench.json 2> $out/${tag}_bench.err || exit 1
 tail -c 400 $out/${tag}_bench.json; echo
-S="--gpus 1 --steps 1 --warmup 1 --no-cpu-baseline --no-alt-math --no-train"
+S="--gpus 1 --steps 1 --warmup 1 --no-cpu-baseline --no-alt-math --no-train --no-strong"
 echo "== rocprofv3 --kernel-trace --stats (sampling only, 1+1 batches; two sampler lanes = the default)"
 rm -rf /tmp/prof_$tag
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python3 bench.py $S > $out/${tag}_prof_bench.json 2> $out/${tag}_prof.err || exit 1
@@ -23,6 +23,14 @@ rm -rf /tmp/prof1_$tag
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1_$tag -- python3 bench.py $S --lanes 1 > $out/${tag}_prof_bench_lanes1.json 2> $out/${tag}_prof1.err || exit 1
 cp /tmp/prof1_$tag/*/*kernel_stats.csv $out/${tag}_kernel_stats_lanes1.csv
 head -8 $out/${tag}_kernel_stats_lanes1.csv
+
+# the 32-series shard of an 8-GPU strong-scaling run (256 series / 8): launch shapes of its own (16-token row chain, one
+# attention head per CU, one sampler lane)
+echo "== rocprofv3 --kernel-trace --stats, --batch 32 (strong-scaling shard)"
+rm -rf /tmp/prof32_$tag
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof32_$tag -- python3 bench.py $S --no-strong --batch 32 > $out/${tag}_prof_bench_b32.json 2> $out/${tag}_prof32.err || exit 1
+cp /tmp/prof32_$tag/*/*kernel_stats.csv $out/${tag}_kernel_stats_b32.csv
+head -8 $out/${tag}_kernel_stats_b32.csv
 
 agg_pmc() {   # <counter dir> <dst csv>: per kernel and counter, dispatches and the per-dispatch average
   python3 - "$1" "$2" <<'PY'

@@ -148,5 +148,22 @@ if os.path.exists(tb_path):
         tbs = uu * u_mb * 1e6 / (us * 1e-6) / 1e12
         lines.append("| `%s` | %s | %.1f | %.1f | %.2f | %.2f |" % (pat, what, uu, us, tbs, tbs / 8.0))
     lines.append("")
+# ---- strong-scaling shards (BASELINE's metric read literally: 256 series at 1/2/4/8 GPUs)
+ss = b.get("strong_shards")
+if ss:
+    lines += ["## Strong-scaling shards: the per-GPU share of a 256-series job, timed on this one GPU (`strong_shards` in the bench line)",
+              "", "| GPUs | series per GPU | series/s per GPU | ms per batch | predicted efficiency | predicted job rate (series/s) |",
+              "|---|---|---|---|---|---|",
+              f"| 1 | {b['config']['global_batch']} | {b['value']:.2f} | {b['ms_per_step']:.0f} | 1.000 | {b['value']:.1f} |"]
+    for n, r in sorted(ss["shards"].items(), key=lambda kv: -int(kv[0])):
+        w = str(r["gpus_for_256_total"])
+        lines.append(f"| {w} | {n} | {r['series_per_s']:.2f} | {r['ms_per_batch']:.0f} | {ss['predicted_strong_efficiency'][w]:.3f} | "
+                     f"{ss['predicted_strong_series_per_s'][w]:.1f} |")
+    lines += ["", "Sampling has no data-path collective (rows are independent, Philox keyed by the global row): N x rate(256 / N) is the N-GPU "
+              "rate up to launch skew between ranks.", ""]
+b32 = os.path.join(P, f"{tag}_kernel_stats_b32.csv")
+if os.path.exists(b32):
+    lines += ["### The 32-series shard under rocprofv3 (`bench.py --batch 32`, one lane, 16-token row chain, one attention head per CU)",
+              "", table(stats("kernel_stats_b32"), 9), ""]
 open(os.path.join(P, f"{tag}_summary.md"), "w").write("\n".join(lines))
 print("\n".join(lines[:16]))
