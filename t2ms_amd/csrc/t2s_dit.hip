@@ -104,19 +104,28 @@ __global__ void time_embedding_kernel(const float* __restrict__ t, const float* 
 // 32 outputs) tile = 64 MFMAs, the A operand (silu(c)) built straight in registers, the packed weights read from
 // L2 -- 384 waves at S = 64, 1536 at S = 512.  (The generic gemm_rows_kernel ran it as 8 workgroups of 384 MFMAs per
 // wave at S = 64: 29 us of a 690 us sampling step.)
+// table_rows > 0 (the sampler's whole-run table): row = j * table_rows + r is step j; r = 0 is the text-free branch, r > 0
+// adds text row r - 1 -- S = steps * table_rows rows, step_ptr unused.
 __global__ __launch_bounds__(256) void adaln_kernel(float* __restrict__ mod, const float* __restrict__ temb,
                                                     int temb_rows, const int* __restrict__ step_ptr,
                                                     const float* __restrict__ text, int uncond_rows, int S,
-                                                    const f32x4* __restrict__ Wp, const float* __restrict__ bias) {
+                                                    const f32x4* __restrict__ Wp, const float* __restrict__ bias,
+                                                    int table_rows) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, half = lane >> 5;
     const int nt = blockIdx.y * 4 + wave;                 // 32-output tile, 0..95
     const int row = blockIdx.x * 32 + j;
     const int rl = row < S ? row : S - 1;                 // clamped for the loads
-    const int trow = step_ptr ? *step_ptr : (temb_rows == 1 ? 0 : rl);
+    int trow, xrow;                                       // time-embedding row, text row (-1: none)
+    if (table_rows > 0) {
+        trow = rl / table_rows;
+        xrow = rl - trow * table_rows - 1;
+    } else {
+        trow = step_ptr ? *step_ptr : (temb_rows == 1 ? 0 : rl);
+        xrow = rl >= uncond_rows ? rl - uncond_rows : -1;
+    }
     const f32x4* tp = reinterpret_cast<const f32x4*>(temb + (size_t)trow * D) + half;
-    const f32x4* xp = rl >= uncond_rows ? reinterpret_cast<const f32x4*>(text + (size_t)(rl - uncond_rows) * D) + half
-                                        : nullptr;
+    const f32x4* xp = xrow >= 0 ? reinterpret_cast<const f32x4*>(text + (size_t)xrow * D) + half : nullptr;
     const f32x4* wp = Wp + (size_t)nt * 16 * 64 + lane;
     f32x4 a[16], b[16];
 #pragma unroll
@@ -283,9 +292,14 @@ int upload_weights(t2s_dit* h, const t2s_dit_weights* w, hipStream_t st) {
 // One DiT forward over S sequences (sequence s reads latent row s % B).
 // ws_seq0: first workspace slot (in sequences) this pass may use -- the sampler runs two half batches as independent
 // lanes on two streams, each in its own slice of the workspace (slots [ws_seq0, ws_seq0 + S))
+struct ModTable {          // the sampler's precomputed adaLN table (NULL base: compute this pass's rows here)
+    const float* base = nullptr;
+    int rows = 0, row0 = 0;
+};
+
 int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const float* temb,
                 int temb_rows, const int* step_ptr, const float* text, float* out0, float* out1,
-                int split, hipStream_t st, bool keep_stream = true, int ws_seq0 = 0) {
+                int split, hipStream_t st, bool keep_stream = true, int ws_seq0 = 0, ModTable mt = ModTable()) {
     int rc;
     const size_t tok0 = (size_t)ws_seq0 * NTOK * D;
     float* const w_h = h->h + tok0;
@@ -297,10 +311,12 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
     float* const w_mod = h->mod + (size_t)ws_seq0 * MODROW;
     __bf16* const w_k3 = h->k3 ? h->k3 + tok0 * 3 : nullptr;
     __bf16* const w_v3 = h->v3 ? h->v3 + tok0 * 3 : nullptr;
-    {   // adaLN for all 4 blocks at once: mod = silu(c) @ W_ada^T + b, c = t_emb (+ text)
+    const bool x3 = h->math == T2S_MATH_BF16X3;
+    const bool use_table = mt.base != nullptr && !x3 && step_ptr != nullptr;
+    if (!use_table) {   // adaLN for all 4 blocks at once: mod = silu(c) @ W_ada^T + b, c = t_emb (+ text)
         TimeScope ts(h, TC_OTHER, st);
         adaln_kernel<<<dim3((S + 31) / 32, MODROW / 128), 256, 0, st>>>(w_mod, temb, temb_rows, step_ptr, text,
-                                                                       uncond_rows, S, h->ada_p, h->ada_b);
+                                                                       uncond_rows, S, h->ada_p, h->ada_b, 0);
         T2S_LAUNCH_CHECK();
     }
     // patchify: the two branches of a CFG pass (S == 2B) see the same tokens, so only B sequences are
@@ -322,6 +338,7 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
     auto rows_args = [&](int blk, int qkv_blk) {
         RowArgs a{};
         a.x = w_h; a.ao = w_ao; a.mod = w_mod; a.M = M; a.blk = blk; a.qkv_blk = qkv_blk;
+        if (use_table) { a.mod = mt.base; a.mod_step = step_ptr; a.mod_rows = mt.rows; a.mod_uncond = uncond_rows; a.mod_row0 = mt.row0; }
         const bool first = blk <= 0 && qkv_blk <= 1;     // rows<qkv 0> and rows<block 0, qkv 1> read the patchified tokens
         a.x_in = first ? tokens : w_h; a.in_seqs = first ? in_seqs : S;
         if (blk == NBLK - 1) {   // the last kernel also runs the final layer
@@ -338,7 +355,6 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
     };
     // T2S_MATH_BF16X3: every product of the row chain and of the attention is evaluated as six bf16 MFMAs
     // (fp32-accurate, t2s_x3.h); k / V^T travel as split bf16 planes
-    const bool x3 = h->math == T2S_MATH_BF16X3;
     auto rows_args_x3 = [&](int blk, int qkv_blk) {
         RowArgsX3 a{};
         a.x = w_h; a.ao = w_ao; a.mod = w_mod; a.M = M; a.blk = blk; a.qkv_blk = qkv_blk;
@@ -400,9 +416,29 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
 // exported to the sampler TU
 namespace t2s {
 int dit_forward_cfg_step(t2s_dit* h, const float* x, const float* temb_table, const int* step_ptr,
-                         const float* text, float* out_u, float* out_c, int B, hipStream_t st, int ws_seq0) {
+                         const float* text, float* out_u, float* out_c, int B, hipStream_t st, int ws_seq0,
+                         const float* mod_table, int mod_rows, int mod_row0) {
+    ModTable mt;
+    mt.base = mod_table; mt.rows = mod_rows; mt.row0 = mod_row0;
     return run_forward(h, x, B, 2 * B, B, temb_table, 1, step_ptr, text, out_u, out_c, B, st, /*keep_stream=*/false,
-                       ws_seq0);
+                       ws_seq0, mt);
+}
+
+// The adaLN modulation of EVERY step of a sampling run in one launch: table (steps, B + 1, MODROW), row 0 of a step = the
+// text-free branch (identical for the whole batch), row 1 + b = batch row b.  It depends on the step's time embedding and
+// the text only, never on the state, so it need not sit on the loop's critical path (10 us of a 640 us step at 32 series):
+// 3.2 GB of the 288 GB at B = 256 / 1000 steps, computed in a few ms per run.  f32 arithmetic: the same MFMA order per
+// row as the per-step launch, i.e. the same bits.
+int dit_adaln_table(t2s_dit* h, const float* temb_table, int steps, const float* text, int B, float* table, hipStream_t st) {
+    const long long rows = (long long)steps * (B + 1);
+    if (rows <= 0 || rows > 0x7fffffffLL / 2) {
+        set_error("dit_adaln_table: %lld rows out of range", rows);
+        return T2S_E_INVALID;
+    }
+    adaln_kernel<<<dim3((unsigned)((rows + 31) / 32), MODROW / 128), 256, 0, st>>>(table, temb_table, steps, nullptr, text, 0,
+                                                                                  (int)rows, h->ada_p, h->ada_b, B + 1);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
 }
 }  // namespace t2s
 
@@ -558,7 +594,7 @@ int t2s_dit_forward_cfg(t2s_dit* h, const float* x, const float* temb, const flo
     T2S_REQUIRE(B > 0 && 2 * B <= h->max_seqs, "t2s_dit_forward_cfg: 2*B=%d exceeds max_seqs=%d", 2 * B,
                 h->max_seqs);
     return t2s::dit_forward_cfg_step(h, x, temb, nullptr, text, out_uncond, out_cond, B,
-                                     (hipStream_t)stream, 0);
+                                     (hipStream_t)stream, 0, nullptr, 0, 0);
 }
 
 int t2s_dit_timing_begin(t2s_dit* h) {

@@ -70,7 +70,11 @@ struct RowArgs {
     float *out0, *out1;
     int split, keep_x;
     const float* ao;   // (M,128) attention output (pre-proj), fragment-major
-    const float* mod;  // (S,MODROW)
+    const float* mod;  // (S,MODROW) adaLN modulation of this pass -- or, when mod_step != NULL, the sampler's table
+    // (steps, mod_rows, MODROW) of the WHOLE run (t2s_sampler.hip: row 0 of a step = the text-free branch, row 1 + b = batch
+    // row b): sequence s of this pass reads step *mod_step, row 0 if s < mod_uncond, else 1 + mod_row0 + (s - mod_uncond)
+    const int* mod_step;
+    int mod_rows, mod_uncond, mod_row0;
     int M;             // S*480 (multiple of 32)
     int blk;           // block whose proj+MLP run (ignored if !DO_MLP)
     int qkv_blk;       // block whose LN1/modulate/qkv run (ignored if !DO_QKV)
@@ -78,6 +82,12 @@ struct RowArgs {
     const float *bp, *b1, *b2, *bq;
     float *q, *k, *v;  // per head (S*4, 480, 32): q, k fragment-major; v TRANSPOSED fragment-major (V^T)
 };
+
+__device__ __forceinline__ const float* mod_row_of(const RowArgs& a, int seq) {
+    if (a.mod_step == nullptr) return a.mod + (size_t)seq * MODROW;
+    const int r = seq < a.mod_uncond ? 0 : 1 + a.mod_row0 + (seq - a.mod_uncond);
+    return a.mod + ((size_t)(*a.mod_step) * a.mod_rows + r) * MODROW;
+}
 
 // GELU(tanh): 0.5 x (1 + tanh(u)) == x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3).
 // On gfx950 the f32 MFMA shares the VALU lanes, so every VALU instruction here is paid in matrix
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
     const bool active = tile < n_tiles;           // tail waves compute on a clamped tile, store nothing
     if (!active) tile = n_tiles - 1;
     const int seq = (tile * 32) / NTOK;           // 480 = 15*32: a tile never straddles sequences
-    const float* __restrict__ modrow = a.mod + (size_t)seq * MODROW;
+    const float* __restrict__ modrow = mod_row_of(a, seq);
 
     constexpr int N_CHUNKS = (DO_MLP ? 20 : 0) + (DO_QKV ? 12 : 0);
     auto chunk_src = [&](int ci) -> const f32x4* {

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows16_kernel(const RowArgs a) {
     const int tile = t16 >> 1, row = 16 * (t16 & 1) + tok;
     const int seq = (tile * 32) / NTOK;
     const int tile_in_seq = tile - seq * (NTOK / 32);
-    const float* __restrict__ modrow = a.mod + (size_t)seq * MODROW;
+    const float* __restrict__ modrow = mod_row_of(a, seq);
 
     constexpr int N_CHUNKS = (DO_MLP ? 20 : 0) + 12;
     auto chunk_src = [&](int ci) -> const f32x4* {

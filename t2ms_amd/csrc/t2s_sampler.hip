@@ -16,7 +16,9 @@ struct t2s_vae;
 
 namespace t2s {
 int dit_forward_cfg_step(t2s_dit* h, const float* x, const float* temb_table, const int* step_ptr,
-                         const float* text, float* out_u, float* out_c, int B, hipStream_t st, int ws_seq0);
+                         const float* text, float* out_u, float* out_c, int B, hipStream_t st, int ws_seq0,
+                         const float* mod_table, int mod_rows, int mod_row0);
+int dit_adaln_table(t2s_dit* h, const float* temb_table, int steps, const float* text, int B, float* table, hipStream_t st);
 
 // ---------------------------------------------------------------- Philox4x32-10 + Box-Muller
 struct u32x4 { uint32_t x, y, z, w; };
@@ -353,6 +355,7 @@ struct t2s_sampler {
     float* eps_u = nullptr;       // (B,1920)
     float* eps_c = nullptr;
     float* tvals = nullptr;       // (steps)
+    float* mod_table = nullptr;   // (steps, batch + 1, 3072): the adaLN modulation of every step, refreshed at the start of a run
     int* step = nullptr;          // device loop indices, one per lane (16 ints apart)
     // Lanes: the rows of the batch are independent through the whole loop, so the batch can run as TWO half
     // batches, each a complete chain (own step counter, own hipGraph, own slice of the DiT workspace) on its own
@@ -385,7 +388,8 @@ int enqueue_step(t2s_sampler* s, float* x, const float* text, const float* noise
     float* xl = x + (size_t)r0 * LAT;
     float* eu = s->eps_u + (size_t)r0 * LAT;
     float* ec = s->eps_c + (size_t)r0 * LAT;
-    int rc = dit_forward_cfg_step(s->dit, xl, s->temb_table, step, text + (size_t)r0 * D, eu, ec, n, st, 2 * r0);
+    int rc = dit_forward_cfg_step(s->dit, xl, s->temb_table, step, text + (size_t)r0 * D, eu, ec, n, st, 2 * r0,
+                                  s->mod_table, c.batch + 1, r0);
     if (rc != T2S_OK) return rc;
     if (c.mode == T2S_MODE_DDPM) {
         StepArgs a{};
@@ -448,6 +452,9 @@ extern "C" int t2s_sampler_create(t2s_dit* dit, t2s_vae* vae, const t2s_sample_c
     alloc((void**)&s->eps_c, B * LAT * sizeof(float));
     alloc((void**)&s->tvals, T * sizeof(float));
     alloc((void**)&s->step, 2 * 16 * sizeof(int));   // one counter per lane, 64 B apart
+    // whole-run adaLN table (dit_adaln_table): up to 16 GB of the 288 GB; beyond that the per-step kernel stays in the loop
+    const size_t table_bytes = T * (B + 1) * (size_t)MODROW * sizeof(float);
+    if (table_bytes <= ((size_t)16 << 30)) alloc((void**)&s->mod_table, table_bytes);
     if (e == hipSuccess) e = hipMemcpy(s->tvals, cfg->t_values, T * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess && cfg->mode == T2S_MODE_DDPM)
         e = hipMemcpy(s->coef, cfg->ddpm_coef, T * 3 * sizeof(float), hipMemcpyHostToDevice);
@@ -493,7 +500,7 @@ extern "C" void t2s_sampler_destroy(t2s_sampler* s) {
     if (s->own) (void)hipStreamDestroy(s->own);
     if (s->ev_in) (void)hipEventDestroy(s->ev_in);
     if (s->ev_out) (void)hipEventDestroy(s->ev_out);
-    void* bufs[] = {s->temb_table, s->coef, s->eps_u, s->eps_c, s->tvals, s->step};
+    void* bufs[] = {s->temb_table, s->coef, s->eps_u, s->eps_c, s->tvals, s->step, s->mod_table};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     delete s;
@@ -560,6 +567,8 @@ extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, cons
         s->lanes_cap = lanes;
         s->g_x = x; s->g_text = text; s->g_noise = noise;
     }
+    // the adaLN modulation of every step for this run's text (state-independent: off the loop's critical path)
+    if (s->mod_table && (rc = dit_adaln_table(s->dit, s->temb_table, c.steps, text, c.batch, s->mod_table, st)) != T2S_OK) return rc;
     if (lanes == 2) {   // fork: lane 1 starts after everything already queued on the caller's stream
         T2S_HIP_CHECK(hipEventRecord(s->ev_fork, st));
         T2S_HIP_CHECK(hipStreamWaitEvent(s->side, s->ev_fork, 0));
