@@ -325,7 +325,11 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
     const bool shared_in = S == 2 * B;
     float* tokens = shared_in ? w_h0 : w_h;
     const int in_seqs = shared_in ? B : S;
-    {
+    // f32 path: the <qkv only> row kernel of block 0 patchifies in its prologue (t2s_rows.h) and writes the tokens for
+    // block 0's <proj + MLP> kernel; the stand-alone launch remains for the bf16x3 kernels.  T2S_PATCHIFY_KERNEL=1: A/B.
+    static const bool patch_launch = getenv("T2S_PATCHIFY_KERNEL") && atoi(getenv("T2S_PATCHIFY_KERNEL")) != 0;
+    const bool patch_fused = h->math != T2S_MATH_BF16X3 && !patch_launch;
+    if (!patch_fused) {
         const int threads = in_seqs * NTOK * 32;
         TimeScope ts(h, TC_OTHER, st);
         patchify_kernel<<<(threads + 255) / 256, 256, 0, st>>>(x, B, tokens, in_seqs, h->conv_w, h->conv_b,
@@ -339,6 +343,9 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
         RowArgs a{};
         a.x = w_h; a.ao = w_ao; a.mod = w_mod; a.M = M; a.blk = blk; a.qkv_blk = qkv_blk;
         if (use_table) { a.mod = mt.base; a.mod_step = step_ptr; a.mod_rows = mt.rows; a.mod_uncond = uncond_rows; a.mod_row0 = mt.row0; }
+        if (blk < 0 && patch_fused) {
+            a.p_lat = x; a.p_B = B; a.p_cw = h->conv_w; a.p_cb = h->conv_b; a.p_pw = h->patch_w; a.p_pb = h->patch_b; a.p_pos = h->pos;
+        }
         const bool first = blk <= 0 && qkv_blk <= 1;     // rows<qkv 0> and rows<block 0, qkv 1> read the patchified tokens
         a.x_in = first ? tokens : w_h; a.in_seqs = first ? in_seqs : S;
         if (blk == NBLK - 1) {   // the last kernel also runs the final layer

@@ -69,6 +69,13 @@ struct RowArgs {
     const float *f_lnw, *f_lnb, *f_ow, *f_ob;
     float *out0, *out1;
     int split, keep_x;
+    // <qkv only> kernels (block 0's LayerNorm + qkv): when p_lat != NULL the tokens are not read from x_in but GENERATED
+    // from the latent (patchify, transformer.py:166-172: conv 2x2 stride 2 -> Linear 4 -> 128, + pos_embed) and, for the
+    // in_seqs distinct sequences, written to x_in's buffer for block 0's <proj + MLP> kernel -- the stand-alone patchify
+    // launch (and one read of its output) leaves the sampling loop's critical path
+    const float* p_lat;   // (p_B, 64, 30); sequence s reads latent row s % p_B
+    int p_B;
+    const float *p_cw, *p_cb, *p_pw, *p_pb, *p_pos;   // conv.weight (4,1,2,2) / bias (4), patch_emb.weight (128,4) / bias, pos_embed (480,128)
     const float* ao;   // (M,128) attention output (pre-proj), fragment-major
     const float* mod;  // (S,MODROW) adaLN modulation of this pass -- or, when mod_step != NULL, the sampler's table
     // (steps, mod_rows, MODROW) of the WHOLE run (t2s_sampler.hip: row 0 of a step = the text-free branch, row 1 + b = batch
@@ -82,6 +89,32 @@ struct RowArgs {
     const float *bp, *b1, *b2, *bq;
     float *q, *k, *v;  // per head (S*4, 480, 32): q, k fragment-major; v TRANSPOSED fragment-major (V^T)
 };
+
+// patchify of one token (shared by the 32- and the 16-token kernel: the same expression, hence the same bits)
+__device__ __forceinline__ void patch_conv(const RowArgs& a, int seq, int n, float (&cv)[4]) {
+    const int hh = n >> 5, ww = n & 31;
+    const float* xin = a.p_lat + (size_t)(seq % a.p_B) * LAT;
+    float px[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) px[i * 2 + j] = xin[(2 * ww + j) * LATW + 2 * hh + i];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float acc = a.p_cw[c * 4 + 0] * px[0];
+        acc = __builtin_fmaf(a.p_cw[c * 4 + 1], px[1], acc);
+        acc = __builtin_fmaf(a.p_cw[c * 4 + 2], px[2], acc);
+        acc = __builtin_fmaf(a.p_cw[c * 4 + 3], px[3], acc);
+        cv[c] = acc + a.p_cb[c];
+    }
+}
+__device__ __forceinline__ float patch_feature(const float (&cv)[4], f32x4 w, float pb, float pos) {
+    float acc = w.x * cv[0];
+    acc = __builtin_fmaf(w.y, cv[1], acc);
+    acc = __builtin_fmaf(w.z, cv[2], acc);
+    acc = __builtin_fmaf(w.w, cv[3], acc);
+    return (acc + pb) + pos;
+}
 
 __device__ __forceinline__ const float* mod_row_of(const RowArgs& a, int seq) {
     if (a.mod_step == nullptr) return a.mod + (size_t)seq * MODROW;
@@ -302,8 +335,42 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
 
     // residual stream of this lane's token, accumulator layout: x[nt][4g+e] = X[row][32nt+8g+4half+e]
     f32x16 x[4];
-    {
-        const int tile_src = tile - (seq - seq % a.in_seqs) * (NTOK / 32);   // same tile of sequence seq % in_seqs
+    const int tile_src = tile - (seq - seq % a.in_seqs) * (NTOK / 32);   // same tile of sequence seq % in_seqs
+    bool generated = false;
+    if constexpr (!DO_MLP) {
+        if (a.p_lat != nullptr) {
+            // patchify in the prologue: patch_emb weight in the (unused) proj / MLP bias slots of LDS, bias in the wave's
+            // (unused) MLP adaLN slots; visible after this barrier (chunk 0 is waited for again further down)
+            for (int i = threadIdx.x; i < 512; i += 64 * ROWS_NW) cb[i] = a.p_pw[i];
+            *reinterpret_cast<f32x4*>(cm + 256 + (lane & 31) * 4) = *reinterpret_cast<const f32x4*>(a.p_pb + (lane & 31) * 4);
+            __syncthreads();
+            const int n = (tile - seq * (NTOK / 32)) * 32 + (lane & 31);
+            float cv[4];
+            patch_conv(a, seq, n, cv);
+            const float* posrow = a.p_pos + (size_t)n * D;
+#pragma unroll
+            for (int G = 0; G < 16; ++G) {
+                const int d0 = 8 * G + 4 * half;
+                const f32x4 pos4 = *reinterpret_cast<const f32x4*>(posrow + d0);
+                const f32x4 pb4 = *reinterpret_cast<const f32x4*>(cm + 256 + d0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    x[G >> 2][4 * (G & 3) + e] = patch_feature(cv, *reinterpret_cast<const f32x4*>(cb + (d0 + e) * 4), pb4[e], pos4[e]);
+            }
+            if (active && seq < a.in_seqs) {   // block 0's <proj + MLP> kernel reads the tokens of sequence s % in_seqs
+                f32x4* xo = const_cast<f32x4*>(reinterpret_cast<const f32x4*>(a.x_in)) + (size_t)tile_src * 16 * 64 + lane;
+#pragma unroll
+                for (int G = 0; G < 16; ++G) {
+                    f32x4 t;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = x[G >> 2][4 * (G & 3) + e];
+                    xo[G * 64] = t;
+                }
+            }
+            generated = true;
+        }
+    }
+    if (!generated) {
         const f32x4* xr = reinterpret_cast<const f32x4*>(a.x_in) + (size_t)tile_src * 16 * 64 + lane;
 #pragma unroll
         for (int G = 0; G < 16; ++G) {

@@ -231,10 +231,39 @@ __global__ __launch_bounds__(256, 2) void dit_rows16_kernel(const RowArgs a) {
 
     // residual stream of this lane's token
     f32x4 x[8];
-    {
-        const int tile_src = tile - (seq - seq % a.in_seqs) * (NTOK / 32);   // same tile of sequence seq % in_seqs
-        load_rows16<8>(reinterpret_cast<const f32x4*>(a.x_in) + (size_t)tile_src * 16 * 64, h, q, row, x);
+    const int tile_src = tile - (seq - seq % a.in_seqs) * (NTOK / 32);   // same tile of sequence seq % in_seqs
+    bool generated = false;
+    if constexpr (!DO_MLP) {
+        if (a.p_lat != nullptr) {
+            // patchify in the prologue (see t2s_rows.h): patch_emb weight in the unused proj / MLP bias slots, bias in the
+            // wave's unused MLP adaLN slots, natural feature order
+            for (int i = threadIdx.x; i < 512; i += 256) cb[i] = a.p_pw[i];
+            *reinterpret_cast<f32x4*>(cm + 256 + (lane & 31) * 4) = *reinterpret_cast<const f32x4*>(a.p_pb + (lane & 31) * 4);
+            __syncthreads();
+            const int n = tile_in_seq * 32 + row;
+            float cv[4];
+            patch_conv(a, seq, n, cv);
+            const float* posrow = a.p_pos + (size_t)n * D;
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                // features 16 mt + pi16(g, r) = 16 mt + 4 h + q + {0, 2, 8, 10}
+                const f32x4 pa = *reinterpret_cast<const f32x4*>(posrow + 16 * mt + 4 * h);
+                const f32x4 pc = *reinterpret_cast<const f32x4*>(posrow + 16 * mt + 8 + 4 * h);
+                const f32x4 ba = *reinterpret_cast<const f32x4*>(cm + 256 + 16 * mt + 4 * h);
+                const f32x4 bc = *reinterpret_cast<const f32x4*>(cm + 256 + 16 * mt + 8 + 4 * h);
+                const int d0 = 16 * mt + 4 * h + q;
+                x[mt][0] = patch_feature(cv, *reinterpret_cast<const f32x4*>(cb + (d0 + 0) * 4), q ? ba[1] : ba[0], q ? pa[1] : pa[0]);
+                x[mt][1] = patch_feature(cv, *reinterpret_cast<const f32x4*>(cb + (d0 + 2) * 4), q ? ba[3] : ba[2], q ? pa[3] : pa[2]);
+                x[mt][2] = patch_feature(cv, *reinterpret_cast<const f32x4*>(cb + (d0 + 8) * 4), q ? bc[1] : bc[0], q ? pc[1] : pc[0]);
+                x[mt][3] = patch_feature(cv, *reinterpret_cast<const f32x4*>(cb + (d0 + 10) * 4), q ? bc[3] : bc[2], q ? pc[3] : pc[2]);
+            }
+            // every lane takes part in the stores' lane exchange; only tokens of the distinct sequences are written
+            if (active && seq < a.in_seqs)
+                store_rows16<8>(const_cast<f32x4*>(reinterpret_cast<const f32x4*>(a.x_in)) + (size_t)tile_src * 16 * 64, h, q, row, x);
+            generated = true;
+        }
     }
+    if (!generated) load_rows16<8>(reinterpret_cast<const f32x4*>(a.x_in) + (size_t)tile_src * 16 * 64, h, q, row, x);
     int ci = 0;
 
     if constexpr (DO_MLP) {
