@@ -10,13 +10,16 @@ One "step" = one pass of the hot path over one batch: x_T (Philox, on device) ->
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Multi-GPU = weak scaling: every rank samples its own 256-series shard (global rows
-[256*rank, 256*rank+256) of the Philox stream); no data-path collective, RCCL only for the
-barrier and the max-over-ranks time.
+Multi-GPU: `value` is WEAK scaling -- every rank samples its own 256-series shard (global rows [256*rank, 256*rank+256) of
+the Philox stream); no data-path collective, RCCL only for the barrier and the max-over-ranks time.  BASELINE's metric read
+literally is STRONG scaling (256 series at 1/2/4/8 GPUs), so the line also carries
+  * at N = 1: `strong_shards` -- the per-GPU share of that job (128 / 64 / 32 series) timed on this GPU, with the predicted
+    strong efficiency rate(256/N) / rate(256) (no collective: N x rate(256/N) is the N-GPU rate);
+  * at N > 1: `strong` -- the same 256 series split over the ranks (their union equals the one-GPU batch bit for bit).
 
 The same JSON line carries, as extra keys: `roofline` (dominant kernel, in-situ HIP-event timing), `cpu_baseline` (the
-oracle on the host cores, N=1 only), `alt_math` (the opt-in bf16x3 arithmetic, N=1 only) and `train` (BASELINE
-configs[3] shape: the bf16 DiT training step of train.py at B=1152 per GPU with the gradient all-reduce at N>1).
+oracle on the host cores, N=1 only: 3 warm + 10 measured CFG steps), `alt_math` (the opt-in bf16x3 arithmetic, N=1 only) and
+`train` (BASELINE configs[3] shape: the bf16 DiT training step of train.py at B=1152 per GPU with the gradient all-reduce at N>1).
 """
 import argparse
 import json

@@ -103,21 +103,23 @@ __device__ __forceinline__ void advance_step_when_last(int* step) {
     }
 }
 
+// Grid-stride over the quads with at most STEP_MAX_WGS workgroups: the arrival counter is ONE address, and same-address
+// atomics serialise at ~25 ns each -- 480 of them (one per 256 quads at B = 256) made this 6 us kernel 18 us.
+constexpr int STEP_MAX_WGS = 96;
 __global__ __launch_bounds__(256) void ddpm_step_kernel(const StepArgs a) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one float4 (quad) per thread
     constexpr int QPR = LAT / 4;
-    if (idx < a.B * QPR) {
-        int t = a.t_index;
-        uint32_t sid = a.stream_id, row0 = a.row0;
-        const float* noise = a.noise;
-        if (a.step_ptr) {
-            const int j = a.step_ptr[0];
-            row0 = (uint32_t)a.step_ptr[1];   // read on the device so a captured graph serves every shard position
-            t = a.steps - 1 - j;
-            sid = (uint32_t)j;
-            if (noise) noise += (size_t)j * a.noise_rows * LAT;
-        }
-        const float c0 = a.coef[t * 3 + 0], c1 = a.coef[t * 3 + 1], c2 = a.coef[t * 3 + 2];
+    int t = a.t_index;
+    uint32_t sid = a.stream_id, row0 = a.row0;
+    const float* noise = a.noise;
+    if (a.step_ptr) {
+        const int j = a.step_ptr[0];
+        row0 = (uint32_t)a.step_ptr[1];   // read on the device so a captured graph serves every shard position
+        t = a.steps - 1 - j;
+        sid = (uint32_t)j;
+        if (noise) noise += (size_t)j * a.noise_rows * LAT;
+    }
+    const float c0 = a.coef[t * 3 + 0], c1 = a.coef[t * 3 + 1], c2 = a.coef[t * 3 + 2];
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < a.B * QPR; idx += gridDim.x * blockDim.x) {  // one float4 (quad) at a time
         const f32x4 x = reinterpret_cast<const f32x4*>(a.x)[idx];
         const f32x4 u = reinterpret_cast<const f32x4*>(a.eps_u)[idx];
         f32x4 pred = u;
@@ -141,8 +143,7 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const StepArgs a) {
 __global__ __launch_bounds__(256) void rf_step_kernel(float* __restrict__ x, const float* __restrict__ vu,
                                                       const float* __restrict__ vc, float cfg, float dt,
                                                       int n4, int* advance) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < n4) {
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += gridDim.x * blockDim.x) {
         const f32x4 u = reinterpret_cast<const f32x4*>(vu)[idx];
         f32x4 pred = u;
         if (vc) pred = u + cfg * (reinterpret_cast<const f32x4*>(vc)[idx] - u);
@@ -396,11 +397,11 @@ int enqueue_step(t2s_sampler* s, float* x, const float* text, const float* noise
         a.x = xl; a.eps_u = eu; a.eps_c = ec; a.noise = noise ? noise + (size_t)r0 * LAT : nullptr; a.coef = s->coef;
         a.step_ptr = step; a.steps = c.steps; a.cfg = c.cfg_scale; a.seed = c.seed; a.row0 = c.row0 + (uint32_t)r0;
         a.B = n; a.noise_rows = c.batch; a.advance = step;
-        const int total = n * (LAT / 4);
-        ddpm_step_kernel<<<(total + 255) / 256, 256, 0, st>>>(a);
+        const int total = n * (LAT / 4), wgs = (total + 255) / 256;
+        ddpm_step_kernel<<<wgs < STEP_MAX_WGS ? wgs : STEP_MAX_WGS, 256, 0, st>>>(a);
     } else {
-        const int n4 = n * (LAT / 4);
-        rf_step_kernel<<<(n4 + 255) / 256, 256, 0, st>>>(xl, eu, ec, c.cfg_scale, 1.0f / (float)c.steps, n4, step);
+        const int n4 = n * (LAT / 4), wgs = (n4 + 255) / 256;
+        rf_step_kernel<<<wgs < STEP_MAX_WGS ? wgs : STEP_MAX_WGS, 256, 0, st>>>(xl, eu, ec, c.cfg_scale, 1.0f / (float)c.steps, n4, step);
     }
     T2S_LAUNCH_CHECK();   // (the update kernel's last workgroup advanced the lane's loop index)
     return T2S_OK;
