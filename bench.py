@@ -504,7 +504,7 @@ def main():
                                      "per-launch durations there are not a kernel property, the pipelined figure is "
                                      "whole_path_frac_of_fp32_mfma_peak"}
         out["kernel_breakdown_us"] = {"attention_x4": kt["attn_us"], "row_chain_x5": kt["rows_us"],
-                                      "other_x4": kt["other_us"], "forward_total": kt["forward_us"]}
+                                      "other_x1_adaln": kt["other_us"], "forward_total": kt["forward_us"]}
         # whole-step figure for context: all DiT FLOPs / wall time
         step_flops = FLOP_FORWARD_PER_SEQ * 2 * B * args.diffusion_steps * args.steps
         out["whole_path_tflops"] = step_flops / elapsed / 1e12
