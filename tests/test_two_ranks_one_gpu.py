@@ -167,5 +167,8 @@ def test_bench_two_ranks_prints_one_json_line(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["value"] > 0
     assert out["scaling"] == "weak" and out["steps"] == 1
+    # strong scaling next to it: the same 64 series split over the two ranks (32 each)
+    st = out["strong"]
+    assert st["scaling"] == "strong" and st["global_batch"] == 64 and st["per_gpu_batch"] == 32 and st["value"] > 0
     tr = out["train"]                 # the training leg ran on both ranks with the gradient all-reduce in it
     assert tr["global_batch"] == 64 and tr["value"] > 0 and 0.0 <= tr["allreduce_share"] < 1.0 and np.isfinite(tr["loss"])
