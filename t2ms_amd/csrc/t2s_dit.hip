@@ -312,7 +312,7 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
     __bf16* const w_k3 = h->k3 ? h->k3 + tok0 * 3 : nullptr;
     __bf16* const w_v3 = h->v3 ? h->v3 + tok0 * 3 : nullptr;
     const bool x3 = h->math == T2S_MATH_BF16X3;
-    const bool use_table = mt.base != nullptr && !x3 && step_ptr != nullptr;
+    const bool use_table = mt.base != nullptr && step_ptr != nullptr;
     if (!use_table) {   // adaLN for all 4 blocks at once: mod = silu(c) @ W_ada^T + b, c = t_emb (+ text)
         TimeScope ts(h, TC_OTHER, st);
         adaln_kernel<<<dim3((S + 31) / 32, MODROW / 128), 256, 0, st>>>(w_mod, temb, temb_rows, step_ptr, text,
@@ -365,6 +365,7 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
     auto rows_args_x3 = [&](int blk, int qkv_blk) {
         RowArgsX3 a{};
         a.x = w_h; a.ao = w_ao; a.mod = w_mod; a.M = M; a.blk = blk; a.qkv_blk = qkv_blk;
+        if (use_table) { a.mod = mt.base; a.mod_step = step_ptr; a.mod_rows = mt.rows; a.mod_uncond = uncond_rows; a.mod_row0 = mt.row0; }
         const bool first = blk <= 0 && qkv_blk <= 1;
         a.x_in = first ? tokens : w_h; a.in_seqs = first ? in_seqs : S;
         if (blk == NBLK - 1) {

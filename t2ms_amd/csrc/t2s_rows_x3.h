@@ -37,7 +37,9 @@ struct RowArgsX3 {
     float *out0, *out1;
     int split, keep_x;
     const float* ao;   // (M,128) attention output (pre-proj), fragment-major
-    const float* mod;  // (S,MODROW)
+    const float* mod;  // (S,MODROW), or the sampler's whole-run table when mod_step != NULL (see RowArgs, t2s_rows.h)
+    const int* mod_step;
+    int mod_rows, mod_uncond, mod_row0;
     int M;
     int blk;
     int qkv_blk;
@@ -106,6 +108,8 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
     if (!active) tile = n_tiles - 1;
     const int seq = (tile * 32) / NTOK;           // 480 = 15*32: a tile never straddles sequences
     const float* __restrict__ modrow = a.mod + (size_t)seq * MODROW;
+    if (a.mod_step != nullptr)      // (spelled out here: a helper without this kernel's target attribute would not inline)
+        modrow = a.mod + ((size_t)(*a.mod_step) * a.mod_rows + (seq < a.mod_uncond ? 0 : 1 + a.mod_row0 + (seq - a.mod_uncond))) * MODROW;
 
     constexpr int N_CHUNKS = (DO_MLP ? 20 : 0) + (DO_QKV ? 12 : 0);
     auto chunk_src = [&](int ci) T2S_X3_KERNEL -> const bf16x8* {
