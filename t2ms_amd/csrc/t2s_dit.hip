@@ -384,7 +384,7 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
     // Small launches run the row chain on 16-token tiles (t2s_rows16.h; bit-identical results): up to 100 sequences, i.e.
     // where the 32-token kernel has fewer than ~1.5 waves per SIMD.  Same-box series/s, 16- vs 32-token tiles: 8 series
     // (16 sequences) +27 %, 16 +25 %, 24 +1 %, 32 (the 8-GPU strong-scaling shard) +1.2 %, 40 +7.5 %, 48 +7.7 %, 64 -2 %
-    // (profiles/r03_rows16_ab.txt).  The last block's kernel (fused final layer) stays on 32-token tiles.
+    // (profiles/r03_rows16_ab.txt; measured with the last block's kernel still on 32-token tiles).
     // T2S_ROWS16_MAX_SEQS moves the switch point (A/B runs; 0 = never).
     static const int rows16_max = getenv("T2S_ROWS16_MAX_SEQS") ? atoi(getenv("T2S_ROWS16_MAX_SEQS")) : 100;
     const bool use16 = !x3 && S <= rows16_max;
@@ -412,7 +412,8 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
             rc = x3 ? launch_dit_rows_x3<true, true>(rows_args_x3(i, i + 1), st)
                     : (use16 ? launch_dit_rows16<true, true>(rows_args16(i, i + 1), st) : launch_dit_rows<true, true>(rows_args(i, i + 1), st));
         else
-            rc = x3 ? launch_dit_rows_x3<true, false>(rows_args_x3(i, -1), st) : launch_dit_rows<true, false>(rows_args(i, -1), st);
+            rc = x3 ? launch_dit_rows_x3<true, false>(rows_args_x3(i, -1), st)
+                    : (use16 ? launch_dit_rows16<true, false>(rows_args16(i, -1), st) : launch_dit_rows<true, false>(rows_args(i, -1), st));
         if (rc != T2S_OK) return rc;
     }
     // (the final layer -- LayerNorm, Linear 128 -> 4, unpatchify -- ran inside the last row kernel)

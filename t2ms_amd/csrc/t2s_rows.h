@@ -152,11 +152,12 @@ __device__ __forceinline__ float ln_y(float x, float mean, float rstd, float sc,
     return __builtin_fmaf((x - mean) * rstd, 1.0f + sc, sh);
 }
 __device__ __forceinline__ float ln_rstd(float ss_total, float eps) { return rsqrtf(ss_total * (1.0f / 128.0f) + eps); }
+__device__ __forceinline__ float ln_affine(float x, float mean, float rstd, float gam, float bet) {   // final LayerNorm (affine)
+    return __builtin_fmaf((x - mean) * rstd, gam, bet);
+}
 
-// LayerNorm (no affine, eps) + modulate over the 128 features a lane pair holds
-__device__ __forceinline__ void ln_modulate(const f32x16 (&x)[4], f32x16 (&y)[4],
-                                            const float* __restrict__ shift,
-                                            const float* __restrict__ scale, int half, float eps) {
+// mean and 1/std over the 128 features a lane pair holds (32-token layout), in the shared reduction tree
+__device__ __forceinline__ void ln_mean_rstd32(const f32x16 (&x)[4], float eps, float& mean, float& rstd) {
     float s0 = 0.f, s1 = 0.f;                       // P_half (e = 0, 2) and P_{half+2} (e = 1, 3)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -169,7 +170,7 @@ __device__ __forceinline__ void ln_modulate(const f32x16 (&x)[4], f32x16 (&y)[4]
         }
     float s = s0 + s1;
     s += xhalf(s);
-    const float mean = s * (1.0f / 128.0f);
+    mean = s * (1.0f / 128.0f);
     float q0 = 0.f, q1 = 0.f;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -184,7 +185,15 @@ __device__ __forceinline__ void ln_modulate(const f32x16 (&x)[4], f32x16 (&y)[4]
         }
     float ss = q0 + q1;
     ss += xhalf(ss);
-    const float rstd = ln_rstd(ss, eps);
+    rstd = ln_rstd(ss, eps);
+}
+
+// LayerNorm (no affine, eps) + modulate over the 128 features a lane pair holds
+__device__ __forceinline__ void ln_modulate(const f32x16 (&x)[4], f32x16 (&y)[4],
+                                            const float* __restrict__ shift,
+                                            const float* __restrict__ scale, int half, float eps) {
+    float mean, rstd;
+    ln_mean_rstd32(x, eps, mean, rstd);
     // The second pass recomputes x - mean from x: hipcc otherwise keeps the 64 differences of the variance pass alive
     // next to x and y (192 registers) and spills some of them -- and every scratch reload waits vmcnt(0), draining
     // the weight DMA and the parking stores.  The empty asm makes `mean` opaque so the subtraction is not CSE'd.
@@ -522,27 +531,11 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
     // 128 features, so everything is lane-local up to one cross-half add per output
     if constexpr (DO_MLP && !DO_QKV) {
         if (a.out0 != nullptr) {
-            float s1 = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    s1 += (x[nt][4 * g] + x[nt][4 * g + 1]) + (x[nt][4 * g + 2] + x[nt][4 * g + 3]);
-            s1 += xhalf(s1);
-            const float mean = s1 * (1.0f / 128.0f);
-            float s2 = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[nt][4 * g + e] -= mean;
-                    s2 += (x[nt][4 * g] * x[nt][4 * g] + x[nt][4 * g + 1] * x[nt][4 * g + 1]) +
-                          (x[nt][4 * g + 2] * x[nt][4 * g + 2] + x[nt][4 * g + 3] * x[nt][4 * g + 3]);
-                }
-            s2 += xhalf(s2);
-            const float rstd = rsqrtf(s2 * (1.0f / 128.0f) + 1e-5f);
-            float fa[4] = {0.f, 0.f, 0.f, 0.f};
+            float mean, rstd;
+            ln_mean_rstd32(x, 1e-5f, mean, rstd);
+            // four dot products over the token's 128 features, in the shared reduction tree: partial fe over the lane's
+            // elements e = 0, 2 (feature group P_half), fo over e = 1, 3 (P_{half+2}), each in ascending feature order
+            float fe[4] = {0.f, 0.f, 0.f, 0.f}, fo[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -552,15 +545,21 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
                     const f32x4 bet = *reinterpret_cast<const f32x4*>(a.f_lnb + col);
                     f32x4 y;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) y[e] = (x[nt][4 * g + e] * rstd) * gam[e] + bet[e];
+                    for (int e = 0; e < 4; ++e) y[e] = ln_affine(x[nt][4 * g + e], mean, rstd, gam[e], bet[e]);
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
                         const f32x4 w = *reinterpret_cast<const f32x4*>(a.f_ow + p * D + col);
-                        fa[p] += (y.x * w.x + y.y * w.y) + (y.z * w.z + y.w * w.w);
+                        fe[p] = __builtin_fmaf(y[0], w[0], fe[p]);
+                        fo[p] = __builtin_fmaf(y[1], w[1], fo[p]);
+                        fe[p] = __builtin_fmaf(y[2], w[2], fe[p]);
+                        fo[p] = __builtin_fmaf(y[3], w[3], fo[p]);
                     }
                 }
-            const float f0 = fa[0] + xhalf(fa[0]), f1 = fa[1] + xhalf(fa[1]);
-            const float f2 = fa[2] + xhalf(fa[2]), f3 = fa[3] + xhalf(fa[3]);
+            float fl[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) fl[p] = fe[p] + fo[p];
+            const float f0 = fl[0] + xhalf(fl[0]), f1 = fl[1] + xhalf(fl[1]);
+            const float f2 = fl[2] + xhalf(fl[2]), f3 = fl[3] + xhalf(fl[3]);
             if (active) {   // lane half 0 writes patch outputs p = 0,1; half 1 writes p = 2,3
                 const int n = (tile - seq * (NTOK / 32)) * 32 + (lane & 31);
                 const int hh = n >> 5, ww = n & 31;

@@ -25,7 +25,7 @@
 // Weights: the same 16 KiB chunks (32 outputs x K = 128, or the 8 x 2 blocks one fc1 chunk feeds into fc2) in 16-layout
 // fragment order, through the same 3-slot LDS ring / counted-vmcnt DMA as t2s_rows.h.  Two output blocks (or two fc2
 // accumulators) are interleaved so that dependent MFMAs sit 64 cycles apart (16x16x4: 32-cycle issue, 40-cycle dependent
-// latency).  Only <qkv> and <proj + MLP + qkv> exist: the last block's kernel (fused final layer) stays on 32-token tiles.
+// latency).  All three instances exist: <qkv>, <proj + MLP + qkv>, <proj + MLP + fused final layer>.
 #pragma once
 #include "t2s_rows.h"
 
@@ -97,14 +97,13 @@ __device__ __forceinline__ float token_sum16(float p) {
     return t + __shfl_xor(t, 16, 64);
 }
 
-__device__ __forceinline__ void ln_modulate16(const f32x4 (&x)[8], f32x4 (&y)[8], const float* __restrict__ shift16,
-                                              const float* __restrict__ scale16, int g, float eps) {
+__device__ __forceinline__ void ln_mean_rstd16(const f32x4 (&x)[8], float eps, float& mean, float& rstd) {
     float p = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) p += x[mt][r];
-    const float mean = token_sum16(p) * (1.0f / 128.0f);
+    mean = token_sum16(p) * (1.0f / 128.0f);
     float qq = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt)
@@ -113,7 +112,13 @@ __device__ __forceinline__ void ln_modulate16(const f32x4 (&x)[8], f32x4 (&y)[8]
             const float d = x[mt][r] - mean;
             qq = __builtin_fmaf(d, d, qq);
         }
-    const float rstd = ln_rstd(token_sum16(qq), eps);
+    rstd = ln_rstd(token_sum16(qq), eps);
+}
+
+__device__ __forceinline__ void ln_modulate16(const f32x4 (&x)[8], f32x4 (&y)[8], const float* __restrict__ shift16,
+                                              const float* __restrict__ scale16, int g, float eps) {
+    float mean, rstd;
+    ln_mean_rstd16(x, eps, mean, rstd);
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
         const f32x4 sc = ldc16(scale16, mt, g);
@@ -121,6 +126,13 @@ __device__ __forceinline__ void ln_modulate16(const f32x4 (&x)[8], f32x4 (&y)[8]
 #pragma unroll
         for (int r = 0; r < 4; ++r) y[mt][r] = ln_y(x[mt][r], mean, rstd, sc[r], sh[r]);
     }
+}
+
+// the lane's four elements {q, q + 2} of two float4 quads of a natural-order vector: features 16 mt + 4 h + q + {0, 2, 8, 10}
+__device__ __forceinline__ f32x4 gather16(const float* __restrict__ vec, int mt, int h, int q) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(vec + 16 * mt + 4 * h);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(vec + 16 * mt + 8 + 4 * h);
+    return q ? f32x4{a[1], a[3], c[1], c[3]} : f32x4{a[0], a[2], c[0], c[2]};
 }
 
 // One chunk = two 16-output blocks x K = 128 (fragments [mo_l][mt] at wb[(8 mo_l + mt) * 64]) against the activation b
@@ -149,7 +161,6 @@ __device__ __forceinline__ void kchunk16(const f32x4* __restrict__ wb, const f32
 
 template <bool DO_MLP, bool DO_QKV>
 __global__ __launch_bounds__(256, 2) void dit_rows16_kernel(const RowArgs a) {
-    static_assert(DO_QKV, "the last block's kernel (fused final layer) runs on 32-token tiles");
     extern __shared__ __attribute__((aligned(16))) f32x4 wring[];  // [ROWS_SLOTS][1024]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows16_kernel(const RowArgs a) {
     const int tile_in_seq = tile - seq * (NTOK / 32);
     const float* __restrict__ modrow = mod_row_of(a, seq);
 
-    constexpr int N_CHUNKS = (DO_MLP ? 20 : 0) + 12;
+    constexpr int N_CHUNKS = (DO_MLP ? 20 : 0) + (DO_QKV ? 12 : 0);
     auto chunk_src = [&](int ci) -> const f32x4* {
         if constexpr (DO_MLP) {
             if (ci < 4) return a.Wp + (size_t)ci * ROWS_CHUNK_F4;
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void dit_rows16_kernel(const RowArgs a) {
             for (int e = 0; e < 4; ++e) cm[((f0 + e) & ~15) | pos16((f0 + e) & 15)] = v[e];
         }
     }
-    {
+    if constexpr (DO_QKV) {
         for (int i = threadIdx.x; i < 384; i += 256) cb[512 + ((i & ~15) | pos16(i & 15))] = a.bq[i];
         const float* src = modrow + a.qkv_blk * MODW;   // shift_msa | scale_msa
         const int f0 = lane * 4;
@@ -348,14 +359,48 @@ __global__ __launch_bounds__(256, 2) void dit_rows16_kernel(const RowArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[m][r] = res_gate(x[m][r], gate[r], acc[m][r], bias[r]);
             }
-            if (active) store_rows16<8>(reinterpret_cast<f32x4*>(a.x) + (size_t)tile * 16 * 64, h, q, row, x);
+            if (active && (DO_QKV || a.out0 == nullptr || a.keep_x))   // final residual stream of this block
+                store_rows16<8>(reinterpret_cast<f32x4*>(a.x) + (size_t)tile * 16 * 64, h, q, row, x);
         }
     } else {
         ROWS_SYNC();  // chunk 0 landed, constants visible
     }
 
+    // ---- fused final layer of the LAST block (transformer.py:182-191), the arithmetic of t2s_rows.h in the 16-token
+    // layout: affine LayerNorm (eps 1e-5), Linear 128 -> 4, unpatchify; lane g of a token writes patch output p = g
+    if constexpr (DO_MLP && !DO_QKV) {
+        if (a.out0 != nullptr) {
+            float mean, rstd;
+            ln_mean_rstd16(x, 1e-5f, mean, rstd);
+            float fp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const f32x4 gam = gather16(a.f_lnw, mt, h, q), bet = gather16(a.f_lnb, mt, h, q);
+                f32x4 y;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = ln_affine(x[mt][r], mean, rstd, gam[r], bet[r]);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const f32x4 w = gather16(a.f_ow + p * D, mt, h, q);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) fp[p] = __builtin_fmaf(y[r], w[r], fp[p]);
+                }
+            }
+            float ft[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) ft[p] = token_sum16(fp[p]);
+            if (active) {
+                const int n = tile_in_seq * 32 + row;
+                const int hh = n >> 5, ww = n & 31;
+                float* dst = (seq < a.split) ? a.out0 + (size_t)seq * LAT : a.out1 + (size_t)(seq - a.split) * LAT;
+                const float v = g == 0 ? ft[0] : (g == 1 ? ft[1] : (g == 2 ? ft[2] : ft[3]));
+                dst[(2 * ww + (g & 1)) * LATW + 2 * hh + (g >> 1)] = v + a.f_ob[g];
+            }
+        }
+    }
+
     // ---------------- q, k, v of the next block ----------------
-    {
+    if constexpr (DO_QKV) {
         f32x4 xm[8];
         ln_modulate16(x, xm, cm, cm + D, g, 1e-6f);
 #pragma unroll 1
@@ -415,6 +460,7 @@ inline int launch_dit_rows16(const RowArgs& a, hipStream_t st) {
 inline int dit_rows16_init() {
     T2S_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dit_rows16_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_LDS_BYTES));
     T2S_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dit_rows16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_LDS_BYTES));
+    T2S_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dit_rows16_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_LDS_BYTES));
     return T2S_OK;
 }
 
