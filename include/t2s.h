@@ -194,10 +194,14 @@ int t2s_dit_train_forward(t2s_dit* h, const t2s_dit_weights* w, const float* x, 
 int t2s_attn_fwd_bf16(const float* q, const float* k, const float* v, float* o_rows, float* lse,
                       int n_seq, void* stream);
 /* Backward of the last t2s_dit_train_forward: dout (B,64,30) = dLoss/dout; writes (overwrites)
- * every gradient tensor of `g`.  The block weight / bias gradients are reduced in a fixed order
- * (bit-reproducible); the small final-layer and patchify gradients (ln, linear_emb_to_patch,
- * patch_emb, conv) are flushed with fp32 atomics, so their last bits may vary from run to run. */
+ * every gradient tensor of `g`.  Every gradient is reduced in a fixed order (bit-reproducible from run to run): the block
+ * weights / biases per row slab in slab order, the small final-layer and patchify gradients (ln, linear_emb_to_patch,
+ * patch_emb, conv) per workgroup in workgroup order. */
 int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g, int B, void* stream);
+/* The gradient with respect to the denoiser's INPUT latent, dinput (B,64,30) (patchify backwards, transformer.py:166-172), after
+ * t2s_dit_train_backward of the same batch.  train.py needs it only when something upstream of the latent trains: the LA-VAE
+ * encoder un-frozen (train.py:31-33, `usepretrainedvae` false). */
+int t2s_dit_train_input_grad(t2s_dit* h, float* dinput, int B, void* stream);
 /* One fused AdamW update (torch.optim.AdamW semantics; train.py:37 uses lr 1e-4, weight_decay 0):
  * p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
  * p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps).  step >= 1. */

@@ -105,6 +105,7 @@ SYMBOLS = {
     "t2s_attn_fwd_bf16": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_dit_train_forward": (_I, [_VP, C.POINTER(DitWeights), _VP, _VP, _I, _VP, _VP, _I, _VP]),
     "t2s_dit_train_backward": (_I, [_VP, _VP, C.POINTER(DitGrads), _I, _VP]),
+    "t2s_dit_train_input_grad": (_I, [_VP, _VP, _I, _VP]),
     "t2s_adamw_step": (_I, [_VP, _VP, _VP, _VP, _U64, _F, _F, _F, _F, _F, _I, _VP]),
     "t2s_adamw_step_multi": (_I, [_VP, _I, _U64, _F, _F, _F, _F, _F, _I, _VP]),
     "t2s_mse_backward": (_I, [_VP, _VP, _VP, _VP, _VP, _U64, _VP]),

@@ -649,6 +649,39 @@ __global__ __launch_bounds__(256) void patchify_rows_kernel(const float* __restr
     }
 }
 
+// gradient of patchify with respect to the LATENT (transformer.py:166-172 backwards): token n = hh*32 + ww owns the 2x2 patch
+// lat[2ww+j][2hh+i]; dcv[c] = sum_d dx[tok][d] patch_w[d][c]; dlat[2ww+j][2hh+i] = sum_c conv_w[c][i][j] dcv[c].  Every latent
+// element belongs to exactly one token: plain stores.  Needed only when something upstream of the latent trains
+// (train.py:31-33 with the LA-VAE encoder un-frozen).
+__global__ __launch_bounds__(256) void patchify_input_grad_kernel(const float* __restrict__ dx, float* __restrict__ dlat, int S,
+                                                                  const float* __restrict__ cw, const float* __restrict__ pw) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= S * NTOK) return;
+    const int s = gid / NTOK, n = gid - s * NTOK;
+    const int hh = n >> 5, ww = n & 31;
+    const f32x4* row = reinterpret_cast<const f32x4*>(dx + (size_t)gid * D);
+    float dcv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int d4 = 0; d4 < D / 4; ++d4) {
+        const f32x4 g = row[d4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(pw + (d4 * 4 + e) * 4);
+            dcv[0] += g[e] * w.x; dcv[1] += g[e] * w.y; dcv[2] += g[e] * w.z; dcv[3] += g[e] * w.w;
+        }
+    }
+    float* out = dlat + (size_t)s * LAT;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc += cw[c * 4 + i * 2 + j] * dcv[c];
+            out[(2 * ww + j) * LATW + 2 * hh + i] = acc;
+        }
+}
+
 // final layer, row-major input (transformer.py:182-191)
 // f != NULL (bf16 training): the layer input is x_mid + gate * f of the last block, formed here (gate_res_kernel's expression)
 __global__ __launch_bounds__(256) void final_rows_kernel(const float* __restrict__ h, int S, const float* __restrict__ lnw,
@@ -1243,6 +1276,16 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
         if ((rc = wgrad(ws, ws->t1, ws->silu_c, g->blk[i].ada_w, g->blk[i].ada_b, S, MODW, D, st))) return rc;
         }
     }
+    return T2S_OK;
+}
+
+int t2s_dit_train_input_grad(t2s_dit* h, float* dinput, int B, void* stream) {
+    T2S_REQUIRE(h && dinput, "t2s_dit_train_input_grad: NULL argument");
+    T2S_REQUIRE(h->train && h->train->S == B, "t2s_dit_train_input_grad: no matching t2s_dit_train_backward (B=%d)", B);
+    t2s_train_ws* ws = h->train;
+    TimeScope ts(h, TC_TR_TAIL, (hipStream_t)stream);
+    patchify_input_grad_kernel<<<(B * NTOK + 255) / 256, 256, 0, (hipStream_t)stream>>>(ws->dx, dinput, B, h->conv_w, h->patch_w);
+    T2S_LAUNCH_CHECK();
     return T2S_OK;
 }
 

@@ -127,10 +127,30 @@ class Encoder(_Codec):
             setattr(w, name, c.data_ptr())
         return w, keep
 
+    def _forward_autograd(self, inputs):
+        """The same forward as torch ops UNDER AUTOGRAD, for the one case that needs the encoder's gradients: train.py:31-33 with
+        `usepretrainedvae` false (the LA-VAE encoder trained jointly with the denoiser).  Host-level plumbing like the MLP
+        denoiser: no scripted configuration of the reference trains the encoder; the frozen / inference path is the HIP kernel
+        below.  nn.ReLU(True) of the reference's Residual mutates the block input, so the skip carries relu(x) (vqvae.py:10-21)."""
+        import torch.nn.functional as F
+        B, Ln = inputs.shape[0], inputs.shape[-1]
+        h = inputs.float().reshape(B, 1, Ln)
+        h = F.relu(self._conv_1(h))
+        h = F.relu(self._conv_2(h))
+        h = self._conv_3(h)
+        for layer in self._residual_stack._layers:
+            h = F.relu(h)
+            h = h + layer._block[3](F.relu(layer._block[1](h)))
+        h = F.relu(h)
+        before = self._pre_vq_conv(h)
+        return F.interpolate(before, size=L.LAT_W, mode="linear", align_corners=True), before
+
     def forward(self, inputs):
         """x (B,L) [or (B,1,L)] -> (z (B,64,30), before (B,64,L/4)); vqvae.py:57-71."""
         if not inputs.is_cuda:
             raise L.T2SError("Encoder.forward: input must live on a GPU; the HIP path has no CPU fallback")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_autograd(inputs)
         B, Ln = inputs.shape[0], inputs.shape[-1]
         x = L.as_f32(inputs).reshape(B, Ln)
         dev = x.device

@@ -150,17 +150,19 @@ class _DitTrainFn(torch.autograd.Function):
         # else references the tensor object -- p.grad must ALIAS the bucket (all-reduce, AdamW pointer table)
         views = [v.view_as(v) for v in bucket["views"]]
         grads = views[:4] + [None] + views[4:]      # pos_embed (index 4 of _dit_tensors) gets none
-        return (None, None, None, None) + tuple(grads)
+        dx = None
+        if ctx.needs_input_grad[1]:                 # something upstream of the latent trains (un-frozen LA-VAE encoder)
+            dx = torch.empty(B, L.LAT_C, L.LAT_W, device=dev, dtype=torch.float32)
+            with torch.cuda.device(dev):
+                L.check(L.lib().t2s_dit_train_input_grad(h, L.dev_ptr(dx), B, L.stream_ptr(dev)), "t2s_dit_train_input_grad")
+        return (None, dx, None, None) + tuple(grads)
 
 
 def dit_forward_autograd(model, input, t, text_input):
     """Transformer.forward under autograd (called from the mirror's forward when grads are on)."""
-    if input.requires_grad:
-        raise L.T2SError("Transformer.forward: a gradient w.r.t. the latent input is not provided "
-                         "(train.py feeds a constant noised latent)")
     dev = input.device
     B = input.shape[0]
-    x = L.as_f32(input.detach())
+    x = L.as_f32(input)            # a latent that requires grad (un-frozen encoder) gets its gradient from t2s_dit_train_input_grad
     tf = L.as_f32(t.to(dev))
     if tf.shape != (B,):
         raise L.T2SError(f"Transformer.forward: t must be ({B},), got {tuple(tf.shape)}")

@@ -408,3 +408,74 @@ def test_drop_in_chain_vae_pickle_train_infer_metrics(dev, tmp_path, monkeypatch
     line = capsys.readouterr().out
     assert "MSE" in line and "WAPE" in line and "DTW" in line and "nan" not in line.lower(), line
     assert "C-FID" in line and "200 iterations" in line, line      # TS2Vec trained + encoded on the GPU: C-FID from the .npy files alone
+
+
+def test_unfrozen_encoder_gradients_match_oracle(dev):
+    """train.py:31-33 with `usepretrainedvae` false: the LA-VAE encoder trains jointly.  The encoder then runs as torch ops
+    under autograd, q_sample as torch glue, and the DiT returns the gradient of its input latent
+    (t2s_dit_train_input_grad, patchify backwards): all 12 encoder gradients and the 48 DiT gradients against autograd
+    through the oracle (encoder -> q_sample -> DiT -> MSE), 2e-4 of each tensor's largest gradient."""
+    import types
+    from model.pretrained.vqvae import vqvae
+    from t2ms_amd.train import mse_loss
+    B, Ls, T = 3, 96, 100
+    xs = synth.make_series(91, B, Ls)
+    text = synth.make_text_embeddings(91, B)
+    t = torch.tensor([3, 41, 97])
+    noise = synth.make_latents(92, B)
+    # oracle
+    sd = {k: v.clone().requires_grad_(k != "pos_embed") for k, v in synth.make_dit_state_dict(2025).items()}
+    vsd = {k: v.clone().requires_grad_(k.startswith("encoder.")) for k, v in synth.make_vae_state_dict(2025).items()}
+    tab = O.ddpm_tables(T)
+    z_ref, _ = O.vae_encode(vsd, xs)
+    xt_ref = O.ddpm_q_sample(tab, z_ref, t, noise)
+    loss_ref = O.mse_loss(O.dit_forward(sd, xt_ref, t, text), noise)
+    loss_ref.backward()
+    # HIP DiT + autograd encoder
+    m = _model(dev)
+    v = vqvae(types.SimpleNamespace(block_hidden_size=128, num_residual_layers=2, res_hidden_size=256, embedding_dim=64))
+    v.load_state_dict(synth.make_vae_state_dict(2025), strict=True)
+    m.encoder = v.encoder.to(dev)
+    z, _ = m.encoder(xs.to(dev))
+    assert z.requires_grad and float((z.detach().cpu() - z_ref.detach()).abs().max()) < 1e-5
+    ab = tab["alpha_bar"].to(dev).gather(-1, t.to(dev)).reshape(-1, 1, 1)
+    x_t = ab ** 0.5 * z + (1 - ab) ** 0.5 * noise.to(dev)
+    loss = mse_loss(m(input=x_t, t=t.to(dev), text_input=text.to(dev)), noise.to(dev))
+    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=2e-5)
+    loss.backward()
+    checked = 0
+    for name, p in m.named_parameters():
+        if name.startswith("unpatch") or name == "pos_embed":
+            continue
+        ref = (vsd[name] if name.startswith("encoder.") else sd[name]).grad
+        got = p.grad.detach().cpu()
+        scale = float(ref.abs().max()) + 1e-12
+        assert float((got - ref).abs().max()) < 2e-4 * scale + 1e-9, (name, float((got - ref).abs().max()), scale)
+        checked += 1
+    assert checked == 48 + 12
+    # with the encoder frozen the forward is the HIP kernel again and the DiT is not asked for an input gradient
+    for p in m.encoder.parameters():
+        p.requires_grad = False
+    z2, _ = m.encoder(xs.to(dev))
+    assert not z2.requires_grad and float((z2 - z.detach()).abs().max()) < 1e-5
+
+
+def test_train_driver_with_unfrozen_encoder(dev, tmp_path, monkeypatch):
+    """`train.py --usepretrainedvae ""` (the reference's flag is an untyped string: only the empty value is false): the
+    encoder's weights move, the checkpoint carries them, the loss is finite."""
+    import train as drv
+    monkeypatch.chdir(tmp_path)
+    save = str(tmp_path / "results")
+    argv = ["--dataset_name", "ETTh1", "--backbone", "ddpm", "--denoiser", "DiT", "--total_step", "100", "--batch_size", "12",
+            "--epochs", "2", "--save_path", save, "--synthetic", "12", "--random_init", "--checkpoint_path", "",
+            "--usepretrainedvae", "", "--seed", "4"]
+    args = drv.get_args(argv)
+    assert not args.usepretrainedvae
+    losses = drv.train(args)
+    assert len(losses) > 0 and np.isfinite(losses).all()
+    ck = torch.load(os.path.join(args.save_path, "model_1.pth"), map_location="cpu")
+    w0 = synth.make_vae_state_dict(4)["encoder._conv_1.weight"]
+    assert float((ck["model"]["encoder._conv_1.weight"] - w0).abs().max()) > 0
+    assert len(ck["optimizer"]["state"]) == 48 + 12
+    # "False" is a non-empty string: frozen, exactly as the reference's argparse line behaves
+    assert drv.get_args([a if a != "" or i == 0 or argv[i - 1] != "--usepretrainedvae" else "False" for i, a in enumerate(argv)]).usepretrainedvae

@@ -105,20 +105,31 @@ def train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world, 
         loss.backward()
     elif n > 0:
         emb = _h2d(emb[lo:hi].float(), device)
+        enc_trains = any(p.requires_grad for p in model.encoder.parameters())
         if latents is not None and idx is not None:
             z = latents[_h2d(idx[lo:hi], device)]                                      # pre-encoded rows (latent cache)
+        elif enc_trains:
+            z, _ = model.encoder(_h2d(x_1[lo:hi].float(), device).contiguous())        # un-frozen encoder (train.py:31-33): autograd
         else:
             with torch.no_grad():
                 z, _ = model.encoder(_h2d(x_1[lo:hi].float(), device).contiguous())    # frozen LA-VAE (train.py:31-33,106)
         noise = philox_normal(n, z[0].numel(), args.seed ^ 0x7261696E, step_no, lo, device).view_as(z)
         if args.backbone == "flowmatching":
             t = _h2d((torch.round(u * args.total_step) / args.total_step)[lo:hi], device)
-            x_t, x_0 = backbone.create_flow(z, t, x_0=noise)
+            if enc_trains:       # the same two formulas as differentiable torch glue (rectified_flow.py:8-12)
+                tt = t.float()[:, None, None]
+                x_t, x_0 = tt * z + (1 - tt) * noise, noise
+            else:
+                x_t, x_0 = backbone.create_flow(z, t, x_0=noise)
             target = z - x_0
         elif args.backbone == "ddpm":
             t = _h2d(torch.floor(u * args.total_step).long()[lo:hi], device)
             target = noise
-            x_t, _ = backbone.q_sample(z, t, target)
+            if enc_trains:       # DDPM.py:19-27 as differentiable torch glue
+                ab = backbone.alpha_bar.gather(-1, t).reshape(-1, 1, 1)
+                x_t = ab ** 0.5 * z + (1 - ab) ** 0.5 * noise
+            else:
+                x_t, _ = backbone.q_sample(z, t, target)
         else:
             raise ValueError(f"Unsupported backbone type: {args.backbone}")
         pred = model(input=x_t, t=t, text_input=None if drop_text else emb)
@@ -130,6 +141,9 @@ def train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world, 
         loss = allreduce_param_grads([p for nm, p in model.named_parameters() if "encoder" not in nm], dist, n_local=n,
                                      n_global=n_global, loss=loss)
     elif dist is not None:
+        enc_params = [p for p in model.encoder.parameters() if p.requires_grad]
+        if enc_params:           # un-frozen encoder: its gradients travel as a second flat message
+            allreduce_param_grads(enc_params, dist, n_local=n, n_global=n_global)
         _, loss = allreduce_gradients(model, dist, n_local=n, n_global=n_global,
                                       loss=loss if loss is not None else torch.zeros((), device=device))
     opt.step()
@@ -174,10 +188,13 @@ def train(args):
         if "encoder" in name:
             p.requires_grad = not args.usepretrainedvae
     if not args.usepretrainedvae:
-        # train.py:31-33 would un-freeze the grafted encoder: that needs the LA-VAE encoder's BACKWARD, which this build
-        # does not have (the codec is frozen in every script of the reference: scripts/*.sh never pass the flag)
-        raise ValueError("--usepretrainedvae False (training the LA-VAE encoder jointly) needs an encoder backward pass; "
-                         "this build trains the denoiser against the frozen codec only")
+        # train.py:31-33: the grafted LA-VAE encoder trains jointly with the denoiser.  (As in the reference the flag is an
+        # untyped argparse string, so only an EMPTY value -- `--usepretrainedvae ""` -- is false; "False" is a non-empty string.)
+        # The encoder then runs as torch ops under autograd (plumbing; model/pretrained/vqvae.py) and the DiT hands back the
+        # gradient of its input latent (t2s_dit_train_input_grad); latents cannot be cached.
+        if args.denoiser != "DiT":
+            raise ValueError("--usepretrainedvae false is wired for the DiT denoiser")
+        args.cache_latents = False
     if rank == 0:
         print(f"Total learnable parameters: {sum(p.numel() for p in model.parameters() if p.requires_grad)}")
     # every parameter, as the reference builds it (train.py:37): the optimizer state_dict then indexes the same 67
