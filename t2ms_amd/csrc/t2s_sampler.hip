@@ -455,7 +455,11 @@ extern "C" int t2s_sampler_create(t2s_dit* dit, t2s_vae* vae, const t2s_sample_c
     alloc((void**)&s->step, 2 * 16 * sizeof(int));   // one counter per lane, 64 B apart
     // whole-run adaLN table (dit_adaln_table): up to 16 GB of the 288 GB; beyond that the per-step kernel stays in the loop
     const size_t table_bytes = T * (B + 1) * (size_t)MODROW * sizeof(float);
-    if (table_bytes <= ((size_t)16 << 30)) alloc((void**)&s->mod_table, table_bytes);
+    const char* table_env = getenv("T2S_ADALN_TABLE");   // =0: keep the per-step adaLN kernel (A/B, and the test of that path)
+    if (e == hipSuccess && !(table_env && atoi(table_env) == 0) && table_bytes <= ((size_t)16 << 30) && hipMalloc((void**)&s->mod_table, table_bytes) != hipSuccess) {
+        s->mod_table = nullptr;       // an optimisation only: a device too full for it keeps the per-step kernel
+        (void)hipGetLastError();
+    }
     if (e == hipSuccess) e = hipMemcpy(s->tvals, cfg->t_values, T * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess && cfg->mode == T2S_MODE_DDPM)
         e = hipMemcpy(s->coef, cfg->ddpm_coef, T * 3 * sizeof(float), hipMemcpyHostToDevice);

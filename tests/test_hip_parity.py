@@ -426,6 +426,20 @@ def test_chain_rf_golden(golden_dir, dev, vae, use_graph, lanes):
     assert _maxdiff(series, g["rf_series"]) < TOL * scale
 
 
+@pytest.mark.parametrize("backbone", ["ddpm", "flowmatching"])
+def test_chain_without_the_whole_run_adaln_table(dev, vae, monkeypatch, backbone):
+    """The sampler precomputes the adaLN modulation of every step (csrc/t2s_sampler.hip: mod_table) when the table fits;
+    a device too full for it -- or T2S_ADALN_TABLE=0 -- keeps the per-step adaLN kernel in the loop.  Same MFMA order per
+    row either way: the two paths agree bit for bit (graph and eager, one and two lanes)."""
+    m, Sampler, xT, text, noises = _chain_setup(dev, vae)
+    kw = dict(x_T=xT, noise=noises) if backbone == "ddpm" else dict(x_T=xT)
+    ref = Sampler(m, vae.decoder, backbone, 20, 7.0, 4, 96, dev, use_graph=True, lanes=1).run(text, **kw)
+    monkeypatch.setenv("T2S_ADALN_TABLE", "0")
+    for use_graph, lanes in ((True, 1), (False, 1), (True, 2)):
+        got = Sampler(m, vae.decoder, backbone, 20, 7.0, 4, 96, dev, use_graph=use_graph, lanes=lanes).run(text, **kw)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (use_graph, lanes)
+
+
 def test_chain_stepwise_class_api_matches_fused(dev, vae):
     """The reference-style loop (infer.py:76-88) written against the mirrored classes gives the
     fused sampler's result (same kernels, same order)."""
