@@ -205,128 +205,6 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_fwd_kernel(const __b
     }
 }
 
-// ------------------------------------------------------------------ forward, persistent producer / consumer form
-// One 16-wave workgroup per CU walks its heads.  Wave 15 is the PRODUCER: it fills the K / V images of head it + 1 into the
-// other LDS buffer by untracked LDS-DMA while the 15 CONSUMER waves (wave w = query tile w of every head) compute head it;
-// there is no barrier after the prologue -- the producer publishes `landed` (heads whose images are complete), a consumer
-// adds 1 to `done[buffer]` when its tile of a head is finished, the producer refills a buffer once all 15 tiles of the head
-// before last are done.  A consumer only waits for the producer, the producer only for consumers two heads back: no cycle.
-constexpr int PC_BUF = 2 * IMG;                     // K + V images of one head
-constexpr int PC_LDS = 2 * PC_BUF + 64;
-
-__device__ __forceinline__ void dma_img_piece_asm(char* img, const __bf16* src, int src_stride, int p, int lane) {
-    const int row = 16 * p + (lane >> 2);
-    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-    glds16_asm_at(reinterpret_cast<const f32x4*>(src + (size_t)row * src_stride + chunk * 8), lds_addr_of(img) + p * 1024);
-}
-
-template <int ABL>
-__global__ __launch_bounds__(1024) T2S_X3_KERNEL void attn16_fwd_pc_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
-                                                             const __bf16* __restrict__ v, __bf16* __restrict__ o_rows,
-                                                             float* __restrict__ lse, int BH, int reverse) {
-    extern __shared__ __attribute__((aligned(16))) char psm[];
-    int* landed = reinterpret_cast<int*>(psm + 2 * PC_BUF);      // heads whose images have landed
-    int* done = landed + 4;                                      // [2]: consumer tiles finished, per buffer (monotone)
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, i = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_it = (BH - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    auto head_of = [&](int it) __attribute__((always_inline)) {
-        const int idx = blockIdx.x + it * gridDim.x;
-        return reverse ? BH - 1 - idx : idx;
-    };
-    if (tid < 3) landed[tid == 0 ? 0 : 3 + tid] = 0;             // landed, done[0], done[1]
-    wg_sync();
-    if (wave == 15) {
-        for (int it = 0; it < n_it; ++it) {
-            const int b = it & 1, bh = head_of(it);
-            const int need = NKB * (it >> 1);                    // tiles of the heads that used this buffer before
-            while (__hip_atomic_load(done + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(2);
-            char* Kd = psm + b * PC_BUF;
-            for (int p = 0; p < ((ABL & 1) ? 0 : 30); ++p) {
-                dma_img_piece_asm(Kd, k + (size_t)bh * NTOK * DH, DH, p, lane);
-                dma_img_piece_asm(Kd + IMG, v + (size_t)bh * NTOK * DH, DH, p, lane);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(landed, it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        return;
-    }
-    const int qt = wave, tokl = qt * 32 + i;
-    bf16x8 qn[2];
-    {
-        const __bf16* qg = q + (size_t)head_of(0) * NTOK * DH;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) qn[s] = *reinterpret_cast<const bf16x8*>(qg + (size_t)tokl * DH + 16 * s + 8 * half);
-    }
-    for (int it = 0; it < n_it; ++it) {
-        const int b = it & 1, bh = head_of(it), seq = bh / NH, head = bh % NH;
-        const char* Ks = psm + b * PC_BUF;
-        const char* Vs = Ks + IMG;
-        bf16x8 qf[2] = {qn[0], qn[1]};
-        if (it + 1 < n_it) {                                      // next head's Q fragments while this one computes
-            const __bf16* qg = q + (size_t)head_of(it + 1) * NTOK * DH;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) qn[s] = *reinterpret_cast<const bf16x8*>(qg + (size_t)tokl * DH + 16 * s + 8 * half);
-        }
-        while (__hip_atomic_load(landed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= it) __builtin_amdgcn_s_sleep(1);
-        f32x16 ot;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ot[r] = 0.f;
-        float m_run = 0.f, l_lane = 0.f;
-        f32x16 negm;
-        for (int jb = 0; jb < ((ABL & 2) ? 1 : NKB); ++jb) {
-            if (jb == 0) {
-                f32x16 raw;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) raw[r] = 0.f;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) raw = mfma16(row_frag(Ks, 0, lane, s), qf[s], raw);
-                float mloc = raw[0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, raw[r]);
-                m_run = pair_max_f(mloc);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) negm[r] = -m_run;
-            }
-            f32x16 st = mfma16_from(row_frag(Ks, jb * 32, lane, 0), qf[0], negm);
-            st = mfma16(row_frag(Ks, jb * 32, lane, 1), qf[1], st);
-            f32x16 pt;
-            float ps = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                pt[r] = __builtin_amdgcn_exp2f(st[r]);
-                ps += pt[r];
-            }
-            if (!(ABL & 3) && __builtin_amdgcn_ballot_w64(!(ps < 1.0995116e12f)) != 0) {
-                float mloc = st[0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[r]);
-                const float up = fmaxf(0.f, pair_max_f(mloc));
-                const float alpha = __builtin_amdgcn_exp2f(-up);
-                m_run += up;
-                ps = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    negm[r] = -m_run;
-                    pt[r] = __builtin_amdgcn_exp2f(st[r] - up);
-                    ps += pt[r];
-                    ot[r] *= alpha;
-                }
-                l_lane *= alpha;
-            }
-            l_lane += ps;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) ot = mfma16(col_frag(Vs, jb * 32, lane, s), acc_frag(pt, s), ot);
-        }
-        // every LDS read of this head has been consumed by an MFMA: hand the buffer back
-        if (lane == 0) (void)__hip_atomic_fetch_add(done + b, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const float l_tot = pair_sum_f(l_lane);
-        const float inv = 1.0f / l_tot;
-        store_row32(o_rows + ((size_t)seq * NTOK + tokl) * D + head * DH, ot, inv, half);
-        if (half == 0) lse[(size_t)bh * NTOK + tokl] = m_run + __builtin_amdgcn_logf(l_tot);
-    }
-}
-
 // ------------------------------------------------------------------ kernel A: dQ (queries on lanes)
 __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_bwd_dq_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ k,
                                                             const __bf16* __restrict__ v, const __bf16* __restrict__ o_rows,
@@ -461,28 +339,6 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_bwd_dkv_kernel(const
 }
 
 int attn16_train_fwd(const __bf16* q, const __bf16* k, const __bf16* v, __bf16* o_rows, float* lse, int BH, hipStream_t st) {
-    const char* pc = getenv("T2S_ATTN_FWD_PC");
-    if (pc && atoi(pc)) {
-        static const int n_cu = [] {
-            int dev = 0, n = 256;
-            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-            return n;
-        }();
-        const int abl = getenv("T2S_FB_ABL") ? atoi(getenv("T2S_FB_ABL")) : 0;
-        const int dir = next_tile_dir();
-#define PC_LAUNCH(A)                                                                                                      \
-    case A:                                                                                                               \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_fwd_pc_kernel<A>),                                   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS) != hipSuccess) return T2S_E_HIP;     \
-        attn16_fwd_pc_kernel<A><<<BH < n_cu ? BH : n_cu, 1024, PC_LDS, st>>>(q, k, v, o_rows, lse, BH, dir);              \
-        break;
-        switch (abl) {
-            PC_LAUNCH(0) PC_LAUNCH(1) PC_LAUNCH(2)
-            default: return T2S_E_INVALID;
-        }
-        T2S_LAUNCH_CHECK();
-        return T2S_OK;
-    }
     attn16_fwd_kernel<<<BH, 512, 0, st>>>(q, k, v, o_rows, lse, next_tile_dir());
     T2S_LAUNCH_CHECK();
     return T2S_OK;

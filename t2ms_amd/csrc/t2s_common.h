@@ -117,18 +117,5 @@ __device__ __forceinline__ void glds16_asm(const f32x4* gsrc_lane, f32x4* lds_wa
                  : "v"(gsrc_lane), "s"(dst)
                  : "memory");
 }
-// the same with the destination given as a wave-uniform LDS BYTE ADDRESS (readfirstlane'd here: for addresses the
-// compiler cannot prove uniform)
-__device__ __forceinline__ void glds16_asm_at(const f32x4* gsrc_lane, unsigned lds_byte_addr) {
-    unsigned keep;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc_lane), "s"(dst)
-                 : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
-    return (unsigned)(size_t)((__attribute__((address_space(3))) const char*)p);
-}
 
 }  // namespace t2s
