@@ -35,13 +35,18 @@ from t2ms_amd import synth                                    # noqa: E402
 from t2ms_amd.sampler import Sampler, np_save_outputs         # noqa: E402
 
 
+def _weight_seed(args):
+    """--random_init: the synthetic weights keep the seed the driver started with (--run_multi advances the NOISE seed)."""
+    return getattr(args, "weight_seed", args.seed)
+
+
 def _load_models(args, device):
     root = args.dataset_name.split("_")[0]
     if args.random_init:
         from model.pretrained.vqvae import vqvae
         vae = vqvae(types.SimpleNamespace(block_hidden_size=128, num_residual_layers=2, res_hidden_size=256,
                                           embedding_dim=64))
-        vae.load_state_dict(synth.make_vae_state_dict(args.seed), strict=True)
+        vae.load_state_dict(synth.make_vae_state_dict(_weight_seed(args)), strict=True)
     else:
         vae = torch.load(f"results/saved_pretrained_models/dataset{root}_epoch2000/final_model.pth",
                          map_location=torch.device("cpu"), weights_only=False)     # infer.py:39
@@ -51,7 +56,7 @@ def _load_models(args, device):
         from model.denoiser.mlp import MLP
         model = MLP()
         if args.random_init:
-            model.load_state_dict(synth.make_mlp_state_dict(args.seed), strict=True)
+            model.load_state_dict(synth.make_mlp_state_dict(_weight_seed(args)), strict=True)
         else:
             model.load_state_dict(torch.load(args.checkpoint_path, map_location="cpu")["model"], strict=False)
         model.encoder = vae.encoder
@@ -61,7 +66,7 @@ def _load_models(args, device):
     model = Transformer().to(device)
     model.encoder = vae.encoder                                                     # infer.py:47
     if args.random_init:
-        sd = synth.make_dit_state_dict(args.seed)
+        sd = synth.make_dit_state_dict(_weight_seed(args))
         sd.update({"encoder." + k: v for k, v in vae.encoder.state_dict().items()})
         model.load_state_dict(sd, strict=True)
     else:
@@ -219,6 +224,7 @@ def main(argv=None):
     args.device = f"cuda:{local_rank}"
     if args.seed is None:
         args.seed = int(time.time()) & 0x7FFFFFFF
+    args.weight_seed = args.seed
     root = args.dataset_name.split("_")[0]
     args.checkpoint_path = os.path.join(args.save_path, "checkpoints", f"{args.backbone}_{args.denoiser}_{root}",
                                         f"model_{args.checkpoint_id}.pth")

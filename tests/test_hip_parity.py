@@ -497,6 +497,36 @@ def test_infer_driver_end_to_end(dev, tmp_path, monkeypatch):
     assert np.load(os.path.join(out, "x_infer_trace.npy")).shape == (3, 24)
 
 
+def test_infer_driver_run_multi_layout(dev, tmp_path, monkeypatch):
+    """`--run_multi True` (infer.py:148-164): the base run plus run_0 .. run_9, each with the four files.  The test loader
+    shuffles (dataloader.py:111 does too), so every run holds the same ground-truth rows in its own order; the generated
+    series differ from run to run (the seed advances)."""
+    import infer as drv
+    monkeypatch.chdir(tmp_path)
+    save = str(tmp_path / "results")
+    drv.main(["--dataset_name", "ETTh1_24", "--backbone", "flowmatching", "--denoiser", "DiT", "--total_step", "2",
+              "--cfg_scale", "7", "--batch_size", "4", "--save_path", save, "--synthetic", "8", "--random_init",
+              "--seed", "3", "--run_multi", "True"])
+    base = os.path.join(save, "generation", "flowmatching_DiT_ETTh1_24_7.0_2")
+    x1 = np.load(os.path.join(base, "x_1.npy"))
+    enc = np.load(os.path.join(base, "x_t_latent_enc_array.npy"))
+    gens = [np.load(os.path.join(base, "x_t.npy"))]
+    for r in range(10):
+        d = os.path.join(base, f"run_{r}")
+        x1r = np.load(os.path.join(d, "x_1.npy"))
+        encr = np.load(os.path.join(d, "x_t_latent_enc_array.npy"))
+        order, order_r = np.lexsort(x1[:, :, 0].T), np.lexsort(x1r[:, :, 0].T)
+        assert np.array_equal(x1r[order_r], x1[order]) and np.array_equal(encr[order_r], enc[order])
+        g = np.load(os.path.join(d, "x_t.npy"))
+        assert g.shape == (8, 24, 1) and np.isfinite(g).all()
+        assert np.load(os.path.join(d, "x_t_latent_dec_array.npy")).shape == (8, 64, 30)
+        gens.append(g)
+    assert not os.path.exists(os.path.join(base, "run_10"))
+    for a in range(len(gens)):
+        for b in range(a + 1, len(gens)):
+            assert not np.array_equal(gens[a], gens[b]), (a, b)
+
+
 def test_config3_rectified_flow_full_batch(dev, vae):
     """BASELINE config 3 shape: B=1024 (2048 sequences per CFG pass), rectified flow, cfg 5, whole
     step in one hipGraph -- at 3 steps; rows must equal the same rows sampled in a 4-row batch
