@@ -62,6 +62,66 @@ def test_backward_matches_oracle_autograd(dev, with_text):
     assert checked == 48
 
 
+def test_rectified_flow_training_step_matches_oracle(dev):
+    """The reference's DEFAULT backbone (train.py:144: flowmatching): t = round(u * total_step) / total_step as a FLOAT
+    (train.py:108), x_t = t x_1 + (1 - t) x_0, target x_1 - x_0 (rectified_flow.py:8-16).  The float-t forward and all 48
+    gradients against autograd through the oracle."""
+    from model.backbone.rectified_flow import RectifiedFlow
+    B, total = 4, 100
+    z = synth.make_latents(81, B)
+    x0 = synth.make_latents(82, B)
+    t = torch.round(torch.tensor([0.0, 0.337, 0.5, 1.0]) * total) / total
+    text = synth.make_text_embeddings(81, B)
+    x_t_ref = O.rf_create_flow(z, t, x0)
+    target = z - x0
+    pred_ref, loss_ref, g_ref = _oracle_grads(2025, x_t_ref, t, text, target)
+    m = _model(dev)
+    rf = RectifiedFlow()
+    x_t, x_0 = rf.create_flow(z.to(dev), t.to(dev), x_0=x0.to(dev))
+    assert float((x_t.cpu() - x_t_ref).abs().max()) < 1e-6 and torch.equal(x_0.cpu(), x0)
+    pred = m(input=x_t, t=t.to(dev), text_input=text.to(dev))
+    assert float((pred.detach().cpu() - pred_ref).abs().max()) < 1e-4
+    loss = rf.loss(pred, target.to(dev))
+    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=1e-5)
+    loss.backward()
+    checked = 0
+    for name, p in m.named_parameters():
+        if name.startswith("unpatch") or name == "pos_embed":
+            continue
+        ref = g_ref[name]
+        err = float((p.grad.detach().cpu() - ref).abs().max())
+        assert err < 2e-4 * (float(ref.abs().max()) + 1e-12) + 1e-9, (name, err)
+        checked += 1
+    assert checked == 48
+
+
+def test_train_driver_default_backbone_then_infer(dev, tmp_path, monkeypatch):
+    """train.py with the reference's default --backbone (flowmatching) and --total_step (100), then infer.py with ITS
+    defaults (flowmatching, cfg 7, 100 steps -> shortened) from the written checkpoint."""
+    import types
+    import infer as infer_drv
+    import train as drv
+    from model.pretrained.vqvae import vqvae
+    monkeypatch.chdir(tmp_path)
+    vae = vqvae(types.SimpleNamespace(block_hidden_size=128, num_residual_layers=2, res_hidden_size=256, embedding_dim=64))
+    vae.load_state_dict(synth.make_vae_state_dict(2025), strict=True)
+    os.makedirs("results/saved_pretrained_models/datasetETTh1_epoch2000")
+    torch.save(vae, "results/saved_pretrained_models/datasetETTh1_epoch2000/final_model.pth")
+    save = str(tmp_path / "results" / "denoiser_results")
+    argv = ["--dataset_name", "ETTh1", "--batch_size", "12", "--epochs", "4", "--save_path", save, "--synthetic", "24",
+            "--checkpoint_path", "", "--seed", "7"]
+    monkeypatch.setattr("sys.argv", ["train.py"] + argv)
+    args = drv.get_args(argv)
+    assert args.backbone == "flowmatching" and args.total_step == 100 and args.denoiser == "DiT"
+    losses = drv.train(args)
+    assert np.isfinite(losses).all() and len(losses) >= 8
+    assert os.path.exists(os.path.join(save, "checkpoints", "flowmatching_DiT_ETTh1", "model_3.pth"))
+    infer_drv.main(["--dataset_name", "ETTh1_48", "--total_step", "5", "--batch_size", "4", "--save_path", save,
+                    "--synthetic", "9", "--checkpoint_id", "3", "--seed", "3"])
+    gen = np.load(os.path.join(save, "generation", "flowmatching_DiT_ETTh1_48_7_5", "x_t.npy"))
+    assert gen.shape == (8, 48, 1) and np.isfinite(gen).all()
+
+
 def test_train_step_reference_fixture(golden_dir, dev):
     """Fixture (9): loss and the 48 per-parameter gradient norms produced by the reference itself."""
     g = np.load(os.path.join(golden_dir, "train_step.npz"))
