@@ -13,9 +13,9 @@
 // activation, the post-attention residual and the LayerNorm outputs never leave the
 // register file).
 //
-// Weights are the A operand.  A workgroup (4 waves = 128 tokens) streams them ONCE through a
-// double-buffered 2 x 16 KiB LDS ring filled by LDS-DMA (global_load_lds_dwordx4) one chunk
-// ahead; a chunk = 16 fragments of 1 KiB = one 32-output tile over K = 128 (proj / fc1 / qkv)
+// Weights are the A operand.  A workgroup (4 waves = 128 tokens) streams them ONCE through an
+// LDS ring of 16 KiB slots (three in the f32 kernel, see ROWS_SLOTS below) filled by LDS-DMA
+// (global_load_lds_dwordx4) ahead of their use; a chunk = 16 fragments of 1 KiB = one 32-output tile over K = 128 (proj / fc1 / qkv)
 // or the 4 x 4 (n-tile, k-group) fragments one fc1 chunk feeds into fc2.  Waves read
 // fragments with conflict-free ds_read_b128 (lane-linear).  One barrier per chunk
 // (= per 64 MFMAs per wave).
@@ -31,7 +31,7 @@
 namespace t2s {
 
 constexpr int ROWS_CHUNK_F4 = 1024;                       // float4 per chunk (16 KiB)
-// LDS: [2 x 16 KiB weight ring][biases: bp 128 | b1 256 | b2 128 | bq 384][per wave: 6 adaLN vectors
+// LDS: [ROWS_SLOTS x 16 KiB weight ring][biases: bp 128 | b1 256 | b2 128 | bq 384][per wave: 6 adaLN vectors
 // of the MLP block (768) | shift, scale of the qkv block (256)].  Every per-feature constant the
 // chunk loops need is read from LDS (lgkmcnt); a global load inside those loops gets sunk next to
 // its use by the compiler and waits with vmcnt(0) -- a full memory round trip, draining the
