@@ -93,6 +93,39 @@ def test_timm_boundary_restatement(golden_dir):
     _close(ym[:, ::5], g["mlp_out"], atol=1e-5)
 
 
+def test_timm_restatement_equals_torch_library_modules():
+    """timm is absent, so its two leaves cannot be run here -- but torch's own library modules implement the
+    same published mathematics independently of this repo: `nn.MultiheadAttention(128, 4, batch_first=True)` with
+    in_proj = qkv (rows [q | k | v], heads = contiguous 32-feature slices, scale 32^-0.5) and out_proj = proj is timm's
+    Attention(128, num_heads=4, qkv_bias=True); Linear -> GELU(tanh) -> Linear is timm's Mlp.  The oracle's restatements
+    (both attention branches) against those modules: a third-party cross-check, still not a pin on timm itself."""
+    sd = synth.make_dit_state_dict(2025)
+    p = "layers.1."
+    x = torch.from_numpy(np.random.RandomState(77).randn(3, 480, 128).astype(np.float32))
+    mha = torch.nn.MultiheadAttention(128, 4, bias=True, batch_first=True)
+    with torch.no_grad():
+        mha.in_proj_weight.copy_(sd[p + "attn.qkv.weight"])
+        mha.in_proj_bias.copy_(sd[p + "attn.qkv.bias"])
+        mha.out_proj.weight.copy_(sd[p + "attn.proj.weight"])
+        mha.out_proj.bias.copy_(sd[p + "attn.proj.bias"])
+        ref, _ = mha(x, x, x, need_weights=False)
+        mlp = torch.nn.Sequential(torch.nn.Linear(128, 256), torch.nn.GELU(approximate="tanh"), torch.nn.Linear(256, 128))
+        mlp[0].weight.copy_(sd[p + "mlp.fc1.weight"])
+        mlp[0].bias.copy_(sd[p + "mlp.fc1.bias"])
+        mlp[2].weight.copy_(sd[p + "mlp.fc2.weight"])
+        mlp[2].bias.copy_(sd[p + "mlp.fc2.bias"])
+        ref_mlp = mlp(x)
+        args = (x, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"], sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+        for impl in ("explicit", "sdpa"):
+            O.set_attention_impl(impl)
+            try:
+                _close(O.timm_attention(*args), ref.numpy(), atol=2e-6)
+            finally:
+                O.set_attention_impl("explicit")
+        _close(O.timm_mlp(x, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], sd[p + "mlp.fc2.weight"],
+                          sd[p + "mlp.fc2.bias"]), ref_mlp.numpy(), atol=2e-6)
+
+
 @pytest.mark.parametrize("L", [24, 48, 96])
 @pytest.mark.parametrize("B", [1, 5])
 def test_vae(golden_dir, L, B):
