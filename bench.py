@@ -398,8 +398,8 @@ def main():
     ap.add_argument("--length", type=int, default=96)
     ap.add_argument("--backbone", default="ddpm", choices=["ddpm", "flowmatching"])
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2],
-                    help="sampler lanes: 0 = the library's default (two half-batch chains on two streams from B >= 128), 1, 2")
+    ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="sampler lanes: 0 = the library's default (two half-batch chains on two streams when B is a multiple of 64 or 32 / 96), 1 .. 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training leg reported as `train`")
     ap.add_argument("--no-strong", action="store_true",
@@ -447,8 +447,7 @@ def main():
     assert bool(torch.isfinite(series).all()) and bool(torch.isfinite(lat).all())
 
     total_series = args.steps * B * world
-    lanes_used = args.lanes or (int(os.environ["T2S_SAMPLER_LANES"]) if os.environ.get("T2S_SAMPLER_LANES") in ("1", "2")
-                                else (2 if B >= 128 and B % 64 == 0 else 1))
+    lanes_used = sampler.graph_lanes or args.lanes or 1       # what the library captured for this batch size
     value = total_series / elapsed
     out = {
         "metric": "generated series/sec (B=256, L=96, 1000-step DDPM)",

@@ -363,11 +363,11 @@ void t2s_sampler_destroy(t2s_sampler* s);
  */
 int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, const float* noise,
                     float* series, float* trace0, void* stream);
-/* Lanes of t2s_sampler_run: the rows of a batch never interact (infer.py:76-88), so the loop may run as two half
- * batches, each a complete chain with its own hipGraph on its own stream (lane 1 on a stream the sampler owns,
+/* Lanes of t2s_sampler_run: the rows of a batch never interact (infer.py:76-88), so the loop may run as two (up to four)
+ * part batches, each a complete chain with its own hipGraph on its own stream (lanes 1.. on streams the sampler owns,
  * forked from / joined to `stream` inside the call), so that one chain's kernels fill the chip while the other's
- * drain.  Bitwise the same result.  lanes: 0 = automatic (two when batch >= 128 and a multiple of 64; env
- * T2S_SAMPLER_LANES=1|2 overrides), 1, 2.  trace0 runs always use one lane. */
+ * drain.  Bitwise the same result.  lanes: 0 = automatic (two when the batch is a multiple of 64, or 32 or 96 series; env
+ * T2S_SAMPLER_LANES=<n> overrides), or 1 .. 4 chains of equal shares.  trace0 runs always use one lane. */
 int t2s_sampler_set_lanes(t2s_sampler* s, int lanes);
 /* Move the sampler to another shard position: global index of its first series (the Philox key of row r is
  * row0 + r).  Takes effect at the next t2s_sampler_run; the captured hipGraphs are kept (the kernels read the

@@ -363,12 +363,13 @@ struct t2s_sampler {
     // stream, joined only before the decode.  One chain alone drains and refills the chip at each of its 9 kernel
     // boundaries per pass and the row-chain kernel quantises to 7.5 tiles per SIMD at 512 sequences; the other
     // lane's kernels fill those holes.  Results are bitwise those of one lane (batch-invariant kernels).
-    int lanes_req = 0;            // 0 = automatic, 1, 2 (t2s_sampler_set_lanes)
+    int lanes_req = 0;            // 0 = automatic, 1 .. MAX_LANES (t2s_sampler_set_lanes)
     int lanes_cap = 0;            // lanes the graphs below were captured for
-    hipGraph_t graph[2] = {nullptr, nullptr};
-    hipGraphExec_t exec[2] = {nullptr, nullptr};
-    hipStream_t side = nullptr;   // lane 1
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    static constexpr int MAX_LANES = 4;
+    hipGraph_t graph[MAX_LANES] = {};
+    hipGraphExec_t exec[MAX_LANES] = {};
+    hipStream_t side[MAX_LANES] = {};          // lanes 1 .. (index 0 unused: lane 0 runs on the caller's stream)
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_LANES] = {};
     // stream == NULL at the C ABI means the default stream, which cannot be captured: graph runs then go through a
     // stream the sampler owns, forked from and joined to the default stream by events inside the call
     hipStream_t own = nullptr;
@@ -408,7 +409,7 @@ int enqueue_step(t2s_sampler* s, float* x, const float* text, const float* noise
 }
 
 void drop_graph(t2s_sampler* s) {
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < t2s_sampler::MAX_LANES; ++l) {
         if (s->exec[l]) (void)hipGraphExecDestroy(s->exec[l]);
         if (s->graph[l]) (void)hipGraphDestroy(s->graph[l]);
         s->exec[l] = nullptr;
@@ -417,14 +418,21 @@ void drop_graph(t2s_sampler* s) {
     s->lanes_cap = 0;
 }
 
-// lanes of this run: two when asked for, or automatically when each half batch still fills the chip (>= 64 series =
-// 128 sequences per lane; measured: 4 % faster at B = 256, 0.6 % at 1024, nothing to gain at 2 x 32) AND splits into two
-// halves of whole 32-row groups (see the split point below: other splits can lose more than the second lane gains)
+// lanes of this run: as asked for, or automatically TWO for two equal halves of whole 32-row groups (batch a multiple of
+// 64) and for 32 / 96 series (16 + 16, 64 + 32).  Measured with the round-3 kernels (tools/strong_probe.py, series/s with
+// 1 / 2 lanes): 256: 60.1 / 63.8, 128: 58.7 / 62.7, 96: 58.1 / 62.3, 64: 57.4 / 60.2, 32: 52.1 / 58.2 -- at the small sizes a
+// launch is mostly fixed cost, which the other lane's kernels cover.  Unequal splits of larger batches go either way
+// (224 = 128 + 96: 60.1 / 62.6, but 160 = 96 + 64: 59.4 / 57.7: the shorter lane finishes early and leaves a 96-series
+// chain alone) and splits without whole groups lose (48: 47.3 / 39.8, 16: 44.1 / 37.7: attention launches below one head
+// per CU), so those stay on one lane; three lanes 61.6 and four 60.4 at 256.
 int pick_lanes(const t2s_sampler* s, bool trace) {
     if (trace || s->cfg.batch < 2) return 1;
-    if (s->lanes_req) return s->lanes_req;
-    if (const char* e = getenv("T2S_SAMPLER_LANES")) return atoi(e) == 2 ? 2 : 1;
-    return (s->cfg.batch >= 128 && s->cfg.batch % 64 == 0) ? 2 : 1;
+    const int B = s->cfg.batch;
+    int lanes = (B % 64 == 0 || B == 32 || B == 96) ? 2 : 1;
+    if (const char* e = getenv("T2S_SAMPLER_LANES")) lanes = atoi(e);
+    if (s->lanes_req) lanes = s->lanes_req;
+    lanes = lanes < 1 ? 1 : (lanes > t2s_sampler::MAX_LANES ? t2s_sampler::MAX_LANES : lanes);
+    return lanes < s->cfg.batch ? lanes : s->cfg.batch;
 }
 
 }  // namespace
@@ -452,7 +460,7 @@ extern "C" int t2s_sampler_create(t2s_dit* dit, t2s_vae* vae, const t2s_sample_c
     alloc((void**)&s->eps_u, B * LAT * sizeof(float));
     alloc((void**)&s->eps_c, B * LAT * sizeof(float));
     alloc((void**)&s->tvals, T * sizeof(float));
-    alloc((void**)&s->step, 2 * 16 * sizeof(int));   // one counter per lane, 64 B apart
+    alloc((void**)&s->step, t2s_sampler::MAX_LANES * 16 * sizeof(int));   // one counter per lane, 64 B apart
     // whole-run adaLN table (dit_adaln_table): up to 16 GB of the 288 GB; beyond that the per-step kernel stays in the loop
     const size_t table_bytes = T * (B + 1) * (size_t)MODROW * sizeof(float);
     const char* table_env = getenv("T2S_ADALN_TABLE");   // =0: keep the per-step adaLN kernel (A/B, and the test of that path)
@@ -483,7 +491,8 @@ extern "C" int t2s_sampler_create(t2s_dit* dit, t2s_vae* vae, const t2s_sample_c
 }
 
 extern "C" int t2s_sampler_set_lanes(t2s_sampler* s, int lanes) {
-    T2S_REQUIRE(s && lanes >= 0 && lanes <= 2, "t2s_sampler_set_lanes: lanes=%d (0 = automatic, 1, 2)", lanes);
+    T2S_REQUIRE(s && lanes >= 0 && lanes <= t2s_sampler::MAX_LANES, "t2s_sampler_set_lanes: lanes=%d (0 = automatic, 1 .. %d)", lanes,
+                t2s_sampler::MAX_LANES);
     s->lanes_req = lanes;
     return T2S_OK;
 }
@@ -499,9 +508,11 @@ extern "C" int t2s_sampler_graph_lanes(const t2s_sampler* s) { return (s && s->e
 extern "C" void t2s_sampler_destroy(t2s_sampler* s) {
     if (!s) return;
     drop_graph(s);
-    if (s->side) (void)hipStreamDestroy(s->side);
+    for (int l = 0; l < t2s_sampler::MAX_LANES; ++l) {
+        if (s->side[l]) (void)hipStreamDestroy(s->side[l]);
+        if (s->ev_join[l]) (void)hipEventDestroy(s->ev_join[l]);
+    }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
-    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     if (s->own) (void)hipStreamDestroy(s->own);
     if (s->ev_in) (void)hipEventDestroy(s->ev_in);
     if (s->ev_out) (void)hipEventDestroy(s->ev_out);
@@ -521,7 +532,7 @@ extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, cons
     hipStream_t st = (hipStream_t)stream;
     const t2s_sample_config& c = s->cfg;
     int rc;
-    const int lanes = pick_lanes(s, trace0 != nullptr);
+    int lanes = pick_lanes(s, trace0 != nullptr);
     const bool graph_ok = c.use_graph && !trace0;
     const bool via_own = graph_ok && st == nullptr;   // the default stream cannot be captured: never a silent eager run
     if (via_own) {
@@ -534,24 +545,28 @@ extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, cons
         T2S_HIP_CHECK(hipStreamWaitEvent(s->own, s->ev_in, 0));
         st = s->own;
     }
-    if (lanes == 2 && !s->side) {
-        T2S_HIP_CHECK(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
-        T2S_HIP_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
-        T2S_HIP_CHECK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
-    }
+    if (lanes > 1 && !s->ev_fork) T2S_HIP_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+    for (int l = 1; l < lanes; ++l)
+        if (!s->side[l]) {
+            T2S_HIP_CHECK(hipStreamCreateWithFlags(&s->side[l], hipStreamNonBlocking));
+            T2S_HIP_CHECK(hipEventCreateWithFlags(&s->ev_join[l], hipEventDisableTiming));
+        }
     // lane l steps rows [r0[l], r0[l] + nr[l]) on lst[l]
     // split point: half the batch, rounded to a multiple of 32 rows when both lanes keep >= 32 -- the persistent
     // attention kernel walks 8 * rows / n_cu (sequence, head) items per CU, a whole number only in steps of 32 rows
     // (a 144 + 112 split of 256 measured 12 % SLOWER than one lane, 128 + 128 or 160 + 96 4 % faster)
-    int cut = c.batch;
-    if (lanes == 2) {
-        cut = (c.batch + 1) / 2;
-        const int cut32 = (cut + 31) / 32 * 32;
-        if (c.batch - cut32 >= 32) cut = cut32;
+    // (more lanes: equal shares, in whole 32-row groups when every lane keeps at least one)
+    constexpr int ML = t2s_sampler::MAX_LANES;
+    int r0[ML + 1] = {}, nr[ML] = {};
+    {
+        const int share = (c.batch + lanes - 1) / lanes, share32 = (share + 31) / 32 * 32;
+        const int step = (c.batch - (lanes - 1) * share32 >= 32) ? share32 : share;
+        for (int l = 0; l <= lanes; ++l) r0[l] = l * step < c.batch ? l * step : c.batch;
+        r0[lanes] = c.batch;
+        for (int l = 0; l < lanes; ++l) nr[l] = r0[l + 1] - r0[l];
+        while (lanes > 1 && nr[lanes - 1] == 0) --lanes;      // a batch too small for its last lane
     }
-    const int r0[2] = {0, cut};
-    const int nr[2] = {r0[1], c.batch - r0[1]};
-    hipStream_t lst[2] = {st, s->side};
+    hipStream_t lst[ML] = {st, s->side[1], s->side[2], s->side[3]};
     if (graph_ok && (!s->exec[0] || s->lanes_cap != lanes || s->g_x != x || s->g_text != text || s->g_noise != noise)) {
         drop_graph(s);
         for (int l = 0; l < lanes; ++l) {
@@ -574,9 +589,9 @@ extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, cons
     }
     // the adaLN modulation of every step for this run's text (state-independent: off the loop's critical path)
     if (s->mod_table && (rc = dit_adaln_table(s->dit, s->temb_table, c.steps, text, c.batch, s->mod_table, st)) != T2S_OK) return rc;
-    if (lanes == 2) {   // fork: lane 1 starts after everything already queued on the caller's stream
+    if (lanes > 1) {    // fork: the other lanes start after everything already queued on the caller's stream
         T2S_HIP_CHECK(hipEventRecord(s->ev_fork, st));
-        T2S_HIP_CHECK(hipStreamWaitEvent(s->side, s->ev_fork, 0));
+        for (int l = 1; l < lanes; ++l) T2S_HIP_CHECK(hipStreamWaitEvent(s->side[l], s->ev_fork, 0));
     }
     for (int l = 0; l < lanes; ++l) {
         set_step_kernel<<<1, 64, 0, lst[l]>>>(s->step + 16 * l, 0, c.row0 + (uint32_t)r0[l]);
@@ -596,9 +611,9 @@ extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, cons
                 return rc;
         }
     }
-    if (lanes == 2) {   // join before the decode (and before anything the caller queues next)
-        T2S_HIP_CHECK(hipEventRecord(s->ev_join, s->side));
-        T2S_HIP_CHECK(hipStreamWaitEvent(st, s->ev_join, 0));
+    for (int l = 1; l < lanes; ++l) {   // join before the decode (and before anything the caller queues next)
+        T2S_HIP_CHECK(hipEventRecord(s->ev_join[l], s->side[l]));
+        T2S_HIP_CHECK(hipStreamWaitEvent(st, s->ev_join[l], 0));
     }
     if (series) {
         if ((rc = t2s_vae_decode(s->vae, x, series, nullptr, c.batch, c.length, st)) != T2S_OK) return rc;

@@ -48,7 +48,7 @@ def philox_normal(n_rows: int, row_elems: int, seed: int, stream_id: int, row0: 
 class Sampler:
     def __init__(self, model, decoder, backbone: str, steps: int, cfg_scale: float, batch: int, length: int,
                  device, use_graph: bool = True, seed: int = 2025, row0: int = 0, lanes: int = 0):
-        """lanes: 0 = automatic (two half-batch chains on two streams when batch >= 128 and a multiple of 64), 1, 2 -- see
+        """lanes: 0 = automatic (two chains on two streams when the batch is a multiple of 64, or 32 / 96 series), 1 .. 4 -- see
         t2s_sampler_set_lanes; a scheduling choice only, the results are bitwise the same."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -143,6 +143,11 @@ class Sampler:
             cur.wait_stream(self.stream)
         self._last = (noise, tr)  # keep caller-provided buffers alive until the stream has consumed them
         return self._x.clone(), (self._series.clone() if decode else None), tr
+
+    @property
+    def graph_lanes(self) -> int:
+        """Lanes of the hipGraphs the sampler currently holds (0: nothing captured / the last run was eager)."""
+        return int(L.lib().t2s_sampler_graph_lanes(self.ptr))
 
     def run_inplace(self, decode: bool = True):
         """Benchmark entry: x_T from Philox into the persistent buffers, no output copies.

@@ -718,7 +718,7 @@ def test_two_lane_sampler_is_bitwise_one_lane(dev, vae, math):
     B = 37
     text = synth.make_text_embeddings(5, B)
     ref = None
-    for lanes, use_graph in ((1, True), (2, True), (2, False)):
+    for lanes, use_graph in ((1, True), (2, True), (2, False), (3, True), (4, True), (4, False)):
         s = Sampler(m, vae.decoder, "ddpm", 6, 9.0, B, 96, dev, use_graph=use_graph, seed=11, row0=100, lanes=lanes)
         lat, series, _ = s.run(text)
         if ref is None:
@@ -728,22 +728,27 @@ def test_two_lane_sampler_is_bitwise_one_lane(dev, vae, math):
             assert torch.equal(lat, ref[0]) and torch.equal(series, ref[1]), (lanes, use_graph)
         lat2, series2 = s.run_inplace()
         assert torch.equal(lat2, ref[0]) and torch.equal(series2, ref[1])
-    # the automatic choice (two lanes from 128 series) against one lane, rectified flow
-    B = 128
-    text = synth.make_text_embeddings(6, B)
-    outs = []
-    for lanes in (1, 0):
-        s = Sampler(m, vae.decoder, "flowmatching", 4, 5.0, B, 96, dev, seed=3, lanes=lanes)
-        outs.append(s.run(text)[:2])
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    # the smallest batches two lanes can take (1 + 1 and 2 + 1 rows)
+    # the automatic choice (two lanes for multiples of 64 and for 32 / 96 series) against one lane, rectified flow
+    for B in (128, 32, 96):
+        text = synth.make_text_embeddings(6, B)
+        outs = []
+        for lanes in (1, 0):
+            s = Sampler(m, vae.decoder, "flowmatching", 4, 5.0, B, 96, dev, seed=3, lanes=lanes)
+            outs.append(s.run(text)[:2])
+            assert s.graph_lanes == (1 if lanes == 1 else 2), (B, lanes, s.graph_lanes)
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), B
+    s = Sampler(m, vae.decoder, "flowmatching", 4, 5.0, 48, 96, dev, seed=3, lanes=0)
+    s.run(synth.make_text_embeddings(6, 48))
+    assert s.graph_lanes == 1                                   # 48 does not split into whole 32-row groups: one lane
+    # the smallest batches several lanes can take (1 + 1, 2 + 1 rows; four lanes asked of 3 rows run as three)
     for B in (2, 3):
         text = synth.make_text_embeddings(7, B)
-        outs = [Sampler(m, vae.decoder, "ddpm", 3, 9.0, B, 96, dev, seed=5, lanes=lanes).run(text)[:2] for lanes in (1, 2)]
-        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), B
+        outs = [Sampler(m, vae.decoder, "ddpm", 3, 9.0, B, 96, dev, seed=5, lanes=lanes).run(text)[:2] for lanes in (1, 2, 4)]
+        for o in outs[1:]:
+            assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]), B
     # bad lane counts are refused with the library's error code, not clamped
-    assert L.lib().t2s_sampler_set_lanes(s.ptr, 3) != 0 and L.lib().t2s_sampler_set_lanes(s.ptr, -1) != 0
-    assert L.lib().t2s_sampler_set_lanes(s.ptr, 2) == 0
+    assert L.lib().t2s_sampler_set_lanes(s.ptr, 5) != 0 and L.lib().t2s_sampler_set_lanes(s.ptr, -1) != 0
+    assert L.lib().t2s_sampler_set_lanes(s.ptr, 4) == 0 and L.lib().t2s_sampler_set_lanes(s.ptr, 2) == 0
 
 
 # ---------------------------------------------------------------- 1000-step chain at the headline schedule

@@ -24,8 +24,8 @@ timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p
 cp /tmp/prof1_$tag/*/*kernel_stats.csv $out/${tag}_kernel_stats_lanes1.csv
 head -8 $out/${tag}_kernel_stats_lanes1.csv
 
-# the 32-series shard of an 8-GPU strong-scaling run (256 series / 8): launch shapes of its own (16-token row chain, one
-# attention head per CU, one sampler lane)
+# the 32-series shard of an 8-GPU strong-scaling run (256 series / 8): launch shapes of its own (two lanes of 16 series:
+# 16-token row chain, the two-workgroups-per-head attention kernel)
 echo "== rocprofv3 --kernel-trace --stats, --batch 32 (strong-scaling shard)"
 rm -rf /tmp/prof32_$tag
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof32_$tag -- python3 bench.py $S --no-strong --batch 32 > $out/${tag}_prof_bench_b32.json 2> $out/${tag}_prof32.err || exit 1

@@ -163,7 +163,7 @@ if ss:
               "rate up to launch skew between ranks.", ""]
 b32 = os.path.join(P, f"{tag}_kernel_stats_b32.csv")
 if os.path.exists(b32):
-    lines += ["### The 32-series shard under rocprofv3 (`bench.py --batch 32`, one lane, 16-token row chain, one attention head per CU)",
+    lines += ["### The 32-series shard under rocprofv3 (`bench.py --batch 32`: two lanes of 16 series, 16-token row chain, two-workgroups-per-head attention)",
               "", table(stats("kernel_stats_b32"), 9), ""]
 open(os.path.join(P, f"{tag}_summary.md"), "w").write("\n".join(lines))
 print("\n".join(lines[:16]))
