@@ -399,7 +399,7 @@ def main():
     ap.add_argument("--backbone", default="ddpm", choices=["ddpm", "flowmatching"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2, 3, 4],
-                    help="sampler lanes: 0 = the library's default (two half-batch chains on two streams when B is a multiple of 64 or 32 / 96), 1 .. 4")
+                    help="sampler lanes: 0 = the library's default (two half-batch chains on two streams when B is a multiple of 64 or B = 32; three at 96), 1 .. 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training leg reported as `train`")
     ap.add_argument("--no-strong", action="store_true",

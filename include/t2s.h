@@ -366,7 +366,7 @@ int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, const float* no
 /* Lanes of t2s_sampler_run: the rows of a batch never interact (infer.py:76-88), so the loop may run as two (up to four)
  * part batches, each a complete chain with its own hipGraph on its own stream (lanes 1.. on streams the sampler owns,
  * forked from / joined to `stream` inside the call), so that one chain's kernels fill the chip while the other's
- * drain.  Bitwise the same result.  lanes: 0 = automatic (two when the batch is a multiple of 64, or 32 or 96 series; env
+ * drain.  Bitwise the same result.  lanes: 0 = automatic (equal shares: two when the batch is a multiple of 64 or 32 series, three for 96; env
  * T2S_SAMPLER_LANES=<n> overrides), or 1 .. 4 chains of equal shares.  trace0 runs always use one lane. */
 int t2s_sampler_set_lanes(t2s_sampler* s, int lanes);
 /* Move the sampler to another shard position: global index of its first series (the Philox key of row r is

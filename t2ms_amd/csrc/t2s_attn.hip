@@ -456,11 +456,13 @@ int launch_attn_packed(const float* q, const float* k, const float* vT, float* o
         else
             n_cu = 256;
     }
-    // persistent from one head per CU on (32 series per GPU in a CFG pass = 256 heads: the shard size of an 8-GPU
-    // strong-scaling run); below that the two-workgroups-per-head kernel spreads a head over two CUs.
-    // T2S_ATTN_PERSIST_MIN=<heads> moves the switch point (A/B runs).
+    // persistent from two heads per CU on; below that the two-workgroups-per-head kernel spreads a head over two CUs and
+    // shares a CU with the other sampler lane's kernels.  (Round 3 first moved the switch to ONE head per CU for the
+    // 32-series shard of an 8-GPU strong-scaling run run as one chain -- 69 vs 75 us alone on the chip; with that shard
+    // now stepped as two lanes of 16 and the 64-series shard as two lanes of 32 = 256 heads each, the packed kernel wins
+    // again: 61.5 vs 59.8 series/s at 64 series, tools/strong_probe.py.)  T2S_ATTN_PERSIST_MIN=<heads> moves the switch.
     static const int persist_min = getenv("T2S_ATTN_PERSIST_MIN") ? atoi(getenv("T2S_ATTN_PERSIST_MIN")) : 0;
-    if (BH >= (persist_min > 0 ? persist_min : n_cu)) {
+    if (BH >= (persist_min > 0 ? persist_min : 2 * n_cu)) {
         // persistent: one 8-wave workgroup per CU walks the heads
         attn_fwd_persistent_kernel<<<n_cu, PERSIST_THREADS, ATT_LDS_BYTES, st>>>(q, k, vT, o, BH);
     } else {

@@ -368,11 +368,13 @@ struct t2s_sampler {
     static constexpr int MAX_LANES = 4;
     hipGraph_t graph[MAX_LANES] = {};
     hipGraphExec_t exec[MAX_LANES] = {};
-    hipStream_t side[MAX_LANES] = {};          // lanes 1 .. (index 0 unused: lane 0 runs on the caller's stream)
+    hipStream_t side[MAX_LANES] = {};          // lanes 1 .. (index 0 unused: lane 0 runs on the caller's stream); BORROWED
+                                               // from the per-device pool below, never destroyed by a sampler
     hipEvent_t ev_fork = nullptr, ev_join[MAX_LANES] = {};
-    // stream == NULL at the C ABI means the default stream, which cannot be captured: graph runs then go through a
-    // stream the sampler owns, forked from and joined to the default stream by events inside the call
-    hipStream_t own = nullptr;
+    // Runs with more than one lane -- and graph runs on the default stream (stream == NULL at the C ABI), which cannot be
+    // captured -- go through the library's pooled streams (lane 0 on pool stream 0), forked from and joined to the
+    // caller's stream by events inside the call
+    hipStream_t own = nullptr;    // borrowed from the pool
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     // pointers the captured graphs were built for
     float* g_x = nullptr;
@@ -381,6 +383,64 @@ struct t2s_sampler {
 };
 
 namespace {
+
+// The lanes' streams come from ONE pool per device, created together the first time a sampler needs it.  HIP maps
+// streams onto a few hardware queues (four by default) in creation order, and two lanes whose streams share a queue run
+// one after the other: with a capture stream per Sampler object (the Python wrapper's, then) lane 0 landed on lane 1's
+// queue for every fourth sampler a process built -- 52 instead of 61 series/s at 64 series, 58 instead of 62 at 96,
+// reproducibly by construction order (tools/strong_probe.py).  Four streams created back to back take four different
+// queues, and because lane 0 runs on pool stream 0 too, the caller's stream -- whatever queue it sits on -- only carries
+// the fork and the join ...  (GPU_MAX_HW_QUEUES=8 / 16 did not help and cost 3-5 % at 128 / 256.)
+// ... in THEORY: measured, pool streams 0 and 2 of four created back to back still shared a queue (96 series as three
+// lanes: 57.9 against 62.3 series/s).  So the pool is CALIBRATED once per device: a 100 us spin kernel on each of two
+// streams tells whether they overlap (the second started before the first ended); candidates are created until four
+// mutually concurrent streams are found (at most 12 candidates, ~10 ms once per process).
+__global__ void spin_kernel(unsigned long long ticks, unsigned long long* stamp) {
+    const unsigned long long t0 = wall_clock64();      // constant 100 MHz
+    if (threadIdx.x == 0) stamp[0] = t0;
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    if (threadIdx.x == 0) stamp[1] = wall_clock64();
+}
+
+bool streams_overlap(hipStream_t a, hipStream_t b, unsigned long long* stamps_dev) {
+    unsigned long long h[4] = {0, 0, 0, 0};
+    spin_kernel<<<1, 64, 0, a>>>(10000ull, stamps_dev);          // 100 us
+    spin_kernel<<<1, 64, 0, b>>>(10000ull, stamps_dev + 2);
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+    if (hipMemcpy(h, stamps_dev, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return false;
+    return h[2] < h[1] && h[0] < h[3];
+}
+
+hipStream_t* lane_streams() {
+    constexpr int ML = t2s_sampler::MAX_LANES;
+    static hipStream_t pool[16][ML] = {};
+    static bool ready[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (ready[dev]) return pool[dev];
+    unsigned long long* stamps = nullptr;
+    if (hipMalloc((void**)&stamps, 4 * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+    int have = 0;
+    hipStream_t spare[12] = {};
+    int n_spare = 0;
+    for (int c = 0; c < 12 && have < ML; ++c) {
+        hipStream_t cand = nullptr;
+        if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) break;
+        bool ok = true;
+        for (int l = 0; l < have && ok; ++l) ok = streams_overlap(pool[dev][l], cand, stamps);
+        if (ok) pool[dev][have++] = cand;
+        else spare[n_spare++] = cand;
+    }
+    // fewer than ML concurrent queues on this device / configuration: the remaining lanes share (correct, only slower)
+    for (int i = 0; have < ML && i < n_spare; ++i) pool[dev][have++] = spare[i], spare[i] = nullptr;
+    for (int i = 0; i < n_spare; ++i)
+        if (spare[i]) (void)hipStreamDestroy(spare[i]);
+    (void)hipFree(stamps);
+    (void)hipGetLastError();
+    if (have < ML) return nullptr;
+    ready[dev] = true;
+    return pool[dev];
+}
 
 // one loop iteration of rows [r0, r0 + n) of the batch on stream st, stepping the lane's counter
 int enqueue_step(t2s_sampler* s, float* x, const float* text, const float* noise, hipStream_t st, int lane, int r0,
@@ -418,17 +478,18 @@ void drop_graph(t2s_sampler* s) {
     s->lanes_cap = 0;
 }
 
-// lanes of this run: as asked for, or automatically TWO for two equal halves of whole 32-row groups (batch a multiple of
-// 64) and for 32 / 96 series (16 + 16, 64 + 32).  Measured with the round-3 kernels (tools/strong_probe.py, series/s with
-// 1 / 2 lanes): 256: 60.1 / 63.8, 128: 58.7 / 62.7, 96: 58.1 / 62.3, 64: 57.4 / 60.2, 32: 52.1 / 58.2 -- at the small sizes a
-// launch is mostly fixed cost, which the other lane's kernels cover.  Unequal splits of larger batches go either way
-// (224 = 128 + 96: 60.1 / 62.6, but 160 = 96 + 64: 59.4 / 57.7: the shorter lane finishes early and leaves a 96-series
-// chain alone) and splits without whole groups lose (48: 47.3 / 39.8, 16: 44.1 / 37.7: attention launches below one head
-// per CU), so those stay on one lane; three lanes 61.6 and four 60.4 at 256.
+// lanes of this run: as asked for, or automatically EQUAL shares of whole 32-row groups: two for a batch that is a
+// multiple of 64 (and 16 + 16 for 32 series), three for 96.  Measured with the round-3 kernels (tools/strong_probe.py,
+// series/s with one lane / the automatic choice): 256: 60.1 / 64.3, 192: 59.9 / 63.5, 128: 58.7 / 62.8, 96: 58.3 / 62.3,
+// 64: 57.4 / 61.5, 32: 52.1 / 58.4 -- at the small sizes a launch is mostly fixed cost, which the other lanes' kernels
+// cover.  Unequal lanes go either way (224 = 128 + 96: 60.1 / 62.6; 160 = 96 + 64: 59.4 / 57.7; 96 = 64 + 32: 55.6 when the
+// two lanes run DIFFERENT attention kernels -- a persistent workgroup fills a CU's registers and the other lane's packed
+// workgroups wait for it) and splits without whole groups lose (48: 47.3 / 39.8, 16: 44.1 / 37.7), so those stay on one
+// lane; three lanes 61.6 and four 60.4 at 256, three 61.2 at 192.
 int pick_lanes(const t2s_sampler* s, bool trace) {
     if (trace || s->cfg.batch < 2) return 1;
     const int B = s->cfg.batch;
-    int lanes = (B % 64 == 0 || B == 32 || B == 96) ? 2 : 1;
+    int lanes = (B % 64 == 0 || B == 32) ? 2 : (B == 96 ? 3 : 1);
     if (const char* e = getenv("T2S_SAMPLER_LANES")) lanes = atoi(e);
     if (s->lanes_req) lanes = s->lanes_req;
     lanes = lanes < 1 ? 1 : (lanes > t2s_sampler::MAX_LANES ? t2s_sampler::MAX_LANES : lanes);
@@ -508,12 +569,9 @@ extern "C" int t2s_sampler_graph_lanes(const t2s_sampler* s) { return (s && s->e
 extern "C" void t2s_sampler_destroy(t2s_sampler* s) {
     if (!s) return;
     drop_graph(s);
-    for (int l = 0; l < t2s_sampler::MAX_LANES; ++l) {
-        if (s->side[l]) (void)hipStreamDestroy(s->side[l]);
+    for (int l = 0; l < t2s_sampler::MAX_LANES; ++l)
         if (s->ev_join[l]) (void)hipEventDestroy(s->ev_join[l]);
-    }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
-    if (s->own) (void)hipStreamDestroy(s->own);
     if (s->ev_in) (void)hipEventDestroy(s->ev_in);
     if (s->ev_out) (void)hipEventDestroy(s->ev_out);
     void* bufs[] = {s->temb_table, s->coef, s->eps_u, s->eps_c, s->tvals, s->step, s->mod_table};
@@ -534,21 +592,28 @@ extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, cons
     int rc;
     int lanes = pick_lanes(s, trace0 != nullptr);
     const bool graph_ok = c.use_graph && !trace0;
-    const bool via_own = graph_ok && st == nullptr;   // the default stream cannot be captured: never a silent eager run
+    // the default stream cannot be captured (never a silent eager run), and several lanes run on streams created TOGETHER
+    // (distinct hardware queues): the caller's stream then only carries the fork and the join
+    hipStream_t const caller = st;
+    const bool via_own = (graph_ok && st == nullptr) || lanes > 1;
     if (via_own) {
         if (!s->own) {
-            T2S_HIP_CHECK(hipStreamCreateWithFlags(&s->own, hipStreamNonBlocking));
+            hipStream_t* pool = lane_streams();
+            T2S_REQUIRE(pool, "t2s_sampler_run: cannot create the lane streams");
+            s->own = pool[0];
             T2S_HIP_CHECK(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
             T2S_HIP_CHECK(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
         }
-        T2S_HIP_CHECK(hipEventRecord(s->ev_in, nullptr));
+        T2S_HIP_CHECK(hipEventRecord(s->ev_in, caller));
         T2S_HIP_CHECK(hipStreamWaitEvent(s->own, s->ev_in, 0));
         st = s->own;
     }
     if (lanes > 1 && !s->ev_fork) T2S_HIP_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
     for (int l = 1; l < lanes; ++l)
         if (!s->side[l]) {
-            T2S_HIP_CHECK(hipStreamCreateWithFlags(&s->side[l], hipStreamNonBlocking));
+            hipStream_t* pool = lane_streams();
+            T2S_REQUIRE(pool, "t2s_sampler_run: cannot create the lane streams");
+            s->side[l] = pool[l];
             T2S_HIP_CHECK(hipEventCreateWithFlags(&s->ev_join[l], hipEventDisableTiming));
         }
     // lane l steps rows [r0[l], r0[l] + nr[l]) on lst[l]
@@ -618,9 +683,9 @@ extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, cons
     if (series) {
         if ((rc = t2s_vae_decode(s->vae, x, series, nullptr, c.batch, c.length, st)) != T2S_OK) return rc;
     }
-    if (via_own) {      // whatever the caller queues on the default stream next sees the results
+    if (via_own) {      // whatever the caller queues on its stream next sees the results
         T2S_HIP_CHECK(hipEventRecord(s->ev_out, st));
-        T2S_HIP_CHECK(hipStreamWaitEvent(nullptr, s->ev_out, 0));
+        T2S_HIP_CHECK(hipStreamWaitEvent(caller, s->ev_out, 0));
     }
     return T2S_OK;
 }

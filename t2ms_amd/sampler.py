@@ -33,6 +33,20 @@ def loop_t_values(backbone: str, steps: int) -> torch.Tensor:
     raise ValueError("No backbone found")
 
 
+_STREAMS = {}
+
+
+def _sampler_stream(device) -> "torch.cuda.Stream":
+    """ONE capture stream per device for every Sampler of the process.  HIP maps streams onto a few hardware queues in
+    creation order and two streams on one queue run one after the other: with a stream per Sampler, lane 0 (this stream)
+    landed on the queue of lane 1 (the library's pooled stream, csrc/t2s_sampler.hip lane_streams) for every fourth Sampler
+    a process built -- 52 instead of 61 series/s at 64 series, reproducibly by construction order (tools/strong_probe.py)."""
+    key = str(torch.device(device))
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(torch.device(device))
+    return _STREAMS[key]
+
+
 def philox_normal(n_rows: int, row_elems: int, seed: int, stream_id: int, row0: int, device) -> torch.Tensor:
     """(n_rows, row_elems) N(0,1) draws of the library's Philox stream: element e of GLOBAL row row0 + r uses counter
     (e/4, row0 + r, stream_id), key = seed -- the same values however the rows are sharded over GPUs."""
@@ -48,7 +62,7 @@ def philox_normal(n_rows: int, row_elems: int, seed: int, stream_id: int, row0: 
 class Sampler:
     def __init__(self, model, decoder, backbone: str, steps: int, cfg_scale: float, batch: int, length: int,
                  device, use_graph: bool = True, seed: int = 2025, row0: int = 0, lanes: int = 0):
-        """lanes: 0 = automatic (two chains on two streams when the batch is a multiple of 64, or 32 / 96 series), 1 .. 4 -- see
+        """lanes: 0 = automatic (equal part-batch chains on own streams: two when the batch is a multiple of 64 or 32 series, three for 96), 1 .. 4 -- see
         t2s_sampler_set_lanes; a scheduling choice only, the results are bitwise the same."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -58,7 +72,7 @@ class Sampler:
         self.batch, self.length, self.seed, self.row0 = int(batch), int(length), int(seed), int(row0)
         self.use_graph = bool(use_graph)
         self.lanes = int(lanes)
-        self.stream = torch.cuda.Stream(self.device)
+        self.stream = _sampler_stream(self.device)
         self.ptr = None
         self._create()
 
