@@ -456,13 +456,14 @@ int launch_attn_packed(const float* q, const float* k, const float* vT, float* o
         else
             n_cu = 256;
     }
-    // persistent from two heads per CU on; below that the two-workgroups-per-head kernel spreads a head over two CUs and
-    // shares a CU with the other sampler lane's kernels.  (Round 3 first moved the switch to ONE head per CU for the
-    // 32-series shard of an 8-GPU strong-scaling run run as one chain -- 69 vs 75 us alone on the chip; with that shard
-    // now stepped as two lanes of 16 and the 64-series shard as two lanes of 32 = 256 heads each, the packed kernel wins
-    // again: 61.5 vs 59.8 series/s at 64 series, tools/strong_probe.py.)  T2S_ATTN_PERSIST_MIN=<heads> moves the switch.
+    // persistent from THREE heads per CU on; below that the two-workgroups-per-head kernel spreads a head over two CUs and
+    // shares a CU with the other sampler lane's kernels (a persistent workgroup fills the register file of its CU).
+    // Series/s with two sampler lanes, packed / persistent (tools/strong_probe.py, T2S_ATTN_PERSIST_MIN): 256 heads per
+    // launch (64 series) 61.5 / 59.8, 512 (128 series) 63.3-64.0 / 62.3-62.5, 768 (192) 62.3-62.6 / 63.2, 1024 (256)
+    // 63.1-63.4 / 63.9-64.1.  (Alone on the chip the persistent kernel wins from one head per CU: 69 vs 75 us at 256 heads --
+    // the switch sat there while the 32-series shard ran as one chain.)  T2S_ATTN_PERSIST_MIN=<heads> moves the switch.
     static const int persist_min = getenv("T2S_ATTN_PERSIST_MIN") ? atoi(getenv("T2S_ATTN_PERSIST_MIN")) : 0;
-    if (BH >= (persist_min > 0 ? persist_min : 2 * n_cu)) {
+    if (BH >= (persist_min > 0 ? persist_min : 3 * n_cu)) {
         // persistent: one 8-wave workgroup per CU walks the heads
         attn_fwd_persistent_kernel<<<n_cu, PERSIST_THREADS, ATT_LDS_BYTES, st>>>(q, k, vT, o, BH);
     } else {

@@ -127,11 +127,11 @@ def test_attention_packed_kernel_vs_oracle(dev):
 
 
 def test_attention_persistent_kernel_multi_item(dev):
-    """n_seq = 160 -> 1280 (head, part) items on a 512-workgroup persistent grid: 2-3 items per
-    workgroup, so the cross-item DMA ring, the Q prefetch and the per-item state reset are all
-    exercised (plus re-reference spikes in every head)."""
+    """n_seq = 200 -> 800 heads on the persistent grid of one workgroup per CU (the launcher goes persistent from three
+    heads per CU): 3-4 heads per workgroup, so the cross-head DMA ring, the Q prefetch and the per-head state reset are
+    all exercised (plus re-reference spikes in every head)."""
     rs = np.random.RandomState(22)
-    n_seq = 160
+    n_seq = 200
     BH = n_seq * 4
     q, k, v = (torch.from_numpy(rs.randn(BH, 480, 32).astype(np.float32)) for _ in range(3))
     k[:, 410] = q[:, 200] * 12.0
