@@ -359,7 +359,10 @@ void t2s_sampler_destroy(t2s_sampler* s);
  *   stream NULL = the default stream.  With use_graph = 1 the graphs are then captured and replayed on a stream
  *          the sampler owns (the default stream cannot be captured), ordered after everything queued on the default
  *          stream before the call and joined back to it before the call returns -- same semantics, never an eager
- *          fallback.  trace0 runs are eager by design (a decode between the steps).
+ *          fallback.  trace0 runs are eager by design (a decode between the steps).  Runs with more than one lane
+ *          (t2s_sampler_set_lanes) execute on the library's own pool of streams in the same way for ANY `stream`: the
+ *          run is ordered after everything queued on `stream` before the call and joined back to it before the call
+ *          returns.
  */
 int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, const float* noise,
                     float* series, float* trace0, void* stream);
