@@ -591,6 +591,7 @@ extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, cons
     const t2s_sample_config& c = s->cfg;
     int rc;
     int lanes = pick_lanes(s, trace0 != nullptr);
+    if (lanes > 1 && !lane_streams()) lanes = 1;      // no stream pool on this device: one chain, same results
     const bool graph_ok = c.use_graph && !trace0;
     // the default stream cannot be captured (never a silent eager run), and several lanes run on streams created TOGETHER
     // (distinct hardware queues): the caller's stream then only carries the fork and the join
