@@ -457,7 +457,7 @@ def main():
         "config": {"workload": f"{'configs[1]' if (args.backbone, args.diffusion_steps, B) == ('ddpm', 1000, 256) else 'custom'}: DiT denoiser, {args.diffusion_steps}-step {args.backbone} with CFG "
                                f"(2 forwards/step), B={B}/GPU, L={args.length}, cfg_scale={args.cfg_scale}, "
                                f"LA-VAE decode; Philox noise on device; hipGraph={'off' if args.no_graph else 'on'}; "
-                               f"sampler lanes={lanes_used} (half-batch chains on own streams, include/t2s.h t2s_sampler_set_lanes)",
+                               f"sampler lanes={lanes_used} (part-batch chains on own streams, include/t2s.h t2s_sampler_set_lanes)",
                    "global_batch": B * world, "diffusion_steps": args.diffusion_steps, "parallelism": f"batch-shard x{world}",
                    "sampler_lanes": lanes_used},
     }
