@@ -379,6 +379,10 @@ int t2s_sampler_set_row0(t2s_sampler* s, uint32_t row0);
 /* Number of lanes the sampler currently holds an instantiated hipGraph for (0: the last run was eager / nothing run
  * yet).  Lets a caller (and tests/test_hip_parity.py) check that use_graph = 1 really replays a graph. */
 int t2s_sampler_graph_lanes(const t2s_sampler* s);
+/* How many MUTUALLY CONCURRENT streams the calibration of the current device's lane-stream pool found (0: the pool has
+ * not been built yet -- it is built by the first multi-lane or NULL-stream graph run; 4: every lane has a hardware queue
+ * of its own).  Diagnostic: HIP streams that share a hardware queue execute one after the other. */
+int t2s_sampler_lane_pool(void);
 
 /* ------------------------------------------------------------------------ *
  * Evaluation metrics: evaluation.py:166-206 (calculate_mse, calculate_wape), :21-45 (calculate_mrr)

@@ -131,6 +131,7 @@ SYMBOLS = {
     "t2s_sampler_set_lanes": (_I, [_VP, _I]),
     "t2s_sampler_set_row0": (_I, [_VP, _U32]),
     "t2s_sampler_graph_lanes": (_I, [_VP]),
+    "t2s_sampler_lane_pool": (_I, []),
 }
 
 _lib: Optional[C.CDLL] = None

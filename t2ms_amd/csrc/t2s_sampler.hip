@@ -411,6 +411,8 @@ bool streams_overlap(hipStream_t a, hipStream_t b, unsigned long long* stamps_de
     return h[2] < h[1] && h[0] < h[3];
 }
 
+int g_lane_pool_concurrent[16] = {};      // per device: mutually concurrent streams the calibration found
+
 hipStream_t* lane_streams() {
     constexpr int ML = t2s_sampler::MAX_LANES;
     static hipStream_t pool[16][ML] = {};
@@ -431,6 +433,7 @@ hipStream_t* lane_streams() {
         if (ok) pool[dev][have++] = cand;
         else spare[n_spare++] = cand;
     }
+    g_lane_pool_concurrent[dev] = have;
     // fewer than ML concurrent queues on this device / configuration: the remaining lanes share (correct, only slower)
     for (int i = 0; have < ML && i < n_spare; ++i) pool[dev][have++] = spare[i], spare[i] = nullptr;
     for (int i = 0; i < n_spare; ++i)
@@ -562,6 +565,12 @@ extern "C" int t2s_sampler_set_row0(t2s_sampler* s, uint32_t row0) {
     T2S_REQUIRE(s, "t2s_sampler_set_row0: NULL sampler");
     s->cfg.row0 = row0;   // uploaded next to the step counters at the start of every run: no re-capture
     return T2S_OK;
+}
+
+extern "C" int t2s_sampler_lane_pool(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+    return g_lane_pool_concurrent[dev];
 }
 
 extern "C" int t2s_sampler_graph_lanes(const t2s_sampler* s) { return (s && s->exec[0]) ? s->lanes_cap : 0; }

@@ -746,6 +746,9 @@ def test_two_lane_sampler_is_bitwise_one_lane(dev, vae, math):
         outs = [Sampler(m, vae.decoder, "ddpm", 3, 9.0, B, 96, dev, seed=5, lanes=lanes).run(text)[:2] for lanes in (1, 2, 4)]
         for o in outs[1:]:
             assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]), B
+    # the lanes ran on the library's calibrated stream pool: at least two of its streams really overlap on this device
+    # (HIP streams that share a hardware queue execute one after the other -- DESIGN.md 4.5)
+    assert L.lib().t2s_sampler_lane_pool() >= 2
     # bad lane counts are refused with the library's error code, not clamped
     assert L.lib().t2s_sampler_set_lanes(s.ptr, 5) != 0 and L.lib().t2s_sampler_set_lanes(s.ptr, -1) != 0
     assert L.lib().t2s_sampler_set_lanes(s.ptr, 4) == 0 and L.lib().t2s_sampler_set_lanes(s.ptr, 2) == 0
