@@ -1154,7 +1154,11 @@ int t2s_dit_train_backward(t2s_dit* h, const float* dout, const t2s_dit_grads* g
     // (Measured and dropped in round 2: the four weight gradients of a block on a side stream.  Issued as soon as their
     // operands exist they only share the HBM bandwidth with the GEMM / LayerNorm kernels they run beside (13.42 ms per step,
     // the same as in order); issued beside the VALU-bound attention backward they slow it by more than they take alone
-    // (attention backward 3.0 -> 4.4 ms per step, 14.1 ms per step): the attention workgroups fill the CUs.)
+    // (attention backward 3.0 -> 4.4 ms per step, 14.1 ms per step): the attention workgroups fill the CUs.
+    // Round 3 repeated both as timing-only builds on a stream CALIBRATED to run concurrently (t2s_sampler.hip lane_streams:
+    // HIP streams that share a hardware queue serialise, which may have been the "same as in order" of round 2): without any
+    // dependency waits 10.92 vs 11.10 ms in order, issued beside the attention backward 11.08 -- the attention backward then
+    // takes 3.1-3.7 instead of 2.2 ms: it is bound by vector issue, but its 16 waves per CU leave the other kernel no slot.)
     for (int i = NBLK - 1; i >= 0 && bf; --i) {
         const int base = i * MODW;
         const t2s_dit_block_grads& b = g->blk[i];
