@@ -6,6 +6,7 @@
 // into a hipGraph and replayed `steps` times; everything that changes from step to step
 // (time-embedding row, DDPM coefficients, noise stream / injected-noise slice) is looked up on
 // the device through a step counter that the last node of the graph advances.
+#include <mutex>
 #include <stdlib.h>
 #include <vector>
 
@@ -417,6 +418,8 @@ hipStream_t* lane_streams() {
     constexpr int ML = t2s_sampler::MAX_LANES;
     static hipStream_t pool[16][ML] = {};
     static bool ready[16] = {};
+    static std::mutex guard;                    // the pool is process-wide: samplers of different threads may meet here
+    std::lock_guard<std::mutex> lock(guard);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     if (ready[dev]) return pool[dev];
