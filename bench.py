@@ -22,6 +22,7 @@ oracle on the host cores, N=1 only: 3 warm + 10 measured CFG steps), `alt_math` 
 `train` (BASELINE configs[3] shape: the bf16 DiT training step of train.py at B=1152 per GPU with the gradient all-reduce at N>1).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -363,6 +364,102 @@ def strong_leg(model, vae, args, dev, dist, rank, world):
             "per_gpu_batch": args.batch // world, "ms_per_step": el / args.steps * 1e3, "steps": args.steps}
 
 
+def infer_driver_leg(dev, dist, rank, world, rows=2048):
+    """infer.py ITSELF at the flags the authors script (reference scripts/script.sh:4: `infer.py --dataset_name
+    exchangerate_24 --cfg_scale 7.0 --total_step 100`, i.e. flowmatching, the default --batch_size 2) on `rows` synthetic
+    test rows with seeded weights: dataset + loader order + encode + coalesced sampler launches + decode + the final
+    gather + D2H, and separately the whole main() incl. model construction, graph capture and writing the four .npy
+    files.  Beside it the same shape as ONE resident sampler (B = 256, 100 RF steps, cfg 7): what the kernels allow."""
+    import shutil
+    import tempfile
+    import infer as drv
+    from t2ms_amd import dist as tdist
+    from t2ms_amd import synth
+    from t2ms_amd.sampler import Sampler
+    tmp = tempfile.mkdtemp(prefix="t2s_bench_infer_") if rank == 0 else None
+    tmp = tmp if dist is None else _bcast_obj(dist, tmp)
+    argv = ["--dataset_name", "exchangerate_24", "--cfg_scale", "7.0", "--total_step", "100", "--synthetic", str(rows),
+            "--random_init", "--seed", "2025", "--save_path", tmp, "--no_figs"]
+    try:
+        tdist.barrier(dist, dev)
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(sys.stderr):        # stdout carries the ONE result line only
+            a = drv.main(argv)
+        tdist.barrier(dist, dev)
+        wall = tdist.max_over_ranks(dist, time.perf_counter() - t0, dev)
+        st = a.stats
+    finally:
+        if rank == 0:
+            shutil.rmtree(tmp, ignore_errors=True)
+    out = {"metric": "infer.py at the authors' flags (scripts/script.sh:4): flowmatching, 100 steps, cfg 7, --batch_size 2, L=24",
+           "value": st["series"] / st["loop_s"], "unit": "series/s", "series": st["series"], "loop_s": st["loop_s"],
+           "whole_main_s": wall, "whole_main_series_per_s": st["series"] / wall, "launches": st["launches"],
+           "series_per_launch_and_gpu": st["series_per_launch_and_gpu"], "loader_batch": st["loader_batch"], "n_gpus": world,
+           "data": f"synthetic ({rows} test rows)",
+           "note": "loop = resident test split -> encode -> coalesced sampler launches -> decode -> final gather -> host; "
+                   "whole_main adds model construction, hipGraph capture and np.save of the four files (the ten jpg plots skipped)"}
+    if rank == 0:       # the kernels' own rate at this shape: one resident 256-series sampler, same steps / cfg / length
+        model, vae = build_models(dev)
+        s = Sampler(model, vae.decoder, "flowmatching", 100, 7.0, 256, 24, dev, use_graph=True, seed=2025, row0=0)
+        s.run(synth.make_text_embeddings(2025, 256).to(dev), decode=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            s.run_inplace(decode=True)
+        torch.cuda.synchronize(dev)
+        ref = 3 * 256 / (time.perf_counter() - t0)
+        out["resident_sampler_b256_series_per_s"] = ref
+        out["frac_of_resident_sampler"] = out["value"] / (ref * world)
+    return out
+
+
+def _bcast_obj(dist, obj, src=0):
+    box = [obj]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def train_driver_leg(dev, dist, rank, world, rows_per_length=200_000, batch=9216, warm_batches=2, timed_batches=8):
+    """train.py's OWN loop (reference train.py:52-95 shape: mix-train, the default --batch_size 9216 split by the collate
+    into three length groups per batch) on 3 x `rows_per_length` synthetic rows, latent cache on, bf16, DDPM T=100: loader
+    order, row gathers, the rank's slice, q_sample, forward, loss, backward, all-reduce, AdamW, loss bookkeeping -- the
+    clock starts after `warm_batches` loader batches and stops after `timed_batches` more (device drained at both ends)."""
+    import shutil
+    import tempfile
+    import train as drv
+    from t2ms_amd import dist as tdist
+    tmp = tempfile.mkdtemp(prefix="t2s_bench_train_")
+    argv = ["--dataset_name", "ETTh1", "--backbone", "ddpm", "--batch_size", str(batch), "--epochs", "1", "--save_path", tmp,
+            "--synthetic", str(rows_per_length), "--random_init", "--checkpoint_path", "", "--seed", "2025", "--bf16",
+            "--max_steps", str(3 * (warm_batches + timed_batches))]
+    a = drv.get_args(argv)
+    clock = {}
+
+    def on_step(n, n_rows):
+        if n == 3 * warm_batches:
+            torch.cuda.synchronize(dev)
+            clock["t0"], clock["rows"] = time.perf_counter(), 0
+        elif n > 3 * warm_batches:
+            clock["rows"] += n_rows
+            if n == 3 * (warm_batches + timed_batches):
+                torch.cuda.synchronize(dev)
+                clock["t1"] = time.perf_counter()
+
+    a.on_step = on_step
+    try:
+        with contextlib.redirect_stdout(sys.stderr):
+            losses = drv.train(a)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    el = tdist.max_over_ranks(dist, clock["t1"] - clock["t0"], dev)
+    steps = 3 * timed_batches
+    return {"metric": "train.py's own loop: mix-train, --batch_size 9216 (three length groups per batch), latent cache, bf16, DDPM T=100",
+            "value": clock["rows"] / el, "unit": "samples/s", "ms_per_step": el / steps * 1e3, "steps": steps,
+            "rows_per_step": clock["rows"] / steps, "rows_per_step_and_gpu": clock["rows"] / steps / world,
+            "dataset_rows": 3 * rows_per_length, "n_gpus": world, "loss": losses[-1] if losses else None,
+            "data": "synthetic", "data_path": "resident tables (datafactory.epoch_index_batches; train.py --loader_batches walks the DataLoader instead)"}
+
+
 def alt_math_run(model, vae, args, dev, text):
     """One extra batch of the same workload in bf16x3 arithmetic (include/t2s.h T2S_MATH_BF16X3: fp32-accurate,
     six bf16 MFMAs per product, attention and row chain).  Reported NEXT TO the headline, never as it."""
@@ -387,6 +484,40 @@ def alt_math_run(model, vae, args, dev, text):
             "bf16_dense_peak_tflops": 2500.0}
 
 
+def spawn_ranks(n_gpus, argv=None):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves, one FRESH process per
+    GPU (`python -m torch.distributed.run --nproc-per-node N bench.py <same flags>` as a CHILD -- never an exec: this
+    parent has made no GPU call, and it stays a plain launcher that relays rank 0's JSON line and the child's exit
+    code).  Rendezvous on 127.0.0.1 at a port the kernel just handed out."""
+    import socket
+    import subprocess
+    argv = list(sys.argv[1:] if argv is None else argv)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n_gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)    # stderr passes through
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.rstrip("\n")               # rank 0's ONE result line, printed once the job has ended cleanly
+        else:
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        print("bench.py: the ranks exited cleanly but rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    if line is not None and rc == 0:
+        print(line, flush=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -405,6 +536,9 @@ def main():
     ap.add_argument("--no-strong", action="store_true",
                     help="skip the strong-scaling figures (N = 1: `strong_shards`, the per-GPU shards 128 / 64 / 32 of a "
                          "256-series job timed on this GPU; N > 1: `strong`, the 256 series split over the ranks)")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="skip the driver legs: `infer_driver` (infer.py at the authors' flags), `train_driver` (train.py's own "
+                         "mix-train loop) and `class_api` (the reference-style loop against the mirrored classes)")
     ap.add_argument("--train-batch", type=int, default=1152, help="per-GPU batch of the training leg")
     ap.add_argument("--train-steps", type=int, default=30)
     ap.add_argument("--no-alt-math", action="store_true", help="skip the extra bf16x3 measurement reported as alt_math")
@@ -414,9 +548,9 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))       # plain `python bench.py --gpus N`: this process becomes the launcher
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
@@ -472,6 +606,15 @@ def main():
             import traceback
             traceback.print_exc()
             train = {"error": f"{type(e).__name__}: {e}"}
+    legs = {}
+    if not args.no_legs:
+        for name, fn in (("infer_driver", infer_driver_leg), ("train_driver", train_driver_leg)):
+            try:
+                legs[name] = fn(dev, dist, rank, world)
+            except Exception as e:      # the headline line must still be printed; the failure is reported in it
+                import traceback
+                traceback.print_exc()
+                legs[name] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         # roofline of the dominant kernel (fused attention; 48 % of all FLOPs), same shapes as the workload
         kt = time_kernels_in_situ(model, dev, lat.clone(), text)
@@ -519,6 +662,9 @@ def main():
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         if train is not None:
             out["train"] = train
+            if "value" in train and "value" in legs.get("train_driver", {}):
+                legs["train_driver"]["frac_of_train_leg"] = legs["train_driver"]["value"] / train["value"]
+        out.update(legs)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -94,3 +94,52 @@ def loader_provider(args, period):
     else:
         ds = T2SDataset(name=csv_name(name), data_root=_root_for(name, False), period=period)
     return ds, DataLoader(ds, batch_size=args.batch_size, shuffle=True, drop_last=True)
+
+
+# ------------------------------------------------------------------ the loader's ORDER without the loader's per-row work
+def epoch_index_batches(loader) -> torch.Tensor:
+    """The index batches ONE `for data in loader` pass would visit, as an (n_batches, batch_size) int64 tensor, consuming
+    the global CPU generator exactly as that pass does -- so a driver may mix this with real passes over the same loader.
+
+    A single-process `DataLoader(shuffle=True, drop_last=True)` (dataloader.py:99,111 of the reference) draws, per pass:
+    one int64 from the global generator when the iterator is built (its `_base_seed`), one more when the first batch is
+    asked for (`RandomSampler.__iter__`: the seed of a private generator), then `torch.randperm(n)` from that private
+    generator; batch k is rows perm[k * B : (k + 1) * B].  No dataset row is touched here: the drivers gather rows from
+    resident tensors instead of running `__getitem__` + collate per row (tests/test_host_logic.py pins this against a
+    real pass)."""
+    n, bs = len(loader.dataset), int(loader.batch_size)
+    torch.empty((), dtype=torch.int64).random_(generator=loader.generator)          # _BaseDataLoaderIter._base_seed
+    if loader.generator is None:
+        g = torch.Generator()
+        g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))     # RandomSampler.__iter__
+    else:
+        g = loader.generator
+    perm = torch.randperm(n, generator=g)
+    nb = n // bs if loader.drop_last else -(-n // bs)
+    if nb * bs > n:          # drop_last=False with a ragged tail: not a shape the T2S drivers build
+        raise ValueError("epoch_index_batches: ragged last batch (drop_last=False) is not supported")
+    return perm[: nb * bs].view(nb, bs)
+
+
+def resident_tables(dataset):
+    """-> list of (series float64 (N,L) ndarray, embeddings float64 (N,128) ndarray, first index in the concatenation) per
+    leaf dataset, in AlternatingDataset order (24, 48, 96) or a single entry for a plain dataset."""
+    leaves = dataset.datasets if hasattr(dataset, "datasets") else [dataset]
+    out, start = [], 0
+    for d in leaves:
+        out.append((d.samples, d.embedding, start))
+        start += len(d)
+    return out
+
+
+def group_by_dataset(idx: torch.Tensor, starts) -> list:
+    """custom_collate_fn's grouping (dataloader.py:115-133) on an index batch: [(which, rows within that dataset)] in
+    dataset order, each group's rows in batch order; empty groups are skipped."""
+    bounds = torch.as_tensor(list(starts[1:]), dtype=torch.int64)
+    which = torch.bucketize(idx, bounds, right=True)
+    out = []
+    for w in range(len(starts)):
+        sel = idx[which == w]
+        if sel.numel():
+            out.append((w, sel - int(starts[w])))
+    return out

@@ -10,7 +10,13 @@ Differences from the reference, all additive:
     noise stream; results do not depend on the number of GPUs;
   * `--synthetic N` / `--random_init` let the driver run without the (offline-unavailable) CSVs and
     trained checkpoints;
-  * under torchrun every rank samples rows [lo,hi) of each batch, rank 0 gathers and writes;
+  * loader batches are coalesced: the reference samples one loader batch per launch (default
+    `--batch_size 2`, a 4-sequence CFG pass); here the same rows in the same order go `--launch_batch`
+    (256) per GPU at a time -- rows are independent and the kernels batch-invariant bit for bit, so
+    the files do not change by a byte (`--launch_batch 0` = the reference's launch shape).  The test
+    split, its embeddings and every output stay in HBM; the host touches no row inside the loop;
+  * under torchrun every rank samples rows [lo,hi) of each launch and keeps them in HBM; the ranks
+    meet in ONE gather at the end (a rank without rows joins empty-handed), rank 0 writes;
   * the per-step decode of the first batch (infer.py:90-93, GIF only) is `--trace`, off by default.
 """
 import argparse
@@ -26,7 +32,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-from datafactory.dataloader import loader_provider            # noqa: E402
+from datafactory.dataloader import epoch_index_batches, loader_provider, resident_tables   # noqa: E402
 from model.backbone.DDPM import DDPM                          # noqa: E402,F401  (API parity)
 from model.backbone.rectified_flow import RectifiedFlow      # noqa: E402,F401
 from model.denoiser.transformer import Transformer            # noqa: E402
@@ -100,6 +106,16 @@ def sample_mlp_config1(model, vae, backbone, x_1, embedding, args, device, row0)
     return x_t, series.reshape(B, -1), z_enc
 
 
+def launch_plan(n_rows, loader_batch, launch_batch, world):
+    """Global row ranges [(s0, s1)] of the sampler launches.  The reference launches once per loader batch
+    (infer.py:66-95; default --batch_size 2 = a 4-sequence CFG pass); rows are independent through the whole loop and the
+    kernels are batch-invariant bit for bit, so the SAME rows in the SAME order may be sampled `launch_batch` per GPU at a
+    time (default 256: the chip-filling shape) without changing a byte of the output.  launch_batch = 0 keeps the
+    reference's launch shape (one launch per loader batch)."""
+    per = loader_batch if launch_batch <= 0 else launch_batch * world
+    return [(s0, min(s0 + per, n_rows)) for s0 in range(0, n_rows, per)]
+
+
 def infer(args):
     device = torch.device(args.device)
     rank, local_rank, world = tdist.env_world()
@@ -117,58 +133,93 @@ def infer(args):
     torch.manual_seed(args.seed)          # identical loader shuffle on every rank
     dataset, dataloader = loader_provider(args, period="test")
     model, vae = _load_models(args, device)
-    if args.denoiser == "DiT":
+    is_mlp = args.denoiser == "MLP"
+    if not is_mlp:
         model.set_math(getattr(args, "math", "f32"))
 
-    x1_all, xt_all, lat_dec_all, lat_enc_all, trace = [], [], [], [], None
-    sampler, t_start, n_series = None, time.time(), 0
-    with torch.no_grad():
-        for batch, (y, x_1, embedding) in enumerate(dataloader):
-            B, L = x_1.shape[0], x_1.shape[-1]
-            lo, hi = tdist.shard_rows(B, rank, world)
-            x_1 = x_1.float().to(device)
-            embedding = embedding.float().to(device)
-            if args.denoiser == "MLP":
-                lat, series, z_enc = sample_mlp_config1(model, vae, backbone, x_1[lo:hi], embedding[lo:hi], args, device,
-                                                        n_series + lo)
-                lat = torch.nn.functional.pad(lat, (0, 30 - lat.shape[2]))      # the .npy layout is (N,64,30): zero-padded
-                series = tdist.gather_rows(dist, series, B, rank, world)
-                lat = tdist.gather_rows(dist, lat, B, rank, world)
-                z_enc = tdist.gather_rows(dist, z_enc, B, rank, world)
-                n_series += B
-                if rank == 0:
-                    print(f"Generating {batch}th Batch TS...  ({n_series / (time.time() - t_start):.1f} series/s)")
-                    x1_all.append(x_1.cpu().numpy().squeeze())
-                    xt_all.append(series.cpu().numpy().squeeze())
-                    lat_dec_all.append(lat.cpu().numpy().squeeze())
-                    lat_enc_all.append(z_enc.cpu().numpy().squeeze())
-                continue
-            z_enc, _ = model.encoder(x_1[lo:hi].contiguous())                      # infer.py:73-74
-            if sampler is None or sampler.batch != hi - lo or sampler.length != L:
-                sampler = Sampler(model, vae.decoder, backbone, args.total_step, args.cfg_scale, hi - lo, L,
-                                  device, use_graph=True, seed=args.seed, row0=0)
-            sampler.set_row0(n_series + lo)       # global row index of this shard's first series; the graph is kept
-            want_trace = bool(args.trace) and batch == 0 and rank == 0
-            lat, series, tr = sampler.run(embedding[lo:hi].contiguous(), decode=True, trace=want_trace)
-            if want_trace:
-                trace = tr.cpu().numpy()
-            series = tdist.gather_rows(dist, series, B, rank, world)
-            lat = tdist.gather_rows(dist, lat, B, rank, world)
-            z_enc = tdist.gather_rows(dist, z_enc, B, rank, world)
-            n_series += B
-            if rank == 0:
-                print(f"Generating {batch}th Batch TS...  ({n_series / (time.time() - t_start):.1f} series/s)")
-                x1_all.append(x_1.cpu().numpy().squeeze())
-                xt_all.append(series.cpu().numpy().squeeze())
-                lat_dec_all.append(lat.cpu().numpy().squeeze())
-                lat_enc_all.append(z_enc.cpu().numpy().squeeze())
+    # The loader's ORDER without the loader's per-row work (datafactory.epoch_index_batches draws what one pass over
+    # the DataLoader draws): output row i is dataset row order[i], exactly the concatenation of the reference's batches
+    # (shuffle=True, drop_last=True, infer.py:66; N = floor(test / B) * B rows).  The test split lives in HBM.
+    batches = epoch_index_batches(dataloader)
     if rank == 0:
-        if not x1_all:
-            raise RuntimeError("the test loader produced no full batch (drop_last=True): lower --batch_size")
-        x_1 = np.concatenate([a.reshape(-1, a.shape[-1]) for a in x1_all], axis=0)
-        x_t = np.concatenate([a.reshape(-1, a.shape[-1]) for a in xt_all], axis=0)
-        lat_dec = np.concatenate([a.reshape(-1, 64, 30) for a in lat_dec_all], axis=0)
-        lat_enc = np.concatenate([a.reshape(-1, 64, 30) for a in lat_enc_all], axis=0)
+        print("dataset length:", batches.shape[0])
+    if batches.shape[0] == 0:
+        raise RuntimeError("the test loader produced no full batch (drop_last=True): lower --batch_size")
+    order = batches.reshape(-1)
+    n_rows, B = int(order.numel()), int(batches.shape[1])
+    (series_tab, emb_tab, _), = resident_tables(dataset)
+    x1_host = torch.as_tensor(series_tab)[order].float()              # (N, L) fp32: what `x_1.float()` gives per batch
+    L = int(x1_host.shape[1])
+    x1_dev = x1_host.to(device)
+    emb_dev = torch.as_tensor(emb_tab)[order].float().to(device)
+    # MLP (plumbing, a torch module): one launch per loader batch, as the reference; DiT: coalesced launches
+    plan = launch_plan(n_rows, B, 0 if is_mlp else int(getattr(args, "launch_batch", 256)), world)
+    flush_rows = int(os.environ.get("T2S_INFER_FLUSH_ROWS", str(1 << 17)))     # outputs stay in HBM this long (16 KB / row)
+
+    out = None
+    if rank == 0:
+        out = (np.empty((n_rows, L), np.float32), np.empty((n_rows, 64, 30), np.float32),
+               np.empty((n_rows, 64, 30), np.float32))
+    held, held_chunks, trace, samplers = [], [], None, {}
+    t_start = time.time()
+
+    def flush():
+        """Collective: every rank hands over the rows it sampled since the last flush (ONE all_gather of the packed
+        (rows, L + 2 * 1920) tensor; a rank without rows joins with an empty tensor) and rank 0 files them by global row."""
+        if not held_chunks:
+            return
+        counts = [sum(tdist.shard_rows(s1 - s0, r, world)[1] - tdist.shard_rows(s1 - s0, r, world)[0]
+                      for s0, s1 in held_chunks) for r in range(world)]
+        mine = torch.cat(held, dim=0) if held else torch.empty(0, L + 2 * 1920, device=device)
+        parts = tdist.gather_ragged(dist, mine, counts, rank)
+        if rank == 0:
+            for r, part in enumerate(parts):
+                if counts[r] == 0:
+                    continue
+                dest = torch.cat([torch.arange(s0 + tdist.shard_rows(s1 - s0, r, world)[0],
+                                               s0 + tdist.shard_rows(s1 - s0, r, world)[1]) for s0, s1 in held_chunks])
+                p = part.cpu().numpy()
+                d = dest.numpy()
+                out[0][d] = p[:, :L]
+                out[1][d] = p[:, L:L + 1920].reshape(-1, 64, 30)
+                out[2][d] = p[:, L + 1920:].reshape(-1, 64, 30)
+        held.clear()
+        held_chunks.clear()
+
+    with torch.no_grad():
+        for k, (s0, s1) in enumerate(plan):
+            lo, hi = tdist.shard_rows(s1 - s0, rank, world)
+            n = hi - lo
+            if n > 0:                     # a rank without rows in this launch (fewer rows than GPUs) only joins the flush
+                x_1, embedding = x1_dev[s0 + lo:s0 + hi], emb_dev[s0 + lo:s0 + hi]
+                if is_mlp:
+                    lat, series, z_enc = sample_mlp_config1(model, vae, backbone, x_1, embedding, args, device, s0 + lo)
+                    lat = torch.nn.functional.pad(lat, (0, 30 - lat.shape[2]))      # the .npy layout is (N,64,30): zero-padded
+                else:
+                    z_enc, _ = model.encoder(x_1.contiguous())                      # infer.py:73-74
+                    sampler = samplers.get(n)
+                    if sampler is None:
+                        sampler = samplers[n] = Sampler(model, vae.decoder, backbone, args.total_step, args.cfg_scale, n, L,
+                                                        device, use_graph=True, seed=args.seed, row0=0)
+                    sampler.set_row0(s0 + lo)     # global row index of this shard's first series; the graph is kept
+                    want_trace = bool(args.trace) and k == 0 and rank == 0
+                    lat, series, tr = sampler.run(embedding.contiguous(), decode=True, trace=want_trace)
+                    if want_trace:
+                        trace = tr.cpu().numpy()
+                held.append(torch.cat([series.reshape(n, L), lat.reshape(n, 1920), z_enc.reshape(n, 1920)], dim=1))
+            held_chunks.append((s0, s1))
+            if rank == 0:
+                print(f"Generating {k}th Batch TS...  (rows {s0}..{s1 - 1} of {n_rows}, {s1 - s0} series per launch)")
+            if sum(b - a for a, b in held_chunks) >= flush_rows:
+                flush()
+        flush()
+    tdist.barrier(dist, device)
+    loop_s = time.time() - t_start
+    args.stats = {"series": n_rows, "loop_s": loop_s, "launches": len(plan), "loader_batch": B, "gpus": world,
+                  "series_per_launch_and_gpu": (plan[0][1] - plan[0][0]) // world}
+    if rank == 0:
+        x_1, (x_t, lat_dec, lat_enc) = x1_host.numpy(), out
+        print(f"{n_rows} series in {loop_s:.2f} s ({n_rows / loop_s:.1f} series/s)")
         np_save_outputs(args.generation_save_path_result, x_1, x_t, lat_dec, lat_enc)   # infer.py:118-123
         if trace is not None:
             np.save(os.path.join(args.generation_save_path_result, "x_infer_trace.npy"), trace)
@@ -209,6 +260,10 @@ def build_parser():
     p.add_argument("--synthetic", type=int, default=0, help="serve N synthetic rows instead of the CSV")
     p.add_argument("--random_init", action="store_true", help="seeded synthetic weights instead of checkpoints")
     p.add_argument("--trace", action="store_true", help="decode row 0 after every step of the first batch")
+    p.add_argument("--no_figs", action="store_true", help="skip the ten fig_i.jpg plots (infer.py:157-163)")
+    p.add_argument("--launch_batch", type=int, default=256,
+                   help="series per GPU and sampler launch: loader batches are coalesced into launches of this size (same "
+                        "rows, same order, same bytes in the files); 0 = one launch per loader batch as the reference")
     p.add_argument("--math", default="f32", choices=["f32", "bf16x3"],
                    help="matrix arithmetic of the DiT: f32 MFMA (default) or fp32-accurate split-bf16 products (faster)")
     return p
@@ -239,8 +294,9 @@ def main(argv=None):
             args.generation_save_path_result = os.path.join(args.generation_save_path, f"run_{run_index}")
             args.seed += 1
             out = infer(args)
-    if out is not None:
+    if out is not None and not args.no_figs:
         _save_figs(args.generation_save_path, out[0], out[1])
+    return args
 
 
 if __name__ == "__main__":

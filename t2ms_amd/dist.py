@@ -129,3 +129,22 @@ def gather_rows(dist, local: torch.Tensor, total: int, rank: int, world: int) ->
     if rank != 0:
         return None
     return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(outs, sizes)], dim=0).to(local.device)
+
+
+def gather_ragged(dist, local: torch.Tensor, counts: List[int], rank: int) -> Optional[List[torch.Tensor]]:
+    """Per-rank (counts[r], ...) tensors -> on rank 0 the list of every rank's tensor (None elsewhere).  `counts` is known
+    on every rank (the shard sizes are a function of the job, not of the data), a rank may hold zero rows and still joins.
+    ONE all_gather of tensors padded to the largest count."""
+    if dist is None:
+        return [local]
+    if local.shape[0] != counts[rank]:
+        raise ValueError(f"gather_ragged: rank {rank} holds {local.shape[0]} rows, expected {counts[rank]}")
+    maxrows = max(max(counts), 1)
+    src = local.detach().cpu() if _staged(dist, local) else local.detach()
+    pad = torch.zeros((maxrows,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    pad[: src.shape[0]] = src
+    outs: List[torch.Tensor] = [torch.empty_like(pad) for _ in counts]
+    dist.all_gather(outs, pad)
+    if rank != 0:
+        return None
+    return [o[:c] for o, c in zip(outs, counts)]

@@ -74,6 +74,15 @@ WORKER = textwrap.dedent("""
         p.grad = torch.full_like(p, float(rank + 1))
     flat, _ = allreduce_gradients(m, d)
     assert torch.all(flat[:N_GRAD] == 1.5), flat[:4]
+    # infer.py's ONE final gather: ragged per-rank row counts, a rank may hold nothing at all
+    for counts in ([3, 2], [4, 0], [0, 1]):
+        mine = torch.full((counts[rank], 5), float(rank + 1))
+        parts = tdist.gather_ragged(d, mine, counts, rank)
+        if rank == 0:
+            assert [tuple(p.shape) for p in parts] == [(c, 5) for c in counts]
+            assert all(torch.all(p == r + 1) for r, p in enumerate(parts))
+        else:
+            assert parts is None
     if rank == 0:
         ref = torch.from_numpy(O.device_normal(2025, 3, 0, total))
         assert torch.equal(full, ref), "sharded draws differ from the single-process stream"

@@ -497,6 +497,28 @@ def test_infer_driver_end_to_end(dev, tmp_path, monkeypatch):
     assert np.load(os.path.join(out, "x_infer_trace.npy")).shape == (3, 24)
 
 
+def test_infer_coalesced_launches_write_the_per_batch_files_bitwise(dev, tmp_path, monkeypatch):
+    """The reference launches the loop once per loader batch (infer.py:66-95; default --batch_size 2 = a 4-sequence CFG pass).
+    infer.py samples the same rows in the same order `--launch_batch` series at a time: rows are independent, the kernels
+    batch-invariant and Philox keyed by the global row, so the four files must not change by a byte -- whatever the launch
+    size (incl. a ragged last launch), against the reference's launch shape (`--launch_batch 0`)."""
+    import infer as drv
+    monkeypatch.chdir(tmp_path)
+    files = ("x_1.npy", "x_t.npy", "x_t_latent_dec_array.npy", "x_t_latent_enc_array.npy")
+    got = {}
+    for lb in (0, 64, 256):
+        save = str(tmp_path / f"lb{lb}")
+        drv.main(["--dataset_name", "ETTh1_48", "--total_step", "3", "--batch_size", "2", "--save_path", save, "--synthetic",
+                  "151", "--random_init", "--seed", "9", "--launch_batch", str(lb)])
+        out = os.path.join(save, "generation", "flowmatching_DiT_ETTh1_48_7_3")      # the reference's default backbone / cfg
+        got[lb] = [np.load(os.path.join(out, f)) for f in files]
+        assert got[lb][0].shape == (150, 48, 1) and got[lb][2].shape == (150, 64, 30)      # floor(151 / 2) * 2 rows
+    for lb in (64, 256):
+        for f, a, b in zip(files, got[0], got[lb]):
+            assert np.array_equal(a, b), (lb, f)
+    assert np.isfinite(got[0][1]).all() and float(np.abs(got[0][1]).max()) > 0
+
+
 def test_infer_driver_run_multi_layout(dev, tmp_path, monkeypatch):
     """`--run_multi True` (infer.py:148-164): the base run plus run_0 .. run_9, each with the four files.  The test loader
     shuffles (dataloader.py:111 does too), so every run holds the same ground-truth rows in its own order; the generated

@@ -122,6 +122,35 @@ def test_train_driver_default_backbone_then_infer(dev, tmp_path, monkeypatch):
     assert gen.shape == (8, 48, 1) and np.isfinite(gen).all()
 
 
+def test_train_driver_resident_batches_equal_the_loader_pass(dev, tmp_path, monkeypatch):
+    """train.py's default data path gathers index batches from device-resident latent / embedding tables
+    (datafactory.epoch_index_batches: the order a pass over the DataLoader draws, no per-row __getitem__ / collate);
+    `--loader_batches` walks the DataLoader as the reference does (train.py:52-95, mix-train: three length groups per
+    batch).  Same rows, same draws: the loss lists and the final weights must be IDENTICAL, and --max_steps stops a run."""
+    import train as drv
+    monkeypatch.chdir(tmp_path)
+    runs = {}
+    for tag, extra in (("resident", []), ("loader", ["--loader_batches"])):
+        save = str(tmp_path / tag)
+        argv = ["--dataset_name", "ETTh1", "--backbone", "ddpm", "--batch_size", "10", "--epochs", "3", "--save_path", save,
+                "--synthetic", "9", "--random_init", "--checkpoint_path", "", "--seed", "5", "--bf16"] + extra
+        losses = drv.train(drv.get_args(argv))
+        ck = torch.load(os.path.join(save, "checkpoints", "ddpm_DiT_ETTh1", "model_2.pth"), map_location="cpu")
+        assert ck["loss_list"] == losses
+        runs[tag] = (losses, ck["model"])
+    (la, wa), (lb, wb) = runs["resident"], runs["loader"]
+    assert len(la) == len(lb) >= 6 and la == lb, (la, lb)            # 3 epochs x 2 batches x up to 3 length groups
+    for k in wa:
+        assert torch.equal(wa[k], wb[k]), k
+    args = drv.get_args(["--dataset_name", "ETTh1", "--backbone", "ddpm", "--batch_size", "10", "--epochs", "3", "--save_path",
+                         str(tmp_path / "short"), "--synthetic", "9", "--random_init", "--checkpoint_path", "", "--seed", "5",
+                         "--bf16", "--max_steps", "4"])
+    ticks = []
+    args.on_step = lambda n, rows: ticks.append((n, rows))
+    short = drv.train(args)
+    assert short == la[:4] and [n for n, _ in ticks] == [1, 2, 3, 4] and all(r > 0 for _, r in ticks)
+
+
 def test_train_step_reference_fixture(golden_dir, dev):
     """Fixture (9): loss and the 48 per-parameter gradient norms produced by the reference itself."""
     g = np.load(os.path.join(golden_dir, "train_step.npz"))

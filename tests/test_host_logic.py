@@ -1,0 +1,118 @@
+"""Host logic of the drivers that needs no GPU: the loader-order helpers the resident data paths of infer.py / train.py
+stand on (they must visit exactly the rows a pass over the DataLoader visits, and consume the CPU generator the same
+way), the launch plan of infer.py, and bench.py's self-spawn launcher."""
+import io
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from datafactory.dataloader import (AlternatingDataset, custom_collate_fn, epoch_index_batches, group_by_dataset,
+                                    loader_provider, resident_tables)
+from datafactory.dataset import SyntheticT2SDataset
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _args(**kw):
+    base = dict(dataset_name="ETTh1_24", batch_size=4, mix_train=False, synthetic=11)
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+@pytest.mark.parametrize("mix,bs", [(False, 4), (False, 1), (True, 7)])
+def test_epoch_index_batches_is_one_pass_over_the_loader(mix, bs):
+    """Same rows in the same order as `for data in loader` (reference dataloader.py:99,111: shuffle=True, drop_last=True),
+    for three consecutive passes, and the global CPU generator ends in the same state (train.py's t / CFG-coin draws
+    follow it)."""
+    ds, loader = loader_provider(_args(mix_train=mix, batch_size=bs, dataset_name="ETTh1" if mix else "ETTh1_24"), "train")
+    torch.manual_seed(77)
+    real = []
+    for _ in range(3):
+        for data in loader:
+            if mix:
+                real.append(np.concatenate([g[1].numpy() for g in data if g[1].shape[1] == 24] or [np.zeros((0, 24))]))
+            else:
+                real.append(data[1].numpy())
+    after_real = float(torch.rand(1))
+    torch.manual_seed(77)
+    tabs = resident_tables(ds)
+    starts = [st for _, _, st in tabs]
+    got = []
+    for _ in range(3):
+        batches = epoch_index_batches(loader)
+        assert batches.shape == (len(loader), bs)
+        for idx in batches:
+            if mix:
+                rows = [r for w, r in group_by_dataset(idx, starts) if w == 0]
+                got.append(tabs[0][0][rows[0].numpy()] if rows else np.zeros((0, 24)))
+            else:
+                got.append(tabs[0][0][idx.numpy()])
+    assert float(torch.rand(1)) == after_real, "the helper consumed the global generator differently from a real pass"
+    assert len(real) == len(got) == 3 * len(loader)
+    for a, b in zip(real, got):
+        assert np.array_equal(a, b)
+
+
+def test_group_by_dataset_is_the_collate_grouping():
+    """custom_collate_fn (dataloader.py:115-133) groups a mixed batch by source dataset, keeping batch order inside a
+    group and skipping empty groups: the index-space version must give the same rows and embeddings."""
+    parts = [SyntheticT2SDataset(5, L, seed=L) for L in (24, 48, 96)]
+    ds = AlternatingDataset(*parts)
+    tabs = resident_tables(ds)
+    starts = [st for _, _, st in tabs]
+    assert starts == [0, 5, 10]
+    for idx in (torch.tensor([14, 0, 7, 3, 9, 1]), torch.tensor([12, 11]), torch.tensor([4]), torch.tensor([5, 10, 0])):
+        want = custom_collate_fn([ds[int(i)] for i in idx])
+        got = group_by_dataset(idx, starts)
+        assert len(want) == len(got)
+        for (texts, xs, embs), (w, rows) in zip(want, got):
+            assert np.array_equal(xs.numpy(), tabs[w][0][rows.numpy()])
+            assert np.array_equal(embs.numpy(), tabs[w][1][rows.numpy()])
+            assert texts == [parts[w].text[int(r)] for r in rows]
+
+
+def test_infer_launch_plan_covers_rows_once_in_order():
+    pytest.importorskip("torch")
+    import infer
+    for n_rows, bs, lb, world in ((2048, 2, 256, 1), (600, 2, 256, 1), (37, 1, 256, 8), (40, 4, 0, 2), (4096, 2, 256, 8)):
+        plan = infer.launch_plan(n_rows, bs, lb, world)
+        assert plan[0][0] == 0 and plan[-1][1] == n_rows
+        assert all(b == c for (_, b), (c, _) in zip(plan, plan[1:]))
+        per = bs if lb == 0 else lb * world
+        assert all(s1 - s0 == per for s0, s1 in plan[:-1]) and 0 < plan[-1][1] - plan[-1][0] <= per
+
+
+def test_bench_self_spawn_builds_a_fresh_rank_launcher(monkeypatch, capsys):
+    """`python bench.py --gpus N` with no torchrun environment starts `python -m torch.distributed.run --nproc-per-node N
+    bench.py <same flags>` as a CHILD (never exec), relays rank 0's one JSON line and returns the child's exit code."""
+    import bench
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None, text=None):
+            seen["cmd"], seen["env"] = cmd, env
+            self.stdout = io.StringIO("rank chatter\n" + json.dumps({"metric": "m", "n_gpus": 4}) + "\nlate chatter\n")
+
+        def wait(self):
+            return seen.get("rc", 0)
+
+    import subprocess
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.setenv("RANK", "3")               # stale torchrun variables must not leak into the children
+    rc = bench.spawn_ranks(4, ["--gpus", "4", "--steps", "2"])
+    out = capsys.readouterr().out.splitlines()
+    assert rc == 0 and out[-1] == json.dumps({"metric": "m", "n_gpus": 4}) and "rank chatter" in out
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5:] == [os.path.join(REPO, "bench.py"), "--gpus", "4", "--steps", "2"]
+    assert "RANK" not in seen["env"] and "WORLD_SIZE" not in seen["env"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    seen["rc"] = 7                                 # a failing child: its code comes back, no result line is printed
+    assert bench.spawn_ranks(4, ["--gpus", "4"]) == 7
+    assert not [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]

@@ -121,6 +121,30 @@ def test_two_rank_sampling_files_equal_single_process_bitwise(tmp_path):
         assert np.array_equal(a, b), f"{f}: sharded output differs from the single-process output"
 
 
+def test_two_rank_sampling_with_empty_shards_and_coalesced_launches(tmp_path):
+    """--batch_size 1 (and the reference's default 2) on two ranks.  With one launch per loader batch (`--launch_batch 0`)
+    every launch has ONE row: rank 1 never samples and must still reach the final gather (round 3 raised
+    `t2s_vae_encode: B=0` there while rank 0 blocked in all_gather).  With coalesced launches both ranks sample.  All
+    variants must write the single-process files bit for bit (reference infer.py:66,129: drop_last loader, default batch 2)."""
+    base = ["--dataset_name", "ETTh1_24", "--backbone", "ddpm", "--denoiser", "DiT", "--total_step", "3", "--cfg_scale", "9",
+            "--synthetic", "7", "--random_init", "--seed", "4"]
+    sub = os.path.join("generation", "ddpm_DiT_ETTh1_24_9.0_3")
+    files = ("x_1.npy", "x_t.npy", "x_t_latent_dec_array.npy", "x_t_latent_enc_array.npy")
+    port = 29560
+    for bs in ("1", "2"):
+        _launch([os.path.join(REPO, "infer.py")] + base + ["--batch_size", bs, "--save_path", str(tmp_path / f"one{bs}")],
+                port, False, str(tmp_path))
+        want = [np.load(tmp_path / f"one{bs}" / sub / f) for f in files]
+        assert want[0].shape[0] == (7 // int(bs)) * int(bs)
+        for lb in (("0", "256") if bs == "1" else ("0",)):
+            port += 1
+            _launch([os.path.join(REPO, "infer.py")] + base + ["--batch_size", bs, "--launch_batch", lb, "--save_path",
+                                                               str(tmp_path / f"two{bs}_{lb}")], port, True, str(tmp_path))
+            for f, a in zip(files, want):
+                assert np.array_equal(a, np.load(tmp_path / f"two{bs}_{lb}" / sub / f)), (bs, lb, f)
+        port += 1
+
+
 def test_two_rank_default_seed_is_rank0s(tmp_path):
     """No --seed: every rank must end up with rank 0's time-based seed (loader order + Philox key)."""
     script = tmp_path / "seed_worker.py"
@@ -157,6 +181,21 @@ def test_two_rank_train_cli_with_groups_smaller_than_the_world(tmp_path):
     assert set(ck) == {"model", "optimizer", "epoch", "loss_list"} and ck["epoch"] == 1
     assert len(ck["loss_list"]) >= 6 and np.isfinite(ck["loss_list"]).all(), r.stdout[-1500:]
     assert len(ck["optimizer"]["param_groups"][0]["params"]) == 67 and len(ck["optimizer"]["state"]) == 48
+
+
+def test_plain_bench_command_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` exactly as the driver types it -- no torchrun, no WORLD_SIZE: the process must start the
+    two ranks itself (fresh children, before any GPU call of its own), relay ONE JSON line with n_gpus = 2 and exit 0."""
+    env = _env(0, True)
+    env.pop("MASTER_ADDR"), env.pop("MASTER_PORT")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--diffusion-steps", "10", "--batch", "64", "--no-cpu-baseline", "--no-train", "--no-legs"]
+    r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["value"] > 0 and out["strong"]["value"] > 0
 
 
 def test_bench_two_ranks_prints_one_json_line(tmp_path):
