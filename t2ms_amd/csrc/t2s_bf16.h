@@ -679,13 +679,17 @@ inline void wgrad16_plan(int M, int N, int K, int n_cu, int* rows_per_wg, int* g
     *rows_per_wg = rows;
     *gx = (M + rows - 1) / rows;
 }
-inline size_t wgrad16_scratch_floats(int M, int n_cu) {      // worst case over the DiT's four linears
+inline size_t wgrad16_scratch_floats(int M, int n_cu) {      // worst case over the DiT's four linears AND over every M' <= M
+    // gx is not monotonic in M (rows_per_wg is rounded up to 64, so a smaller M can need one more slab than a larger one): a
+    // workspace built for cap_seqs sequences serves every smaller batch, so it is sized for the bound gx <= per slabs
+    (void)M;
     size_t worst = 0;
     const int shapes[4][2] = {{128, 128}, {256, 128}, {384, 128}, {128, 256}};
     for (auto& sh : shapes) {
-        int rows, gx;
-        wgrad16_plan(M, sh[0], sh[1], n_cu, &rows, &gx);
-        const size_t need = (size_t)gx * (sh[0] / 128) * (sh[1] / 128) * (128 * 128) + (size_t)gx * (sh[0] / 128) * 128;
+        const int tiles = (sh[0] / 128) * (sh[1] / 128);
+        int per = 3 * n_cu / tiles;
+        per = per < 1 ? 1 : per;
+        const size_t need = (size_t)per * tiles * (128 * 128) + (size_t)per * (sh[0] / 128) * 128;
         worst = need > worst ? need : worst;
     }
     return worst;

@@ -165,7 +165,10 @@ def _scratch_handle(device):
     """A 1-sequence handle with dummy weights, used only for its time-frequency table."""
     key = str(device)
     if key not in _SCRATCH:
-        z = torch.zeros(480 * 128, device=device)
+        # every dummy pointer must cover the LARGEST tensor t2s_dit_create packs from it: adaLN_modulation.1.weight is
+        # (768,128) = 98,304 floats.  (Until round 4 this was 480 * 128: the pack kernels read 148 KB past the buffer, a
+        # memory fault whenever the block happened to end a 2 MB allocator segment.)
+        z = torch.zeros(768 * 128, device=device)
         w = L.DitWeights()
         for name, _ in L.DitWeights._fields_[:-1]:
             setattr(w, name, z.data_ptr())
