@@ -413,6 +413,57 @@ def infer_driver_leg(dev, dist, rank, world, rows=2048):
     return out
 
 
+def class_api_leg(dev, batch=256, length=96, total_steps=1000, cfg=9.0, warm=10, timed=100):
+    """The loop of reference infer.py:76-88 written against the mirrored classes -- per diffusion step two
+    `model(input=, t=, text_input=)` calls, the CFG combination as torch glue, `ddpm.p_sample` -- i.e. the literal drop-in
+    of INTEGRATION.md section 1, eager launches, no fused sampler.  `timed` steps after `warm`, extrapolated to
+    `total_steps` (every step costs the same) + one decode; beside it the fused sampler as ONE lane (same shape)."""
+    from model.backbone.DDPM import DDPM
+    from t2ms_amd import synth
+    from t2ms_amd.sampler import Sampler
+    model, vae = build_models(dev)
+    ddpm = DDPM(total_steps, dev)
+    emb = synth.make_text_embeddings(2025, batch).to(dev)
+    x_t = torch.randn(batch, 64, 30, device=dev)
+
+    def steps(x_t, j0, n):
+        for j in range(j0, j0 + n):
+            t = torch.full((x_t.size(0),), total_steps - 1 - j, dtype=torch.long, device=dev)
+            pred_uncond = model(input=x_t, t=t, text_input=None)
+            pred_cond = model(input=x_t, t=t, text_input=emb)
+            pred = pred_uncond + cfg * (pred_cond - pred_uncond)
+            x_t = ddpm.p_sample(x_t, pred, t)
+        return x_t
+
+    with torch.no_grad():
+        x_t = steps(x_t, 0, warm)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        x_t = steps(x_t, warm, timed)
+        t_host = time.perf_counter() - t0            # the host has ENQUEUED the steps: its own cost per step
+        torch.cuda.synchronize(dev)
+        t_step = (time.perf_counter() - t0) / timed
+        t0 = time.perf_counter()
+        series, _ = vae.decoder(x_t, length=length)
+        torch.cuda.synchronize(dev)
+        t_dec = time.perf_counter() - t0
+    assert bool(torch.isfinite(series).all())
+    one = Sampler(model, vae.decoder, "ddpm", 100, cfg, batch, length, dev, use_graph=True, seed=2025, row0=0, lanes=1)
+    one.run(emb, decode=True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(2):
+        one.run_inplace(decode=False)
+    torch.cuda.synchronize(dev)
+    t_fused = (time.perf_counter() - t0) / 200
+    value = batch / (t_step * total_steps + t_dec)
+    return {"metric": f"reference-style class-API loop (infer.py:76-88 against the mirrors), B={batch}, {total_steps}-step DDPM, cfg {cfg}",
+            "value": value, "unit": "series/s", "ms_per_diffusion_step": t_step * 1e3,
+            "host_enqueue_ms_per_diffusion_step": t_host / timed * 1e3,
+            "fused_sampler_one_lane_ms_per_diffusion_step": t_fused * 1e3, "frac_of_fused_one_lane": t_fused / t_step,
+            "sample": f"{warm} warm + {timed} timed steps, extrapolated x{total_steps}/{timed} + 1 decode ({t_dec * 1e3:.1f} ms)"}
+
+
 def _bcast_obj(dist, obj, src=0):
     box = [obj]
     dist.broadcast_object_list(box, src=src)
@@ -615,6 +666,13 @@ def main():
                 import traceback
                 traceback.print_exc()
                 legs[name] = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0 and world == 1 and (args.backbone, B) == ("ddpm", 256):
+            try:
+                legs["class_api"] = class_api_leg(dev, B, args.length, args.diffusion_steps, args.cfg_scale)
+            except Exception as e:
+                import traceback
+                traceback.print_exc()
+                legs["class_api"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         # roofline of the dominant kernel (fused attention; 48 % of all FLOPs), same shapes as the workload
         kt = time_kernels_in_situ(model, dev, lat.clone(), text)

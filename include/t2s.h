@@ -363,6 +363,17 @@ void t2s_sampler_destroy(t2s_sampler* s);
  *          (t2s_sampler_set_lanes) execute on the library's own pool of streams in the same way for ANY `stream`: the
  *          run is ordered after everything queued on `stream` before the call and joined back to it before the call
  *          returns.
+ * Threads: one sampler is driven by one thread at a time, and so is the t2s_dit it was created on (its workspace).  Two
+ *          threads may drive two samplers on two t2s_dit handles of one device concurrently: runs that use the library's
+ *          stream pool (several lanes, or stream NULL with use_graph) serialise their ENQUEUE on a per-device lock held
+ *          for the length of the call (the GPU work stays asynchronous); a single-lane run captures on the caller's
+ *          `stream`, which -- like any HIP stream under capture -- must not be used by another thread meanwhile.
+ *          The pool is created and calibrated by the first t2s_sampler_create on a device (not by a run), so a run
+ *          never allocates or synchronises for it.
+ * Memory:  t2s_sampler_create also allocates a whole-run adaLN table (steps x (batch + 1) x 3072 floats: 3.2 GB at
+ *          256 series x 1000 steps, ~2 % of a step) when that is at most 1/8 of the device memory currently free and
+ *          16 GB; otherwise -- or with T2S_ADALN_TABLE=0 in the environment -- the per-step adaLN kernel runs instead
+ *          (bitwise the same results).
  */
 int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, const float* noise,
                     float* series, float* trace0, void* stream);

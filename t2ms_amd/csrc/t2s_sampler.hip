@@ -414,15 +414,22 @@ bool streams_overlap(hipStream_t a, hipStream_t b, unsigned long long* stamps_de
 
 int g_lane_pool_concurrent[16] = {};      // per device: mutually concurrent streams the calibration found
 
+// The pool is shared by every sampler of the process on a device, lane 0 included: two host threads driving two samplers
+// would capture, record events and launch graphs on the SAME streams at once (one thread's work pulled into the other's
+// capture, or hipErrorStreamCaptureIsolation).  A run that uses pool streams holds this lock from its first event to its
+// join: the enqueue of a run is host work of a few ms, the GPU side stays asynchronous.
+std::mutex g_pool_use[16];
+
 hipStream_t* lane_streams() {
     constexpr int ML = t2s_sampler::MAX_LANES;
     static hipStream_t pool[16][ML] = {};
-    static bool ready[16] = {};
+    static bool ready[16] = {}, failed[16] = {};
     static std::mutex guard;                    // the pool is process-wide: samplers of different threads may meet here
     std::lock_guard<std::mutex> lock(guard);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     if (ready[dev]) return pool[dev];
+    if (failed[dev]) return nullptr;            // calibrated once per process: a device without streams stays on one lane
     unsigned long long* stamps = nullptr;
     if (hipMalloc((void**)&stamps, 4 * sizeof(unsigned long long)) != hipSuccess) return nullptr;
     int have = 0;
@@ -443,7 +450,13 @@ hipStream_t* lane_streams() {
         if (spare[i]) (void)hipStreamDestroy(spare[i]);
     (void)hipFree(stamps);
     (void)hipGetLastError();
-    if (have < ML) return nullptr;
+    if (have < ML) {                            // stream creation failed part-way: give back what was made, do not retry
+        for (int i = 0; i < have; ++i) (void)hipStreamDestroy(pool[dev][i]), pool[dev][i] = nullptr;
+        g_lane_pool_concurrent[dev] = 0;
+        failed[dev] = true;
+        (void)hipGetLastError();
+        return nullptr;
+    }
     ready[dev] = true;
     return pool[dev];
 }
@@ -528,10 +541,16 @@ extern "C" int t2s_sampler_create(t2s_dit* dit, t2s_vae* vae, const t2s_sample_c
     alloc((void**)&s->eps_c, B * LAT * sizeof(float));
     alloc((void**)&s->tvals, T * sizeof(float));
     alloc((void**)&s->step, t2s_sampler::MAX_LANES * 16 * sizeof(int));   // one counter per lane, 64 B apart
-    // whole-run adaLN table (dit_adaln_table): up to 16 GB of the 288 GB; beyond that the per-step kernel stays in the loop
+    // whole-run adaLN table (dit_adaln_table; 3.2 GB at 256 series x 1000 steps for ~2 % of a step): only while it is a
+    // small part of what the device has FREE right now -- at most 1/8 of it and 16 GB -- so that a process holding several
+    // samplers, or sharing the GPU with torch's allocator or a training job, does not run dry later for an optimisation;
+    // beyond that the per-step kernel stays in the loop (same bits).  T2S_ADALN_TABLE=0 switches the table off.
     const size_t table_bytes = T * (B + 1) * (size_t)MODROW * sizeof(float);
     const char* table_env = getenv("T2S_ADALN_TABLE");   // =0: keep the per-step adaLN kernel (A/B, and the test of that path)
-    if (e == hipSuccess && !(table_env && atoi(table_env) == 0) && table_bytes <= ((size_t)16 << 30) && hipMalloc((void**)&s->mod_table, table_bytes) != hipSuccess) {
+    size_t mem_free = 0, mem_total = 0;
+    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 0, (void)hipGetLastError();
+    if (e == hipSuccess && !(table_env && atoi(table_env) == 0) && table_bytes <= ((size_t)16 << 30) && table_bytes <= mem_free / 8 &&
+        hipMalloc((void**)&s->mod_table, table_bytes) != hipSuccess) {
         s->mod_table = nullptr;       // an optimisation only: a device too full for it keeps the per-step kernel
         (void)hipGetLastError();
     }
@@ -553,6 +572,9 @@ extern "C" int t2s_sampler_create(t2s_dit* dit, t2s_vae* vae, const t2s_sample_c
         t2s_sampler_destroy(s);
         return rc;
     }
+    // calibrate the lane-stream pool HERE (create synchronises anyway): t2s_sampler_run then never allocates, copies or
+    // synchronises for it -- legal while the calling thread has a capture open, and its timing test runs on an idle stream
+    (void)lane_streams();
     *out = s;
     return T2S_OK;
 }
@@ -609,7 +631,12 @@ extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, cons
     // (distinct hardware queues): the caller's stream then only carries the fork and the join
     hipStream_t const caller = st;
     const bool via_own = (graph_ok && st == nullptr) || lanes > 1;
+    std::unique_lock<std::mutex> pool_lock;             // held to the end of the call when this run touches pool streams
     if (via_own) {
+        int dev = 0;
+        T2S_HIP_CHECK(hipGetDevice(&dev));
+        T2S_REQUIRE(dev >= 0 && dev < 16, "t2s_sampler_run: device %d", dev);
+        pool_lock = std::unique_lock<std::mutex>(g_pool_use[dev]);
         if (!s->own) {
             hipStream_t* pool = lane_streams();
             T2S_REQUIRE(pool, "t2s_sampler_run: cannot create the lane streams");

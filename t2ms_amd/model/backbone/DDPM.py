@@ -56,6 +56,10 @@ class DDPM:
         if x.dim() != 3 or (x.shape[1] * x.shape[2]) % 4 != 0:
             raise L.T2SError(f"DDPM: latent must be (B,C,W) with C*W a multiple of 4 ((B,64,30) on the DiT path), "
                              f"got {tuple(x.shape)}")
+        if not t.is_cuda and t.numel() and (int(t.min()) < 0 or int(t.max()) >= self.total_steps):
+            # a host-side t costs nothing to check; the reference's gather (DDPM.py:7-9) raises for it.  (A device-side t
+            # is checked by the kernels: a row outside the table comes out NaN rather than read out of bounds.)
+            raise IndexError(f"DDPM: t must lie in [0, {self.total_steps}), got [{int(t.min())}, {int(t.max())}]")
         ti = t.to(device=x.device, dtype=torch.int32).contiguous()
         if ti.shape != (x.shape[0],):
             raise L.T2SError(f"DDPM: t must be ({x.shape[0]},), got {tuple(ti.shape)}")

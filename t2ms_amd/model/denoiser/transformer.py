@@ -210,16 +210,34 @@ class Transformer(nn.Module):
 
     # ---------------------------------------------------------------- HIP handle management
     def _dit_tensors(self):
-        ts = [self.conv.weight, self.conv.bias, self.patch_emb.weight, self.patch_emb.bias, self.pos_embed,
-              self.ln.weight, self.ln.bias, self.linear_emb_to_patch.weight, self.linear_emb_to_patch.bias]
-        for blk in self.layers:
-            ts += [blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight, blk.attn.proj.bias,
-                   blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias,
-                   blk.adaLN_modulation[-1].weight, blk.adaLN_modulation[-1].bias]
+        """The 49 tensors the kernels read, in t2s_dit_weights order.  Walks the modules' own parameter dicts (what
+        nn.Module.__getattr__ would do 150 times per call at ~0.5 us each): the class-API loop calls this twice per
+        forward, and a re-assigned Parameter is still seen because nothing is cached."""
+        m = self._modules
+        ts = [m["conv"]._parameters["weight"], m["conv"]._parameters["bias"], m["patch_emb"]._parameters["weight"],
+              m["patch_emb"]._parameters["bias"], self._parameters["pos_embed"], m["ln"]._parameters["weight"],
+              m["ln"]._parameters["bias"], m["linear_emb_to_patch"]._parameters["weight"],
+              m["linear_emb_to_patch"]._parameters["bias"]]
+        for blk in m["layers"]._modules.values():
+            b = blk._modules
+            attn, mlp, ada = b["attn"]._modules, b["mlp"]._modules, b["adaLN_modulation"]._modules["1"]._parameters
+            for lin in (attn["qkv"], attn["proj"], mlp["fc1"], mlp["fc2"]):
+                ts.append(lin._parameters["weight"])
+                ts.append(lin._parameters["bias"])
+            ts.append(ada["weight"])
+            ts.append(ada["bias"])
         return ts
 
     def _weights_struct(self, device):
+        """-> (t2s_dit_weights, the tensors it points into, stamp).  The stamp -- (data_ptr, _version) per tensor --
+        changes whenever a parameter was written in place or re-allocated; while it stands, the struct of the last call
+        is handed back (the reference-style loop calls the model twice per diffusion step: building 49 detached views
+        and 59 ctypes fields each time cost 150 us of host time per forward, more than a small batch's kernels)."""
         ts = self._dit_tensors()
+        stamp = tuple([(t.data_ptr(), t._version) for t in ts])
+        cached = self.__dict__.get("_t2s_ws")
+        if cached is not None and cached[0] == device and cached[3] == stamp:
+            return cached[1], cached[2], stamp
         for t in ts:
             if t.device != device:
                 raise L.T2SError(f"Transformer parameters live on {t.device} but the input is on {device}; "
@@ -234,7 +252,8 @@ class Transformer(nn.Module):
         for i in range(DEPTH):
             for n, t in zip(bnames, keep[9 + 10 * i: 19 + 10 * i]):
                 setattr(w.blk[i], n, t.data_ptr())
-        stamp = tuple((t.data_ptr(), t._version) for t in ts)
+        if all(k.data_ptr() == t.data_ptr() for k, t in zip(keep, ts)):      # fp32 contiguous parameters: no copies made
+            self.__dict__["_t2s_ws"] = (device, w, keep, stamp)
         return w, keep, stamp
 
     def t2s_handle(self, device, n_seqs: int):
@@ -290,7 +309,8 @@ class Transformer(nn.Module):
 
     def __getstate__(self):
         state = self.__dict__.copy()
-        for k in ("_t2s_h", "_t2s_dev", "_t2s_stamp", "_t2s_math_applied", "_t2s_bucket", "_t2s_flat_grad", "_t2s_fwd_gen"):
+        for k in ("_t2s_h", "_t2s_dev", "_t2s_stamp", "_t2s_math_applied", "_t2s_bucket", "_t2s_flat_grad", "_t2s_fwd_gen",
+                  "_t2s_ws"):
             state.pop(k, None)
         return state
 

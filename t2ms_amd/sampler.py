@@ -34,6 +34,12 @@ def loop_t_values(backbone: str, steps: int) -> torch.Tensor:
 
 
 _STREAMS = {}
+_RUN_LOCKS = {}          # per device: the Samplers of a process share one capture stream (below), so one run enqueues at a time
+
+
+def _run_lock(device) -> "threading.Lock":
+    import threading
+    return _RUN_LOCKS.setdefault(str(torch.device(device)), threading.Lock())
 
 
 def _sampler_stream(device) -> "torch.cuda.Stream":
@@ -150,11 +156,12 @@ class Sampler:
             if self.model.t2s_handle_id() != self._dit_uid:
                 self._create()  # the model re-created its handle (capacity grew / device moved): drop the graph
             cur = torch.cuda.current_stream(dev)
-            self.stream.wait_stream(cur)
-            L.check(L.lib().t2s_sampler_run(self.ptr, L.dev_ptr(self._x), L.dev_ptr(self._text), L.dev_ptr(noise),
-                                            L.dev_ptr(self._series) if decode else None, L.dev_ptr(tr),
-                                            self.stream.cuda_stream), "t2s_sampler_run")
-            cur.wait_stream(self.stream)
+            with _run_lock(dev):        # two host threads must not capture / launch on the shared stream at once
+                self.stream.wait_stream(cur)
+                L.check(L.lib().t2s_sampler_run(self.ptr, L.dev_ptr(self._x), L.dev_ptr(self._text), L.dev_ptr(noise),
+                                                L.dev_ptr(self._series) if decode else None, L.dev_ptr(tr),
+                                                self.stream.cuda_stream), "t2s_sampler_run")
+                cur.wait_stream(self.stream)
         self._last = (noise, tr)  # keep caller-provided buffers alive until the stream has consumed them
         return self._x.clone(), (self._series.clone() if decode else None), tr
 
@@ -172,11 +179,12 @@ class Sampler:
                 self._create()
             self.draw_xT(self._x)
             cur = torch.cuda.current_stream(dev)
-            self.stream.wait_stream(cur)
-            L.check(L.lib().t2s_sampler_run(self.ptr, L.dev_ptr(self._x), L.dev_ptr(self._text), None,
-                                            L.dev_ptr(self._series) if decode else None, None,
-                                            self.stream.cuda_stream), "t2s_sampler_run")
-            cur.wait_stream(self.stream)
+            with _run_lock(dev):
+                self.stream.wait_stream(cur)
+                L.check(L.lib().t2s_sampler_run(self.ptr, L.dev_ptr(self._x), L.dev_ptr(self._text), None,
+                                                L.dev_ptr(self._series) if decode else None, None,
+                                                self.stream.cuda_stream), "t2s_sampler_run")
+                cur.wait_stream(self.stream)
         return self._x, self._series
 
 
