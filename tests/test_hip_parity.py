@@ -777,6 +777,42 @@ def test_two_lane_sampler_is_bitwise_one_lane(dev, vae, math):
     assert L.lib().t2s_sampler_set_lanes(s.ptr, 4) == 0 and L.lib().t2s_sampler_set_lanes(s.ptr, 2) == 0
 
 
+def test_every_launch_shape_reproduces_itself_beside_foreign_traffic(dev, dit, vae):
+    """A short cut of tools/stress_determinism.py for the hand-counted vmcnt / lgkmcnt rings (tests/test_isa_pins.py pins
+    their ISA shape; this checks their behaviour): every launch shape of the DiT forward -- 16- and 32-token row tiles,
+    packed and persistent attention, partial tiles, conditional and text-free -- and of the fused sampler (graph replay,
+    one / two / three lanes, adaLN table) is run three times while another stream streams 256 MB through HBM, and must
+    reproduce its first result bit for bit.  One pass: a property check, not a hunt."""
+    from t2ms_amd.sampler import Sampler
+    side = torch.cuda.Stream(dev)
+    junk = torch.randn(64 << 20, device=dev)
+    with torch.no_grad():
+        for B in (1, 3, 7, 16, 25, 32, 50, 64, 100, 128, 256):
+            x = synth.make_latents(100 + B, B).to(dev)
+            t = torch.full((B,), 500, dtype=torch.long, device=dev)
+            text = synth.make_text_embeddings(100 + B, B).to(dev)
+            first = None
+            for rep in range(3):
+                with torch.cuda.stream(side):
+                    junk.mul_(1.0000001)
+                got = (dit(input=x, t=t, text_input=text), dit(input=x, t=t, text_input=None))
+                if first is None:
+                    first = got
+                    assert bool(torch.isfinite(got[0]).all())
+                else:
+                    assert torch.equal(got[0], first[0]) and torch.equal(got[1], first[1]), (B, rep)
+        for B in (8, 32, 96, 256):
+            s = Sampler(dit, vae.decoder, "ddpm", 12, 9.0, B, 96, dev, seed=5)
+            lat0, ser0, _ = s.run(synth.make_text_embeddings(7, B).to(dev))
+            for rep in range(2):
+                with torch.cuda.stream(side):
+                    junk.mul_(1.0000001)
+                lat, ser = s.run_inplace()
+                torch.cuda.synchronize(dev)
+                assert torch.equal(lat, lat0) and torch.equal(ser, ser0), (B, rep)
+    torch.cuda.synchronize(dev)
+
+
 def test_two_host_threads_drive_two_samplers_on_one_device(dev, vae):
     """Every multi-lane sampler of a process runs on ONE per-device pool of lane streams (lane 0 included).  Two host
     threads driving two samplers at once would capture / record / launch on the same streams -- one thread's work pulled
