@@ -202,20 +202,20 @@ def train_leg(dev, dist, rank, world, batch=1152, length=96, steps=30, warmup=4,
     x = synth.make_series(1, batch, length)                       # this rank's rows; the driver slices a global batch
     text = synth.make_text_embeddings(1, batch)
     lat_local = latent_cache.encode_all(model.encoder, x, dev)
-    # train_step shards a GLOBAL batch by rank: hand it global-shaped inputs whose slice [lo, hi) is this rank's data
+    # train_step shards a GLOBAL batch by rank: hand it global-shaped tables whose rows [lo, hi) are this rank's data --
+    # the resident form train.py itself uses (device tables + a device index vector: no host -> device copy in a step)
     lo, _ = tdist.shard_rows(n_global, rank, world)
-    xg = torch.zeros(n_global, length)
-    eg = torch.zeros(n_global, 128)
-    eg[lo:lo + batch] = text
+    eg = torch.zeros(n_global, 128, device=dev)
+    eg[lo:lo + batch] = text.to(dev)
     latents = torch.zeros(n_global, 64, 30, device=dev)
     latents[lo:lo + batch] = lat_local
-    idx = torch.arange(n_global)
+    idx = torch.arange(n_global, device=dev)
     torch.manual_seed(2025)
 
     def run(n, d, first):
         loss = None
         for i in range(n):
-            loss = drv.train_step(model, ddpm, opt, d, args, xg, eg, dev, rank, world, latents, idx, first + i)
+            loss = drv.train_step(model, ddpm, opt, d, args, None, None, dev, rank, world, latents, idx, first + i, eg)
         return loss
 
     run(warmup, dist, 0)

@@ -270,6 +270,12 @@ int t2s_rf_create_flow(const float* x1, const float* x0, const float* t, float* 
  * DDPM.py:35 / infer.py:75 in perf mode; parity mode injects noise instead.) */
 int t2s_philox_normal(float* out, uint64_t seed, uint32_t stream_id, uint32_t row0, int n_rows,
                       int row_elems, void* stream);
+/* U[0,1) draws of the same stream: element e of GLOBAL row r = lane e % 4 of counter (e/4, r, stream_id, 0), key = seed,
+ * as the 24-bit uniform (x >> 8) * 2^-24 (exact in fp32, never 1.0).  out: (n_rows,row_elems), any row_elems >= 1.
+ * (replaces torch.rand at train.py:109,113: the per-row diffusion time of a training step, drawn on the device as a
+ * function of (seed, step, global row) -- the same for any number of GPUs, and no host -> device copy per step.) */
+int t2s_philox_uniform(float* out, uint64_t seed, uint32_t stream_id, uint32_t row0, int n_rows,
+                       int row_elems, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * LA-VAE codec: model/pretrained/vqvae.py:36-105 (Encoder, Decoder)

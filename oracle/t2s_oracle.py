@@ -392,6 +392,21 @@ def philox4x32_10(ctr: np.ndarray, key: np.ndarray) -> np.ndarray:
     return c
 
 
+def device_uniform(seed: int, stream: int, row0: int, n_rows: int, row_elems: int = 1) -> np.ndarray:
+    """t2s_philox_uniform: element e of GLOBAL row r = lane e % 4 of ctr (e // 4, r, stream, 0), key = seed, as the
+    24-bit uniform (x >> 8) * 2^-24 in [0, 1).  -> (n_rows, row_elems) float32."""
+    q = (row_elems + 3) // 4
+    ctr = np.zeros((n_rows, q, 4), dtype=np.uint32)
+    ctr[..., 0] = np.arange(q, dtype=np.uint32)[None, :]
+    ctr[..., 1] = np.arange(row0, row0 + n_rows, dtype=np.uint32)[:, None]
+    ctr[..., 2] = np.uint32(stream & 0xFFFFFFFF)
+    key = np.zeros((n_rows, q, 2), dtype=np.uint32)
+    key[..., 0] = np.uint32(seed & 0xFFFFFFFF)
+    key[..., 1] = np.uint32((seed >> 32) & 0xFFFFFFFF)
+    x = philox4x32_10(ctr, key).reshape(n_rows, q * 4)[:, :row_elems]
+    return ((x >> np.uint32(8)).astype(np.float64) * 2.0 ** -24).astype(np.float32)
+
+
 def device_normal(seed: int, stream: int, row0: int, n_rows: int, row_elems: int = LAT_C * LAT_W
                   ) -> np.ndarray:
     """The HIP generator's definition (t2ms_amd/csrc/t2s_sampler.hip, t2s_philox_normal):

@@ -121,6 +121,7 @@ SYMBOLS = {
     "t2s_ddpm_q_sample": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP]),
     "t2s_rf_create_flow": (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_philox_normal": (_I, [_VP, _U64, _U32, _U32, _I, _I, _VP]),
+    "t2s_philox_uniform": (_I, [_VP, _U64, _U32, _U32, _I, _I, _VP]),
     "t2s_vae_create": (_I, [C.POINTER(VaeWeights), C.POINTER(_VP)]),
     "t2s_vae_destroy": (None, [_VP]),
     "t2s_vae_decode": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP]),

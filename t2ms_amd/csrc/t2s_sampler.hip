@@ -69,6 +69,18 @@ __global__ void philox_normal_kernel(float* __restrict__ out, uint64_t seed, uin
     reinterpret_cast<f32x4*>(out)[idx] = normal4(seed, stream_id, row0 + (uint32_t)row, (uint32_t)quad);
 }
 
+// U[0,1) draws of the same counter layout: element e of global row `row` = lane e % 4 of counter (e / 4, row, stream_id);
+// 24-bit uniforms (exact in fp32, never 1.0)
+__global__ void philox_uniform_kernel(float* __restrict__ out, uint64_t seed, uint32_t stream_id, uint32_t row0, int n_rows,
+                                      int row_elems) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * row_elems) return;
+    const int row = idx / row_elems, e = idx - row * row_elems;
+    const u32x4 r = philox4x32_10(u32x4{(uint32_t)(e >> 2), row0 + (uint32_t)row, stream_id, 0u}, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint32_t v = (e & 3) == 0 ? r.x : ((e & 3) == 1 ? r.y : ((e & 3) == 2 ? r.z : r.w));
+    out[idx] = (float)(v >> 8) * (1.0f / 16777216.0f);
+}
+
 // ---------------------------------------------------------------- sampler update kernels
 struct StepArgs {
     float* x;             // (B,1920) in place
@@ -274,6 +286,16 @@ extern "C" int t2s_philox_normal(float* out, uint64_t seed, uint32_t stream_id, 
                 "t2s_philox_normal: bad argument (n_rows=%d,row_elems=%d; row_elems %% 4 must be 0)", n_rows, row_elems);
     const int q = row_elems / 4, total = n_rows * q;
     philox_normal_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(out, seed, stream_id, row0, n_rows, q);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+extern "C" int t2s_philox_uniform(float* out, uint64_t seed, uint32_t stream_id, uint32_t row0, int n_rows, int row_elems,
+                                  void* stream) {
+    T2S_REQUIRE(out && n_rows > 0 && row_elems > 0 && (long long)n_rows * row_elems < (1ll << 31),
+                "t2s_philox_uniform: bad argument (n_rows=%d,row_elems=%d)", n_rows, row_elems);
+    const int total = n_rows * row_elems;
+    philox_uniform_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(out, seed, stream_id, row0, n_rows, row_elems);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }

@@ -65,6 +65,18 @@ def philox_normal(n_rows: int, row_elems: int, seed: int, stream_id: int, row0: 
     return out
 
 
+def philox_uniform(n_rows: int, row_elems: int, seed: int, stream_id: int, row0: int, device) -> torch.Tensor:
+    """(n_rows, row_elems) U[0,1) draws of the library's Philox stream (t2s_philox_uniform): 24-bit uniforms keyed like
+    philox_normal by (seed, stream_id, GLOBAL row) -- the per-row diffusion time of a training step (train.py:109,113)."""
+    device = torch.device(device)
+    out = torch.empty(n_rows, row_elems, device=device, dtype=torch.float32)
+    if n_rows:
+        with torch.cuda.device(device):
+            L.check(L.lib().t2s_philox_uniform(L.dev_ptr(out), int(seed), int(stream_id) & 0xFFFFFFFF, int(row0), n_rows,
+                                               row_elems, L.stream_ptr(device)), "t2s_philox_uniform")
+    return out
+
+
 class Sampler:
     def __init__(self, model, decoder, backbone: str, steps: int, cfg_scale: float, batch: int, length: int,
                  device, use_graph: bool = True, seed: int = 2025, row0: int = 0, lanes: int = 0):

@@ -323,6 +323,24 @@ def test_philox_matches_oracle(dev):
     assert abs(big.mean().item()) < 2e-3 and abs(big.std().item() - 1.0) < 2e-3
 
 
+def test_philox_uniform_is_exact_sharding_invariant_and_in_range(dev):
+    """t2s_philox_uniform (the per-row diffusion time of a training step, train.py:109,113): 24-bit uniforms, so the device
+    values must EQUAL the numpy restatement, lie in [0, 1) -- floor(u * T) < T and never an out-of-table row -- and not
+    depend on the sharding (rows 5.. drawn alone equal rows 5.. of the whole draw)."""
+    from t2ms_amd.sampler import philox_uniform
+    for row_elems in (1, 3, 7):
+        got = philox_uniform(9, row_elems, 77, 12, 1000, dev)
+        assert np.array_equal(got.cpu().numpy(), O.device_uniform(77, 12, 1000, 9, row_elems))
+        assert torch.equal(philox_uniform(4, row_elems, 77, 12, 1005, dev), got[5:])
+    big = philox_uniform(1 << 20, 1, 2025 ^ 0x74696D65, 3, 0, dev).view(-1)
+    assert float(big.min()) >= 0.0 and float(big.max()) < 1.0 and abs(float(big.mean()) - 0.5) < 2e-3
+    for T in (100, 1000):
+        t = torch.floor(big * T).long()
+        assert int(t.min()) == 0 and int(t.max()) == T - 1
+        assert float((torch.bincount(t, minlength=T).float() / big.numel() * T - 1).abs().max()) < 0.15
+    assert philox_uniform(0, 1, 1, 1, 0, dev).shape == (0, 1)
+
+
 @pytest.mark.parametrize("L_", [24, 48, 96])
 @pytest.mark.parametrize("B", [1, 5])
 def test_vae_golden(golden_dir, dev, vae, L_, B):

@@ -68,27 +68,33 @@ def _h2d(t, device):
     return out
 
 
+TIME_KEY = 0x74696D65       # "time": xor-ed into the seed for the per-row diffusion-time stream (the noise stream uses "rain")
+
+
 def train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world, latents=None, idx=None, step_no=0,
-               emb_table=None):
+               emb_table=None, drop_text=None):
     """One optimisation step on this rank's slice of the batch (train.py:103-127 / 60-87).
 
     Two ways to name the batch: host tensors `x_1` (n, L) / `emb` (n, 128) as the DataLoader collates them, or -- the
     resident path -- `idx` (n,) dataset rows into the device tables `latents` (N, 64, 30) and `emb_table` (N, 128) with
-    `x_1 = emb = None`: the rank then moves only ITS slice of the index vector to the device.
+    `x_1 = emb = None`: the rank then takes only ITS slice of the index vector (a device tensor is sliced in place: the
+    resident path of train() uploads a whole plan of index batches at a time, so a step issues NO host -> device copy).
 
     Every rank runs every step -- also with an EMPTY slice (a length group smaller than the world size): it then
     contributes a zero bucket, because the gradient all-reduce is a collective.  All random draws are functions of
-    (seed, step, GLOBAL row): t and the CFG coin come from the CPU generator (identically seeded on every rank, and
-    always drawn for the whole batch so the generators stay in lock-step whatever the shard sizes), the Gaussian
-    targets from the library's Philox stream keyed by the global row.  The step is therefore the same computation for
-    any number of GPUs (up to the summation order of the all-reduce), and the gradient is that of the mean loss over
+    (seed, step, GLOBAL row): the per-row diffusion time t (train.py:109,113: `torch.rand`) and the Gaussian targets come
+    from the library's Philox streams keyed by the global row, drawn ON the device (t2s_philox_uniform / _normal: no
+    host -> device copy per step); the CFG coin (train.py:120-122) from the CPU generator, identically seeded on every
+    rank (`drop_text` hands in a coin train() drew ahead, in the same order).  The step is therefore the same computation
+    for any number of GPUs (up to the summation order of the all-reduce), and the gradient is that of the mean loss over
     the GLOBAL batch: rank r's bucket is weighted n_r / n."""
-    from t2ms_amd.sampler import philox_normal
+    from t2ms_amd.sampler import philox_normal, philox_uniform
     n_global = int(x_1.shape[0] if x_1 is not None else idx.shape[0])
     lo, hi = tdist.shard_rows(n_global, rank, world)
     n = hi - lo
-    u = torch.rand(n_global)                                   # CPU generator: same on every rank
-    drop_text = bool(torch.rand(1) < 0.3)                      # classifier-free guidance coin (train.py:120-122)
+    if drop_text is None:
+        drop_text = bool(torch.rand(1) < 0.3)                  # classifier-free guidance coin (train.py:120-122)
+    u = philox_uniform(n, 1, args.seed ^ TIME_KEY, step_no, lo, device).view(n) if n > 0 else None
     opt.zero_grad()
     loss = None
     is_mlp = getattr(args, "denoiser", "DiT") == "MLP"
@@ -103,14 +109,16 @@ def train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world, 
         if args.backbone != "ddpm":
             raise ValueError("config 1 (MLP denoiser) is wired for --backbone ddpm")
         noise = philox_normal(n, z[0].numel(), args.seed ^ 0x7261696E, step_no, lo, device).view_as(z)
-        t = _h2d(torch.floor(u * args.total_step).long()[lo:hi], device)
+        t = torch.floor(u * args.total_step).long()
         x_t, _ = backbone.q_sample(z.contiguous(), t, noise)
         pred = model(x_t, t, None if drop_text else emb)
         loss = backbone.loss(pred, noise)
         loss.backward()
     elif n > 0:
         enc_trains = any(p.requires_grad for p in model.encoder.parameters())
-        idx_dev = _h2d(idx[lo:hi], device) if (latents is not None and idx is not None) else None
+        idx_dev = None
+        if latents is not None and idx is not None:
+            idx_dev = idx[lo:hi] if idx.is_cuda else _h2d(idx[lo:hi], device)
         emb = emb_table[idx_dev] if emb_table is not None else _h2d(emb[lo:hi].float(), device)
         if idx_dev is not None:
             z = latents[idx_dev]                                                       # pre-encoded rows (latent cache)
@@ -121,7 +129,7 @@ def train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world, 
                 z, _ = model.encoder(_h2d(x_1[lo:hi].float(), device).contiguous())    # frozen LA-VAE (train.py:31-33,106)
         noise = philox_normal(n, z[0].numel(), args.seed ^ 0x7261696E, step_no, lo, device).view_as(z)
         if args.backbone == "flowmatching":
-            t = _h2d((torch.round(u * args.total_step) / args.total_step)[lo:hi], device)
+            t = torch.round(u * args.total_step) / args.total_step                     # train.py:109
             if enc_trains:       # the same two formulas as differentiable torch glue (rectified_flow.py:8-12)
                 tt = t.float()[:, None, None]
                 x_t, x_0 = tt * z + (1 - tt) * noise, noise
@@ -129,7 +137,7 @@ def train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world, 
                 x_t, x_0 = backbone.create_flow(z, t, x_0=noise)
             target = z - x_0
         elif args.backbone == "ddpm":
-            t = _h2d(torch.floor(u * args.total_step).long()[lo:hi], device)
+            t = torch.floor(u * args.total_step).long()                                # train.py:113
             target = noise
             if enc_trains:       # DDPM.py:19-27 as differentiable torch glue
                 ab = backbone.alpha_bar.gather(-1, t).reshape(-1, 1, 1)
@@ -245,45 +253,57 @@ def train(args):
             loss_list.extend(torch.stack(pending).tolist())
             pending.clear()
 
-    def epoch_groups():
-        """-> per loader batch, the list of (x_1, emb, latents, idx, emb_table) train_step takes."""
-        if resident:
-            for idx in epoch_index_batches(dataloader):
-                groups = group_by_dataset(idx, starts) if args.mix_train else [(0, idx)]
-                yield [(None, None, lat_tabs[w], rows, emb_tabs[w]) for w, rows in groups]
-            return
-        for data in dataloader:
-            groups = data if args.mix_train else [data]
-            yield [(g[1], g[2], cache.get(int(g[1].shape[1])) if cache else None, g[3] if len(g) > 3 else None, None)
-                   for g in groups]
+    # Resident path: a PLAN of index batches for several epochs at once.  Per epoch the CPU generator is consumed exactly
+    # as the loader pass + the steps' CFG coins consume it (two draws when the pass starts, then one coin per length group in
+    # visiting order), the rows of a batch are ordered by length group (stable: the collate's grouping, dataloader.py:115-133)
+    # and made local to their dataset; the plan's index array goes to the device in ONE copy -- every >= PLAN_STEPS
+    # optimisation steps even for a set with one batch per epoch -- and a step slices it in place.
+    PLAN_STEPS = 64
 
-    for epoch in range(start_epoch, args.epochs):
-        for batch, groups in enumerate(epoch_groups()):
-            for x_1, emb, lat, idx, emb_tab in groups:
-                loss = train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world, lat, idx, step_no, emb_tab)
-                n_rows = int(x_1.shape[0] if x_1 is not None else idx.shape[0])
-                step_no += 1
-                steps_done += 1
-                seen += n_rows
-                pending.append(loss.detach())           # .item() here (train.py:126) would drain the GPU at every step
-                if on_step is not None:
-                    on_step(steps_done, n_rows)
-                # the reference prints at batch 0 of EVERY epoch (train.py:128-129): with the 1-2 batches per epoch of an
-                # ETTh1-sized set that would be a device sync per step -- report on a step count instead
-                if steps_done == 1 or steps_done % 100 == 0:
-                    flush()
-                    if rank == 0:
-                        print(f"[Epoch {epoch}] [batch {batch}] loss: {loss_list[-1]:.6f}  "
-                              f"({seen / (time.time() - t0):.1f} samples/s)")
-                if max_steps and steps_done >= max_steps:
-                    stop = True
-                    break
-            if stop:
-                break
-            if args.mix_train:
-                sched.step()
-        if stop:
-            break
+    def plan_epochs(first_epoch):
+        plans, n_steps, e = [], 0, first_epoch
+        while e < args.epochs and (not plans or n_steps < PLAN_STEPS):
+            batches = epoch_index_batches(dataloader)                                   # (nb, B) rows of the concatenation
+            if args.mix_train and len(starts) > 1:
+                which = torch.bucketize(batches, torch.as_tensor(starts[1:], dtype=torch.int64), right=True)
+                order = torch.argsort(which, dim=1, stable=True)
+                which = which.gather(1, order)
+                rows = batches.gather(1, order) - torch.as_tensor(starts, dtype=torch.int64)[which]
+                counts = torch.stack([(which == w).sum(1) for w in range(len(starts))], dim=1)   # (nb, groups)
+            else:
+                rows, counts = batches, torch.full((batches.shape[0], 1), batches.shape[1], dtype=torch.int64)
+            groups = [[(w, int(c)) for w, c in enumerate(row) if c] for row in counts.tolist()]
+            coins = [[bool(torch.rand(1) < 0.3) for _ in g] for g in groups]            # train.py:120-122, in visiting order
+            plans.append((e, rows, groups, coins))
+            n_steps += sum(len(g) for g in groups)
+            e += 1
+        flat = torch.cat([p[1].reshape(-1) for p in plans]) if plans else torch.empty(0, dtype=torch.int64)
+        return plans, _h2d(flat, device)
+
+    def epoch_batches(first_epoch):
+        """-> (epoch, batch index, [(x_1, emb, latents, idx, emb_table, coin)]) for every loader batch from `first_epoch` on."""
+        if not resident:
+            for e in range(first_epoch, args.epochs):
+                for b, data in enumerate(dataloader):
+                    groups = data if args.mix_train else [data]
+                    yield e, b, [(g[1], g[2], cache.get(int(g[1].shape[1])) if cache else None, g[3] if len(g) > 3 else None,
+                                  None, None) for g in groups]
+            return
+        e = first_epoch
+        while e < args.epochs:
+            plans, flat_dev = plan_epochs(e)
+            off = 0
+            for ep, rows, groups, coins in plans:
+                for b in range(rows.shape[0]):
+                    out, o = [], off + b * rows.shape[1]
+                    for (w, c), coin in zip(groups[b], coins[b]):
+                        out.append((None, None, lat_tabs[w], flat_dev[o:o + c], emb_tabs[w], coin))
+                        o += c
+                    yield ep, b, out
+                off += rows.numel()
+            e += len(plans)
+
+    def end_of_epoch(epoch):
         if not args.mix_train:
             sched.step()
         if (epoch % 1000 == 0 or epoch == args.epochs - 1) and rank == 0:
@@ -291,6 +311,37 @@ def train(args):
             print(f"Saving model {epoch} to {args.save_path}...")
             torch.save(dict(model=model.state_dict(), optimizer=opt.state_dict(), epoch=epoch, loss_list=loss_list),
                        os.path.join(args.save_path, f"model_{epoch}.pth"))
+
+    epoch = None
+    for ep, batch, groups in epoch_batches(start_epoch):
+        if epoch is not None and ep != epoch:
+            end_of_epoch(epoch)
+        epoch = ep
+        for x_1, emb, lat, idx, emb_tab, coin in groups:
+            loss = train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world, lat, idx, step_no, emb_tab, coin)
+            n_rows = int(x_1.shape[0] if x_1 is not None else idx.shape[0])
+            step_no += 1
+            steps_done += 1
+            seen += n_rows
+            pending.append(loss.detach())           # .item() here (train.py:126) would drain the GPU at every step
+            if on_step is not None:
+                on_step(steps_done, n_rows)
+            # the reference prints at batch 0 of EVERY epoch (train.py:128-129): with the 1-2 batches per epoch of an
+            # ETTh1-sized set that would be a device sync per step -- report on a step count instead
+            if steps_done == 1 or steps_done % 100 == 0:
+                flush()
+                if rank == 0:
+                    print(f"[Epoch {epoch}] [batch {batch}] loss: {loss_list[-1]:.6f}  "
+                          f"({seen / (time.time() - t0):.1f} samples/s)")
+            if max_steps and steps_done >= max_steps:
+                stop = True
+                break
+        if stop:
+            break
+        if args.mix_train:
+            sched.step()
+    if epoch is not None and not stop:
+        end_of_epoch(epoch)
     flush()
     tdist.barrier(dist, device)
     return loss_list
