@@ -238,6 +238,23 @@ def train_leg(dev, dist, rank, world, batch=1152, length=96, steps=30, warmup=4,
         out["ms_per_step_without_allreduce"] = el0 / steps * 1e3
         out["allreduce_share"] = max(0.0, 1.0 - el0 / el)
         out["allreduce"] = "one SUM all-reduce of the flat 3.7 MB fp32 gradient bucket per step (RCCL)"
+    if rank == 0 and dist is None and batch == 1152:
+        # the shape the reference's DEFAULT flags train at (mix-train, train.py:145): a 9,216-row batch is three length
+        # groups of ~3,072 rows = 384 rows per GPU and step on eight GPUs -- the step at that shard size, same model
+        t0 = time.perf_counter()
+        sub = torch.arange(384, device=dev)
+        for i in range(4):
+            drv.train_step(model, ddpm, opt, None, args, None, None, dev, 0, 1, latents, sub, 20_000 + i, eg)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(20):
+            drv.train_step(model, ddpm, opt, None, args, None, None, dev, 0, 1, latents, sub, 20_010 + i, eg)
+        torch.cuda.synchronize(dev)
+        ms384 = (time.perf_counter() - t0) / 20 * 1e3
+        out["mix_train_shard"] = {"rows_per_gpu_and_step": 384, "ms_per_step": ms384, "samples_per_s_per_gpu": 384 / ms384 * 1e3,
+                                  "frac_of_1152_row_rate": (384 / ms384) / (batch / (el / steps * 1e3)),
+                                  "note": "one GPU on the per-GPU shard of an 8-GPU mix-train step (three length groups per "
+                                          "9,216-row batch); no all-reduce in this figure"}
     if rank == 0:               # per-class kernel time, in situ (HIP events around every launch of 3 eager steps)
         h = model.t2s_handle(dev, batch)
         torch.cuda.synchronize(dev)
@@ -254,10 +271,23 @@ def train_leg(dev, dist, rank, world, batch=1152, length=96, steps=30, warmup=4,
         out["hbm_bytes_per_step_model"] = bytes_model["total"]
         out["hbm_bytes_model_note"] = bytes_model["note"]
         kernel_ms = sum(v["ms_per_step"] for v in br.values())
+        traffic = _train_traffic_from_profile(batch)
+        t_k = kernel_ms * 1e-3
+        tflops = FLOP_TRAIN_PER_SAMPLE * batch / t_k / 1e12
+        minimal = TRAIN_MINIMAL_U * bytes_model["u"]
+        # three readings of the same step, none hidden: SURVEY 8(d) names the bf16 MFMA peak as config 4's roofline
+        # (mfma_frac); the kernels are built HBM-bound, so `frac` prices the bytes they move BY DESIGN against 8 TB/s and
+        # hbm_frac_measured prices the bytes the PMC passes actually counted; bytes_vs_minimal says how far the design is
+        # from the byte-minimal one of DESIGN.md 4.3 (one recompute chain per half block, weight gradients inside the chains)
         out["roofline"] = {"bound": "hbm", "kernel": f"whole step (largest class: {top})",
-                           "achieved": bytes_model["total"] / (kernel_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                           "frac": bytes_model["total"] / (kernel_ms * 1e-3) / 1e9 / 8000.0,
-                           "traffic": _train_traffic_from_profile(batch),
+                           "achieved": bytes_model["total"] / t_k / 1e9, "peak": 8000.0, "unit": "GB/s",
+                           "frac": bytes_model["total"] / t_k / 1e9 / 8000.0,
+                           "traffic": traffic,
+                           "hbm_frac_measured": (traffic / t_k / 1e9 / 8000.0) if traffic else None,
+                           "bytes_minimal": minimal,
+                           "bytes_vs_minimal": (traffic / minimal) if traffic else bytes_model["total"] / minimal,
+                           "mfma_tflops": tflops, "mfma_peak_tflops": PEAK_BF16_MFMA_TFLOPS,
+                           "mfma_frac": tflops / PEAK_BF16_MFMA_TFLOPS,
                            "traffic_source": {"file": "profiles/train_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                                       "passes of tools/bench_train.py)", "measured_by_this_run": False},
                            "timing": f"sum of HIP-event launch durations over {n_t} eager steps = {kernel_ms:.2f} ms/step"}
@@ -292,10 +322,14 @@ TRAIN_U = {
 }
 
 
+TRAIN_MINIMAL_U = 168       # 42 u per block for the byte-minimal chain design = 23.8 GB at B = 1152
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak
+
+
 def train_bytes_model(batch):
     u = batch * 480 * 128 * 2
     units = sum(per * n for per, n in TRAIN_U.values())
-    return {"total": units * u, "note": f"{units:.1f} u per step by design (table TRAIN_U in bench.py / DESIGN.md 4.3), "
+    return {"total": units * u, "u": u, "note": f"{units:.1f} u per step by design (table TRAIN_U in bench.py / DESIGN.md 4.3), "
                                         f"u = {u / 1e6:.1f} MB = one bf16 (M,128) tensor"}
 
 
