@@ -616,6 +616,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="sampler lanes: 0 = the library's default (two half-batch chains on two streams when B is a multiple of 64 or B = 32; three at 96), 1 .. 4")
+    ap.add_argument("--loop-graph", type=int, default=-1, choices=[-1, 0, 1],
+                    help="what a lane's hipGraph holds: 1 = the whole loop (steps x 10 kernel nodes, one launch per run), 0 = one "
+                         "step replayed `steps` times, -1 = the library's default (include/t2s.h t2s_sampler_set_loop_graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training leg reported as `train`")
     ap.add_argument("--no-strong", action="store_true",
@@ -651,7 +654,7 @@ def main():
     model, vae = build_models(dev)
     model.set_math(args.math)
     sampler = Sampler(model, vae.decoder, args.backbone, args.diffusion_steps, args.cfg_scale, B, args.length,
-                      dev, use_graph=not args.no_graph, seed=2025, row0=rank * B, lanes=args.lanes)
+                      dev, use_graph=not args.no_graph, seed=2025, row0=rank * B, lanes=args.lanes, loop_graph=args.loop_graph)
     text = synth.make_text_embeddings(2025, B, row0=rank * B).to(dev)
     sampler.run(text, decode=True)                      # allocates persistent buffers, captures the graph
     for _ in range(max(0, args.warmup - 1)):

@@ -389,6 +389,12 @@ int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, const float* no
  * drain.  Bitwise the same result.  lanes: 0 = automatic (equal shares: two when the batch is a multiple of 64 or 32 series, three for 96; env
  * T2S_SAMPLER_LANES=<n> overrides), or 1 .. 4 chains of equal shares.  trace0 runs always use one lane. */
 int t2s_sampler_set_lanes(t2s_sampler* s, int lanes);
+/* What a lane's hipGraph holds (use_graph = 1): whole_loop = 1 -> the WHOLE loop, steps x (forward + update) kernel nodes,
+ * launched once per run ("whole loop in one hipGraph"); 0 -> ONE step, replayed `steps` times from the
+ * host; -1 -> the library's default (env T2S_SAMPLER_LOOP_GRAPH=0|1 overrides it).  Every node reads its loop index from
+ * the lane's device counter, so both forms run the same kernels in the same order: bitwise the same result.  Takes effect
+ * at the next t2s_sampler_run (the graphs are re-captured when the form changes). */
+int t2s_sampler_set_loop_graph(t2s_sampler* s, int whole_loop);
 /* Move the sampler to another shard position: global index of its first series (the Philox key of row r is
  * row0 + r).  Takes effect at the next t2s_sampler_run; the captured hipGraphs are kept (the kernels read the
  * value from device memory next to the step counter).  infer.py:66 loops over batches with one sampler. */

@@ -130,6 +130,7 @@ SYMBOLS = {
     "t2s_sampler_destroy": (None, [_VP]),
     "t2s_sampler_run": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "t2s_sampler_set_lanes": (_I, [_VP, _I]),
+    "t2s_sampler_set_loop_graph": (_I, [_VP, _I]),
     "t2s_sampler_set_row0": (_I, [_VP, _U32]),
     "t2s_sampler_graph_lanes": (_I, [_VP]),
     "t2s_sampler_lane_pool": (_I, []),

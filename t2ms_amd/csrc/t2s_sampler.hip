@@ -388,6 +388,8 @@ struct t2s_sampler {
     // lane's kernels fill those holes.  Results are bitwise those of one lane (batch-invariant kernels).
     int lanes_req = 0;            // 0 = automatic, 1 .. MAX_LANES (t2s_sampler_set_lanes)
     int lanes_cap = 0;            // lanes the graphs below were captured for
+    int whole_req = -1;           // t2s_sampler_set_loop_graph: 1 = the WHOLE loop is one graph per lane, 0 = one step, -1 = default
+    int whole_cap = 0;            // what the graphs below hold
     static constexpr int MAX_LANES = 4;
     hipGraph_t graph[MAX_LANES] = {};
     hipGraphExec_t exec[MAX_LANES] = {};
@@ -509,6 +511,14 @@ int enqueue_step(t2s_sampler* s, float* x, const float* text, const float* noise
     return T2S_OK;
 }
 
+// Whole-loop graphs by default?  Same-box A/B (tools/ab_loop_graph.sh, profiles/r04_loop_graph_ab.txt), series/s one-step /
+// whole-loop: rectified flow 100 steps at B = 1024 637.4 / 636.3 (-0.2 %, noise), at B = 32 569.3 / 574.7 (+0.9 %: the host's
+// 200 graph launches per run are on the critical path of a 56 ms run), DDPM 1000 steps at B = 256 63.70 / 63.75.  So: the
+// whole loop as ONE graph per lane for the step counts the authors sample with (10 - 100, scripts/script.sh), where it is
+// never slower and a capture is <= 2,560 nodes; the one-step graph beyond (a 1000-step loop would be 10,000 nodes per
+// lane for nothing).
+inline int loop_graph_default(int steps) { return steps <= 256; }
+
 void drop_graph(t2s_sampler* s) {
     for (int l = 0; l < t2s_sampler::MAX_LANES; ++l) {
         if (s->exec[l]) (void)hipGraphExecDestroy(s->exec[l]);
@@ -608,6 +618,12 @@ extern "C" int t2s_sampler_set_lanes(t2s_sampler* s, int lanes) {
     return T2S_OK;
 }
 
+extern "C" int t2s_sampler_set_loop_graph(t2s_sampler* s, int whole_loop) {
+    T2S_REQUIRE(s && (whole_loop == 0 || whole_loop == 1 || whole_loop == -1), "t2s_sampler_set_loop_graph: %d (1 whole loop, 0 one step, -1 default)", whole_loop);
+    s->whole_req = whole_loop;
+    return T2S_OK;
+}
+
 extern "C" int t2s_sampler_set_row0(t2s_sampler* s, uint32_t row0) {
     T2S_REQUIRE(s, "t2s_sampler_set_row0: NULL sampler");
     s->cfg.row0 = row0;   // uploaded next to the step counters at the start of every run: no re-capture
@@ -694,11 +710,21 @@ extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, cons
         while (lanes > 1 && nr[lanes - 1] == 0) --lanes;      // a batch too small for its last lane
     }
     hipStream_t lst[ML] = {st, s->side[1], s->side[2], s->side[3]};
-    if (graph_ok && (!s->exec[0] || s->lanes_cap != lanes || s->g_x != x || s->g_text != text || s->g_noise != noise)) {
+    // One graph per lane holds either ONE step (replayed `steps` times from the host) or the WHOLE loop (steps x 10 kernel
+    // nodes, launched once): every node reads its loop index from the lane's device counter, so the two are the same
+    // kernels in the same order.  Default: see loop_graph_default().
+    int whole = s->whole_req;
+    if (whole < 0) {
+        const char* e = getenv("T2S_SAMPLER_LOOP_GRAPH");
+        whole = e ? (atoi(e) != 0) : loop_graph_default(c.steps);
+    }
+    if (graph_ok && (!s->exec[0] || s->lanes_cap != lanes || s->whole_cap != whole || s->g_x != x || s->g_text != text ||
+                     s->g_noise != noise)) {
         drop_graph(s);
         for (int l = 0; l < lanes; ++l) {
             T2S_HIP_CHECK(hipStreamBeginCapture(lst[l], hipStreamCaptureModeThreadLocal));
-            rc = enqueue_step(s, x, text, noise, lst[l], l, r0[l], nr[l]);
+            rc = T2S_OK;
+            for (int j = 0; j < (whole ? c.steps : 1) && rc == T2S_OK; ++j) rc = enqueue_step(s, x, text, noise, lst[l], l, r0[l], nr[l]);
             hipError_t e = hipStreamEndCapture(lst[l], &s->graph[l]);
             if (rc != T2S_OK) {
                 drop_graph(s);
@@ -712,6 +738,7 @@ extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, cons
             T2S_HIP_CHECK(hipGraphInstantiate(&s->exec[l], s->graph[l], nullptr, nullptr, 0));
         }
         s->lanes_cap = lanes;
+        s->whole_cap = whole;
         s->g_x = x; s->g_text = text; s->g_noise = noise;
     }
     // the adaLN modulation of every step for this run's text (state-independent: off the loop's critical path)
@@ -724,7 +751,9 @@ extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, cons
         set_step_kernel<<<1, 64, 0, lst[l]>>>(s->step + 16 * l, 0, c.row0 + (uint32_t)r0[l]);
         T2S_LAUNCH_CHECK();
     }
-    for (int j = 0; j < c.steps; ++j) {
+    if (graph_ok && whole)
+        for (int l = 0; l < lanes; ++l) T2S_HIP_CHECK(hipGraphLaunch(s->exec[l], lst[l]));
+    for (int j = 0; j < c.steps && !(graph_ok && whole); ++j) {
         for (int l = 0; l < lanes; ++l) {
             if (graph_ok) {
                 T2S_HIP_CHECK(hipGraphLaunch(s->exec[l], lst[l]));

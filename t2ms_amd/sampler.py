@@ -79,7 +79,7 @@ def philox_uniform(n_rows: int, row_elems: int, seed: int, stream_id: int, row0:
 
 class Sampler:
     def __init__(self, model, decoder, backbone: str, steps: int, cfg_scale: float, batch: int, length: int,
-                 device, use_graph: bool = True, seed: int = 2025, row0: int = 0, lanes: int = 0):
+                 device, use_graph: bool = True, seed: int = 2025, row0: int = 0, lanes: int = 0, loop_graph: int = -1):
         """lanes: 0 = automatic (equal part-batch chains on own streams: two when the batch is a multiple of 64 or 32 series, three for 96), 1 .. 4 -- see
         t2s_sampler_set_lanes; a scheduling choice only, the results are bitwise the same."""
         self.device = torch.device(device)
@@ -90,6 +90,7 @@ class Sampler:
         self.batch, self.length, self.seed, self.row0 = int(batch), int(length), int(seed), int(row0)
         self.use_graph = bool(use_graph)
         self.lanes = int(lanes)
+        self.loop_graph = int(loop_graph)     # 1: the whole loop as one hipGraph per lane, 0: one step replayed, -1: library default
         self.stream = _sampler_stream(self.device)
         self.ptr = None
         self._create()
@@ -117,6 +118,7 @@ class Sampler:
             self.ptr = C.c_void_p()
             L.check(L.lib().t2s_sampler_create(dit, vae, C.byref(cfg), C.byref(self.ptr)), "t2s_sampler_create")
             L.check(L.lib().t2s_sampler_set_lanes(self.ptr, self.lanes), "t2s_sampler_set_lanes")
+            L.check(L.lib().t2s_sampler_set_loop_graph(self.ptr, self.loop_graph), "t2s_sampler_set_loop_graph")
         self._fin = weakref.finalize(self, L.lib().t2s_sampler_destroy, self.ptr)
         self._keep = (tvals, coef)
 

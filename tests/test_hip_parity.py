@@ -831,6 +831,27 @@ def test_every_launch_shape_reproduces_itself_beside_foreign_traffic(dev, dit, v
     torch.cuda.synchronize(dev)
 
 
+def test_whole_loop_graph_equals_step_graph_bitwise(dev, dit, vae):
+    """SURVEY 8(d) config 3 words the loop as "whole loop in one hipGraph": t2s_sampler_set_loop_graph(1) captures steps x
+    (forward + update) nodes per lane and launches them once; the default replays a one-step graph `steps` times.  Every
+    node reads its loop index from the lane's device counter, so the two -- and an eager run -- must agree bit for bit,
+    for both backbones, one and two lanes, and across a change of form on one sampler (re-capture)."""
+    from t2ms_amd.sampler import Sampler
+    for backbone, steps, cfg, B in (("flowmatching", 20, 5.0, 64), ("ddpm", 12, 9.0, 7)):
+        text = synth.make_text_embeddings(3, B).to(dev)
+        ref = Sampler(dit, vae.decoder, backbone, steps, cfg, B, 96, dev, use_graph=False, seed=9).run(text)
+        for lanes in (1, 2):
+            s = Sampler(dit, vae.decoder, backbone, steps, cfg, B, 96, dev, use_graph=True, seed=9, lanes=lanes, loop_graph=1)
+            lat, ser, _ = s.run(text)
+            assert torch.equal(lat, ref[0]) and torch.equal(ser, ref[1]), (backbone, lanes)
+            lat2, ser2 = s.run_inplace()                                  # the replay of the whole-loop graph
+            assert torch.equal(lat2, ref[0]) and torch.equal(ser2, ref[1])
+            L.check(L.lib().t2s_sampler_set_loop_graph(s.ptr, 0))         # back to the one-step form: re-captured
+            lat3, ser3 = s.run_inplace()
+            assert torch.equal(lat3, ref[0]) and torch.equal(ser3, ref[1])
+    assert L.lib().t2s_sampler_set_loop_graph(s.ptr, 2) != 0
+
+
 def test_two_host_threads_drive_two_samplers_on_one_device(dev, vae):
     """Every multi-lane sampler of a process runs on ONE per-device pool of lane streams (lane 0 included).  Two host
     threads driving two samplers at once would capture / record / launch on the same streams -- one thread's work pulled
