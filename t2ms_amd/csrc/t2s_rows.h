@@ -383,12 +383,7 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
         const f32x4* xr = reinterpret_cast<const f32x4*>(a.x_in) + (size_t)tile_src * 16 * 64 + lane;
 #pragma unroll
         for (int G = 0; G < 16; ++G) {
-#ifdef T2S_ROWS_ABL       /* timing-only build (tools/ab_sample.sh): no prologue loads = the bound of a perfect prefetch */
-            const f32x4 t = {0.25f * lane + G, 1.f, -1.f, 0.5f};
-            (void)xr;
-#else
             const f32x4 t = xr[G * 64];
-#endif
 #pragma unroll
             for (int e = 0; e < 4; ++e) x[G >> 2][4 * (G & 3) + e] = t[e];
         }
@@ -403,12 +398,7 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
             const f32x4* ar = reinterpret_cast<const f32x4*>(a.ao) + (size_t)tile * 16 * 64 + lane;
 #pragma unroll
             for (int G = 0; G < 16; ++G) {
-#ifdef T2S_ROWS_ABL
-                const f32x4 t = {0.125f * lane - G, 0.5f, -0.5f, 1.f};
-                (void)ar;
-#else
                 const f32x4 t = ar[G * 64];
-#endif
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bop[G >> 2][4 * (G & 3) + e] = t[e];
             }
