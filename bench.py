@@ -627,6 +627,9 @@ def main():
     ap.add_argument("--no-legs", action="store_true",
                     help="skip the driver legs: `infer_driver` (infer.py at the authors' flags), `train_driver` (train.py's own "
                          "mix-train loop) and `class_api` (the reference-style loop against the mirrored classes)")
+    ap.add_argument("--infer-driver-rows", type=int, default=2048, help="synthetic test rows of the `infer_driver` leg")
+    ap.add_argument("--train-driver-rows", type=int, default=200_000, help="synthetic rows PER LENGTH of the `train_driver` leg")
+    ap.add_argument("--train-driver-batch", type=int, default=9216, help="--batch_size of the `train_driver` leg (train.py:142)")
     ap.add_argument("--train-batch", type=int, default=1152, help="per-GPU batch of the training leg")
     ap.add_argument("--train-steps", type=int, default=30)
     ap.add_argument("--no-alt-math", action="store_true", help="skip the extra bf16x3 measurement reported as alt_math")
@@ -696,7 +699,9 @@ def main():
             train = {"error": f"{type(e).__name__}: {e}"}
     legs = {}
     if not args.no_legs:
-        for name, fn in (("infer_driver", infer_driver_leg), ("train_driver", train_driver_leg)):
+        for name, fn in (("infer_driver", lambda *a: infer_driver_leg(*a, rows=args.infer_driver_rows)),
+                         ("train_driver", lambda *a: train_driver_leg(*a, rows_per_length=args.train_driver_rows,
+                                                                     batch=args.train_driver_batch))):
             try:
                 legs[name] = fn(dev, dist, rank, world)
             except Exception as e:      # the headline line must still be printed; the failure is reported in it

@@ -119,7 +119,8 @@ def test_bench_distributed_branch_through_rccl_one_rank(tmp_path):
     """bench.py's N > 1 code (NCCL barrier + max-over-ranks around the timed region, the strong leg, the training leg
     with and without the gradient all-reduce) at world size 1 through RCCL."""
     r = _run([os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--diffusion-steps", "20",
-              "--batch", "64", "--no-cpu-baseline", "--no-alt-math", "--train-batch", "32", "--train-steps", "3"],
+              "--batch", "64", "--no-cpu-baseline", "--no-alt-math", "--train-batch", "32", "--train-steps", "3",
+              "--infer-driver-rows", "300", "--train-driver-rows", "2000", "--train-driver-batch", "96"],
              29563, True, REPO)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -129,3 +130,7 @@ def test_bench_distributed_branch_through_rccl_one_rank(tmp_path):
     tr = out["train"]
     assert tr["value"] > 0 and 0.0 <= tr["allreduce_share"] < 1.0 and np.isfinite(tr["loss"])
     assert "RCCL" in tr["allreduce"]
+    # the driver legs ran with the process group live: infer.py's final gather (all_gather on device tensors) and
+    # train.py's own loop (seed broadcast, bucket all-reduce, barrier) through RCCL -- no error swallowed
+    assert out["infer_driver"]["value"] > 0 and out["infer_driver"]["series"] == 300, out["infer_driver"]
+    assert out["train_driver"]["value"] > 0 and np.isfinite(out["train_driver"]["loss"]), out["train_driver"]

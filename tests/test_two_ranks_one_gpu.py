@@ -200,7 +200,8 @@ def test_plain_bench_command_starts_its_own_ranks(tmp_path):
 
 def test_bench_two_ranks_prints_one_json_line(tmp_path):
     r = _launch([os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--diffusion-steps", "20",
-                 "--batch", "64", "--no-cpu-baseline", "--train-batch", "32", "--train-steps", "3"], 29556, True, REPO)
+                 "--batch", "64", "--no-cpu-baseline", "--train-batch", "32", "--train-steps", "3",
+                 "--infer-driver-rows", "300", "--train-driver-rows", "2000", "--train-driver-batch", "96"], 29556, True, REPO)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
@@ -211,3 +212,6 @@ def test_bench_two_ranks_prints_one_json_line(tmp_path):
     assert st["scaling"] == "strong" and st["global_batch"] == 64 and st["per_gpu_batch"] == 32 and st["value"] > 0
     tr = out["train"]                 # the training leg ran on both ranks with the gradient all-reduce in it
     assert tr["global_batch"] == 64 and tr["value"] > 0 and 0.0 <= tr["allreduce_share"] < 1.0 and np.isfinite(tr["loss"])
+    # the real drivers under two ranks: infer.py (launches sharded over the ranks, ONE final gather) and train.py's loop
+    assert out["infer_driver"]["n_gpus"] == 2 and out["infer_driver"]["series"] == 300 and out["infer_driver"]["value"] > 0
+    assert out["train_driver"]["n_gpus"] == 2 and out["train_driver"]["value"] > 0, out["train_driver"]
