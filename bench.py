@@ -177,7 +177,7 @@ TRAIN_CLASSES = ("attention", "row_chain", "other", "train_gemm", "train_attn_fw
                  "train_elementwise", "train_tail")
 
 
-def train_leg(dev, dist, rank, world, batch=1152, length=96, steps=30, warmup=4, dtype="bf16"):
+def train_leg(dev, dist, rank, world, batch=1152, length=96, steps=30, warmup=4, dtype="bf16", mix_shard=True):
     """BASELINE configs[3] shape under the same clock discipline as the headline: DiT training step of train.py
     (train.train_step: cached LA-VAE latents -> q_sample -> forward -> MSE -> backward -> ONE flat-bucket all-reduce
     -> fused AdamW), bf16 MFMA operands with fp32 master weights, per-GPU batch 1152 (global 9216 on 8 GPUs), L=96,
@@ -238,7 +238,7 @@ def train_leg(dev, dist, rank, world, batch=1152, length=96, steps=30, warmup=4,
         out["ms_per_step_without_allreduce"] = el0 / steps * 1e3
         out["allreduce_share"] = max(0.0, 1.0 - el0 / el)
         out["allreduce"] = "one SUM all-reduce of the flat 3.7 MB fp32 gradient bucket per step (RCCL)"
-    if rank == 0 and dist is None and batch == 1152:
+    if rank == 0 and dist is None and batch == 1152 and mix_shard:
         # the shape the reference's DEFAULT flags train at (mix-train, train.py:145): a 9,216-row batch is three length
         # groups of ~3,072 rows = 384 rows per GPU and step on eight GPUs -- the step at that shard size, same model
         t0 = time.perf_counter()

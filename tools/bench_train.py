@@ -28,7 +28,8 @@ def main():
     torch.cuda.set_device(tdist.local_device_index())
     dev = torch.device("cuda", tdist.local_device_index())
     dist = tdist.init("nccl", dev)
-    out = bench.train_leg(dev, dist, rank, world, batch=a.batch, steps=a.steps, warmup=a.warmup, dtype=a.dtype)
+    out = bench.train_leg(dev, dist, rank, world, batch=a.batch, steps=a.steps, warmup=a.warmup, dtype=a.dtype,
+                          mix_shard=False)     # the PMC passes count bytes per step: only whole steps of ONE shape
     if rank == 0:
         print(json.dumps(out))
     tdist.barrier(dist, dev)

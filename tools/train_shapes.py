@@ -25,7 +25,7 @@ def main():
     dev = torch.device("cuda", 0)
     rows = []
     for b in [int(x) for x in a.batches.split(",")]:
-        o = bench.train_leg(dev, None, 0, 1, batch=b, steps=a.steps, warmup=3)
+        o = bench.train_leg(dev, None, 0, 1, batch=b, steps=a.steps, warmup=3, mix_shard=False)
         kc = {k: round(v["ms_per_step"], 3) for k, v in o["kernel_classes"].items()}
         rows.append({"batch": b, "ms_per_step": round(o["ms_per_step"], 3), "us_per_row": round(o["ms_per_step"] * 1e3 / b, 3),
                      "samples_per_s": round(o["value"]), "kernel_ms": round(sum(kc.values()), 3), "classes": kc})
