@@ -537,6 +537,46 @@ def test_infer_coalesced_launches_write_the_per_batch_files_bitwise(dev, tmp_pat
     assert np.isfinite(got[0][1]).all() and float(np.abs(got[0][1]).max()) > 0
 
 
+@pytest.mark.parametrize("backbone,steps,cfg", [("ddpm", 6, 9.0), ("flowmatching", 5, 7.0)])
+def test_infer_driver_files_equal_the_oracle_end_to_end(dev, tmp_path, monkeypatch, backbone, steps, cfg):
+    """infer.py itself against the CPU oracle: the four files of a DiT run (loader order, encoder, coalesced launches over
+    a ragged tail, Philox x_T and per-step draws keyed by the GLOBAL row, CFG loop, decoder) must be what the oracle's
+    restatement of infer.py:65-123 gives on the rows the files name -- the loop of the reference, not just its shapes."""
+    import infer as drv
+    from datafactory.dataset import SyntheticT2SDataset
+    monkeypatch.chdir(tmp_path)
+    seed, L_, n_ds, bs = 21, 48, 11, 2
+    save = str(tmp_path / "res")
+    drv.main(["--dataset_name", f"ETTh1_{L_}", "--backbone", backbone, "--denoiser", "DiT", "--total_step", str(steps),
+              "--cfg_scale", str(cfg), "--batch_size", str(bs), "--save_path", save, "--synthetic", str(n_ds), "--random_init",
+              "--seed", str(seed), "--launch_batch", "4"])                    # launches of 4 + 4 + 2 rows
+    out = os.path.join(save, "generation", f"{backbone}_DiT_ETTh1_{L_}_{cfg}_{steps}")
+    x1 = np.load(os.path.join(out, "x_1.npy"))[:, :, 0]
+    xt = np.load(os.path.join(out, "x_t.npy"))[:, :, 0]
+    lat = np.load(os.path.join(out, "x_t_latent_dec_array.npy"))
+    enc = np.load(os.path.join(out, "x_t_latent_enc_array.npy"))
+    n = (n_ds // bs) * bs
+    assert x1.shape == xt.shape == (n, L_) and lat.shape == enc.shape == (n, 64, 30)
+    ds = SyntheticT2SDataset(n_ds, L_)
+    rows = [int(np.argmin(np.abs(ds.samples - x1[i][None]).sum(axis=1))) for i in range(n)]
+    assert len(set(rows)) == n and np.allclose(ds.samples[rows], x1, atol=1e-6)       # a shuffled subset, each row once
+    text = torch.from_numpy(ds.embedding[rows]).float()
+    sd, vsd = synth.make_dit_state_dict(seed), synth.make_vae_state_dict(seed)
+    with torch.no_grad():
+        z_ref, _ = O.vae_encode(vsd, torch.from_numpy(x1))
+        x_T = torch.from_numpy(O.device_normal(seed, 0xFFFFFFFF, 0, n)).view(n, 64, 30)
+        if backbone == "ddpm":
+            noises = [torch.from_numpy(O.device_normal(seed, j, 0, n)).view(n, 64, 30) for j in range(steps)]
+            ref = O.sample_ddpm(sd, x_T, text, steps, cfg, noises)
+        else:
+            ref = O.sample_rf(sd, x_T, text, steps, cfg)
+        series, _ = O.vae_decode(vsd, ref, L_)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float(np.abs(enc - z_ref.numpy()).max()) < 1e-5
+    assert float(np.abs(lat - ref.numpy()).max()) < 1e-4 * scale, float(np.abs(lat - ref.numpy()).max())
+    assert float(np.abs(xt - series.reshape(n, L_).numpy()).max()) < 1e-4 * scale
+
+
 def test_infer_driver_run_multi_layout(dev, tmp_path, monkeypatch):
     """`--run_multi True` (infer.py:148-164): the base run plus run_0 .. run_9, each with the four files.  The test loader
     shuffles (dataloader.py:111 does too), so every run holds the same ground-truth rows in its own order; the generated

@@ -151,6 +151,58 @@ def test_train_driver_resident_batches_equal_the_loader_pass(dev, tmp_path, monk
     assert short == la[:4] and [n for n, _ in ticks] == [1, 2, 3, 4] and all(r > 0 for _, r in ticks)
 
 
+def test_train_driver_first_steps_equal_the_oracle(dev, tmp_path, monkeypatch):
+    """train.py itself against the CPU oracle, fp32 arithmetic: the losses of the first optimisation steps of a split-train
+    DDPM run must be what the oracle's restatement of train.py:103-127 gives on the rows and CFG coins the driver used
+    (recorded at its `train_step` calls; that the resident order IS the loader's order is
+    test_train_driver_resident_batches_equal_the_loader_pass) -- latents from the (cached) frozen encoder, per-row
+    t = floor(u T) with u from the library's Philox uniform stream, targets from its normal stream, AdamW + OneCycleLR
+    between the steps (oracle side: torch autograd, torch.optim.AdamW)."""
+    import train as drv
+    from datafactory.dataset import SyntheticT2SDataset
+    monkeypatch.chdir(tmp_path)
+    seed, B, n_ds, T, n_steps = 13, 6, 12, 100, 3
+    argv = ["--dataset_name", "ETTh1_96", "--backbone", "ddpm", "--batch_size", str(B), "--epochs", "2", "--save_path",
+            str(tmp_path / "res"), "--synthetic", str(n_ds), "--random_init", "--checkpoint_path", "", "--seed", str(seed),
+            "--split_train", "--max_steps", str(n_steps)]
+    calls, real = [], drv.train_step
+
+    def spy(model, backbone, opt, dist, args, x_1, emb, device, rank, world, latents=None, idx=None, step_no=0,
+            emb_table=None, drop_text=None):
+        calls.append((idx.cpu().clone(), bool(drop_text), int(step_no), float(opt.param_groups[0]["lr"])))
+        return real(model, backbone, opt, dist, args, x_1, emb, device, rank, world, latents, idx, step_no, emb_table, drop_text)
+
+    monkeypatch.setattr(drv, "train_step", spy)
+    losses = drv.train(drv.get_args(argv))
+    assert len(losses) == n_steps == len(calls) and [c[2] for c in calls] == [0, 1, 2]
+    assert sorted(torch.cat([calls[0][0], calls[1][0]]).tolist()) == list(range(n_ds))      # epoch 0 = a permutation
+    # ---- the oracle's run of the same three steps
+    ds = SyntheticT2SDataset(n_ds, 96)
+    sd = {k: v.clone().requires_grad_(not k.startswith(("pos_embed", "unpatch."))) for k, v in synth.make_dit_state_dict(seed).items()}
+    vsd = synth.make_vae_state_dict(seed)
+    opt = torch.optim.AdamW([v for v in sd.values() if v.requires_grad], lr=1e-4, weight_decay=0.0)
+    tab = O.ddpm_tables(T)
+    want = []
+    for idx, coin, step_no, lr in calls:
+        x1 = torch.from_numpy(ds.samples[idx.numpy()]).float()
+        emb = torch.from_numpy(ds.embedding[idx.numpy()]).float()
+        with torch.no_grad():
+            z, _ = O.vae_encode(vsd, x1)
+        u = torch.from_numpy(O.device_uniform(seed ^ drv.TIME_KEY, step_no, 0, B, 1)).view(B)
+        t = torch.floor(u * T).long()
+        eps = torch.from_numpy(O.device_normal(seed ^ 0x7261696E, step_no, 0, B)).view(B, 64, 30)
+        pred = O.dit_forward(sd, O.ddpm_q_sample(tab, z, t, eps), t, None if coin else emb)
+        loss = torch.nn.functional.mse_loss(pred, eps)
+        opt.zero_grad()
+        loss.backward()
+        opt.param_groups[0]["lr"] = lr              # the OneCycleLR value the driver stepped with (4e-6 at the start)
+        opt.step()
+        want.append(float(loss.detach()))
+    assert 0 < calls[0][3] < 1e-4
+    for a, b in zip(losses, want):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), (losses, want)
+
+
 def test_train_step_reference_fixture(golden_dir, dev):
     """Fixture (9): loss and the 48 per-parameter gradient norms produced by the reference itself."""
     g = np.load(os.path.join(golden_dir, "train_step.npz"))
