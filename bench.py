@@ -450,7 +450,7 @@ def infer_driver_leg(dev, dist, rank, world, rows=2048):
 def class_api_leg(dev, batch=256, length=96, total_steps=1000, cfg=9.0, warm=10, timed=100):
     """The loop of reference infer.py:76-88 written against the mirrored classes -- per diffusion step two
     `model(input=, t=, text_input=)` calls, the CFG combination as torch glue, `ddpm.p_sample` -- i.e. the literal drop-in
-    of INTEGRATION.md section 1, eager launches, no fused sampler.  `timed` steps after `warm`, extrapolated to
+    of INTEGRATION.md section 1, eager launches, no fused sampler (the mirror pairs the two calls into one CFG pass).  `timed` steps after `warm`, extrapolated to
     `total_steps` (every step costs the same) + one decode; beside it the fused sampler as ONE lane (same shape)."""
     from model.backbone.DDPM import DDPM
     from t2ms_amd import synth

@@ -89,6 +89,7 @@ SYMBOLS = {
     "t2s_time_embedding": (_I, [_VP, _VP, _VP, _I, _VP]),
     "t2s_dit_forward": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP]),
     "t2s_dit_forward_cfg": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
+    "t2s_dit_forward_cfg_rows": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _I, _VP]),
     "t2s_dit_read_stream": (_I, [_VP, _VP, _I, _VP]),
     "t2s_dit_timing_begin": (_I, [_VP]),
     "t2s_dit_timing_end": (_I, [_VP, C.POINTER(C.c_double)]),

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void adaln_kernel(float* __restrict__ mod, con
         trow = rl / table_rows;
         xrow = rl - trow * table_rows - 1;
     } else {
-        trow = step_ptr ? *step_ptr : (temb_rows == 1 ? 0 : rl);
+        trow = step_ptr ? *step_ptr : (temb_rows == 1 ? 0 : rl % temb_rows);   // a CFG pass (S = 2 temb_rows): both branches read row b
         xrow = rl >= uncond_rows ? rl - uncond_rows : -1;
     }
     const f32x4* tp = reinterpret_cast<const f32x4*>(temb + (size_t)trow * D) + half;
@@ -604,6 +604,15 @@ int t2s_dit_forward_cfg(t2s_dit* h, const float* x, const float* temb, const flo
                 h->max_seqs);
     return t2s::dit_forward_cfg_step(h, x, temb, nullptr, text, out_uncond, out_cond, B,
                                      (hipStream_t)stream, 0, nullptr, 0, 0);
+}
+
+int t2s_dit_forward_cfg_rows(t2s_dit* h, const float* x, const float* temb, int temb_rows, const float* text,
+                             float* out_uncond, float* out_cond, int B, void* stream) {
+    T2S_REQUIRE(h && x && temb && text && out_uncond && out_cond, "t2s_dit_forward_cfg_rows: NULL argument");
+    T2S_REQUIRE(B > 0 && 2 * B <= h->max_seqs, "t2s_dit_forward_cfg_rows: 2*B=%d exceeds max_seqs=%d", 2 * B, h->max_seqs);
+    T2S_REQUIRE(temb_rows == 1 || temb_rows == B, "t2s_dit_forward_cfg_rows: temb_rows=%d must be 1 or B=%d", temb_rows, B);
+    return run_forward(h, x, B, 2 * B, B, temb, temb_rows, nullptr, text, out_uncond, out_cond, B, (hipStream_t)stream,
+                            /*keep_stream=*/false);
 }
 
 int t2s_dit_timing_begin(t2s_dit* h) {

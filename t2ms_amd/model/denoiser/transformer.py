@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import itertools
+import os
 import math
 import weakref
 
@@ -310,7 +311,7 @@ class Transformer(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         for k in ("_t2s_h", "_t2s_dev", "_t2s_stamp", "_t2s_math_applied", "_t2s_bucket", "_t2s_flat_grad", "_t2s_fwd_gen",
-                  "_t2s_ws"):
+                  "_t2s_ws", "_t2s_pair"):
             state.pop(k, None)
         return state
 
@@ -327,6 +328,17 @@ class Transformer(nn.Module):
         return self._forward_nograd(input, t, text_input)
 
     def _forward_nograd(self, input, t, text_input):
+        """One forward -- or, once the reference's sampling pattern has been seen, half of a PAIR.
+
+        infer.py:79-80 / 85-86 calls `model(x_t, t, None)` and then `model(x_t, t, emb)` on the SAME x_t and t in every
+        diffusion step.  Run one by one, each call is its own chain of ~10 launches (at the reference's default loader
+        batch of 2 that is twice the launch floor of a step, and the unconditional branch cannot share the patchify); as
+        ONE 2B-sequence classifier-free-guidance pass (t2s_dit_forward_cfg_rows) the two branches cost one chain -- and the
+        results are the same bits (rows are batch-invariant; tested).  So: after a text-free call has been followed by a
+        conditional call on the same (x_t, t), the next text-free call runs the pass with the remembered text and keeps
+        the conditional output; the conditional call that follows hands it out if -- and only if -- x_t, t and the text are
+        the very tensors (storage, version, shape) the pass read.  Anything else (another text, a changed x_t, a lone
+        text-free call) falls back to plain forwards and disarms the speculation until the pattern shows again."""
         dev = input.device
         B = input.shape[0]
         x = L.as_f32(input)
@@ -338,16 +350,50 @@ class Transformer(nn.Module):
             text = L.as_f32(text_input)
             if tuple(text.shape) != (B, EMB):
                 raise L.T2SError(f"Transformer.forward: text_input must be ({B},128), got {tuple(text.shape)}")
+        pair = self.__dict__.setdefault("_t2s_pair", {"armed": False, "last_uncond": None, "text": None, "stash": None})
+        key_x, key_t = _tensor_key(input), _tensor_key(t)
+        if text is not None and pair["stash"] is not None:
+            # the stash HOLDS the tensors the pass read: their storage cannot have been handed to another tensor meanwhile,
+            # so equal (address, version, geometry) means equal contents
+            held, keys, stamp, out_c = pair["stash"]        # `held` only keeps the storages alive; `keys` were taken at the pass
+            pair["stash"] = None
+            del held
+            if keys == (key_x, key_t, _tensor_key(text_input)) and stamp == self._param_stamp():
+                return out_c                                   # the pass of the text-free call already computed this branch
+            pair["armed"] = False                              # speculation missed: back to plain forwards
         with torch.cuda.device(dev):
-            h = self.t2s_handle(dev, B)
+            speculate = (text is None and pair["armed"] and pair["text"] is not None and pair["text"].shape[0] == B
+                         and pair["text"].device == dev and not os.environ.get("T2S_NO_PAIRING"))
+            h = self.t2s_handle(dev, 2 * B if speculate else B)
             st = L.stream_ptr(dev)
             temb = torch.empty(B, EMB, device=dev, dtype=torch.float32)
             out = torch.empty(B, LAT_W, LAT_H, device=dev, dtype=torch.float32)
             lib = L.lib()
             L.check(lib.t2s_time_embedding(h, L.dev_ptr(tf, "t"), L.dev_ptr(temb), B, st), "t2s_time_embedding")
-            L.check(lib.t2s_dit_forward(h, L.dev_ptr(x, "input"), L.dev_ptr(temb), B, L.dev_ptr(text, "text_input"),
-                                        L.dev_ptr(out), B, st), "t2s_dit_forward")
+            if speculate:
+                ptext = pair["text"]
+                out_c = torch.empty_like(out)
+                L.check(lib.t2s_dit_forward_cfg_rows(h, L.dev_ptr(x, "input"), L.dev_ptr(temb), B, L.dev_ptr(L.as_f32(ptext)),
+                                                     L.dev_ptr(out), L.dev_ptr(out_c), B, st), "t2s_dit_forward_cfg_rows")
+                pair["stash"] = ((input, t, ptext), (key_x, key_t, _tensor_key(ptext)), self.__dict__.get("_t2s_stamp"), out_c)
+            else:
+                L.check(lib.t2s_dit_forward(h, L.dev_ptr(x, "input"), L.dev_ptr(temb), B, L.dev_ptr(text, "text_input"),
+                                            L.dev_ptr(out), B, st), "t2s_dit_forward")
+        if text is None:
+            pair["last_uncond"] = (key_x, key_t)
+        else:
+            if pair["last_uncond"] == (key_x, key_t):          # the pattern: arm, and remember THIS text tensor
+                pair["armed"], pair["text"] = True, text_input
+            pair["last_uncond"] = None
         return out
+
+    def _param_stamp(self):
+        return tuple([(p.data_ptr(), p._version) for p in self._dit_tensors()])
+
+
+def _tensor_key(t):
+    """Identity of a tensor's contents as far as the host can know it: storage address, in-place version, geometry."""
+    return (t.data_ptr(), t._version, tuple(t.shape), t.dtype, tuple(t.stride()))
 
 
 for _cls in (Transformer, Transformerlayer, TimeEmbedding, InverseLatentEmbedding, LatentEmbedding):

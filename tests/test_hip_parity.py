@@ -495,6 +495,68 @@ def test_trace_and_perf_mode_sharding(dev, vae):
     assert tr.shape == (8, 48) and torch.equal(tr[-1], sb[0])
 
 
+def test_class_api_pairs_the_two_cfg_calls_without_changing_a_bit(dev):
+    """The mirror runs the reference loop's `model(x_t, t, None)` / `model(x_t, t, emb)` pair (infer.py:79-80, 85-86) as ONE
+    2B-sequence CFG pass once it has seen the pattern, handing the conditional half out at the second call.  Every output
+    must equal the un-paired forwards bit for bit, and every way the pattern can break must fall back to plain forwards:
+    another text tensor, an x_t written in place between the two calls, a per-row t, a lone text-free call, new weights."""
+    from model.denoiser.transformer import Transformer
+
+    def fresh():
+        m = Transformer()
+        m.load_state_dict(synth.make_dit_state_dict(31337, gain=0.7), strict=True)
+        return m.to(dev).eval()
+
+    m, ref = fresh(), fresh()
+    B = 5
+    emb = synth.make_text_embeddings(3, B).to(dev)
+    emb2 = synth.make_text_embeddings(4, B).to(dev)
+
+    def plain(x, t, text):                      # a model that never pairs: every call on its own
+        ref.__dict__.pop("_t2s_pair", None)
+        return ref(input=x, t=t, text_input=text)
+
+    with torch.no_grad():
+        x = synth.make_latents(9, B).to(dev)
+        hits = 0
+        for j in range(6):
+            t = torch.full((B,), 17 - j, dtype=torch.long, device=dev) if j != 3 else torch.arange(B, device=dev) * 7   # per-row t
+            u = m(input=x, t=t, text_input=None)
+            stashed = m.__dict__["_t2s_pair"]["stash"] is not None
+            c = m(input=x, t=t, text_input=emb)
+            hits += int(stashed and m.__dict__["_t2s_pair"]["stash"] is None and m.__dict__["_t2s_pair"]["armed"])
+            assert torch.equal(u, plain(x, t, None)) and torch.equal(c, plain(x, t, emb)), j
+            x = x + 0.1 * (u + 2.0 * (c - u))
+        assert hits == 5                          # every step after the first ran as one pass (the per-row t included)
+        # another text tensor at the conditional call: the stash must not be handed out
+        t = torch.full((B,), 3, dtype=torch.long, device=dev)
+        u = m(input=x, t=t, text_input=None)
+        c = m(input=x, t=t, text_input=emb2)
+        assert torch.equal(c, plain(x, t, emb2))
+        assert m.__dict__["_t2s_pair"]["stash"] is None and m.__dict__["_t2s_pair"]["text"] is emb2    # re-armed on the NEW text
+        # re-arm, then write x_t in place between the two calls (version bump): recomputed on the new contents
+        for _ in range(2):
+            u = m(input=x, t=t, text_input=None)
+            c = m(input=x, t=t, text_input=emb)
+        u = m(input=x, t=t, text_input=None)
+        assert m.__dict__["_t2s_pair"]["stash"] is not None
+        x.mul_(0.5)
+        c = m(input=x, t=t, text_input=emb)
+        assert torch.equal(c, plain(x, t, emb))
+        # lone text-free calls (e.g. an unconditional sampler) stay correct, armed or not
+        for _ in range(3):
+            assert torch.equal(m(input=x, t=t, text_input=None), plain(x, t, None))
+        # new weights between the two calls of a pair: the stash is stale and must be dropped
+        for _ in range(2):
+            m(input=x, t=t, text_input=None)
+            m(input=x, t=t, text_input=emb)
+        m(input=x, t=t, text_input=None)
+        sd2 = synth.make_dit_state_dict(77, gain=0.7)
+        m.load_state_dict(sd2, strict=True)
+        ref.load_state_dict(sd2, strict=True)
+        assert torch.equal(m(input=x, t=t, text_input=emb), plain(x, t, emb))
+
+
 def test_infer_driver_end_to_end(dev, tmp_path, monkeypatch):
     """The drop-in driver: reference flags and path derivations, the four .npy files evaluation.py reads
     (infer.py:118-123,146), via synthetic data + seeded weights."""
