@@ -143,3 +143,36 @@ def group_by_dataset(idx: torch.Tensor, starts) -> list:
         if sel.numel():
             out.append((w, sel - int(starts[w])))
     return out
+
+
+def plan_epochs(loader, starts, mix: bool, first_epoch: int, last_epoch: int, min_steps: int = 64, coin_p: float = 0.3):
+    """Index batches of SEVERAL epochs at once for a resident training loop (train.py of this repository).
+
+    For epochs first_epoch, first_epoch + 1, ... (< last_epoch) until the plan holds >= min_steps optimisation steps, the
+    global CPU generator is consumed exactly as a loader pass + the steps' classifier-free-guidance coins consume it (two
+    draws when the pass starts -- epoch_index_batches -- then ONE `torch.rand(1) < coin_p` per length group in visiting
+    order, train.py:120-122 of the reference), the rows of each batch are put in custom_collate_fn's group order (stable:
+    dataset 0's rows first, each group in batch order) and made local to their dataset.
+
+    -> (plans, flat): plans = [(epoch, rows (nb, B) int64, groups [[(dataset, count)]], coins [[bool]])]; flat = every
+    plan's rows concatenated (ONE host -> device copy serves all of its steps: batch b of plan p starts at
+    sum(rows.numel() of earlier plans) + b * B, its groups follow each other)."""
+    plans, n_steps, e = [], 0, first_epoch
+    starts_t = torch.as_tensor(list(starts), dtype=torch.int64)
+    while e < last_epoch and (not plans or n_steps < min_steps):
+        batches = epoch_index_batches(loader)                                       # (nb, B) rows of the concatenation
+        if mix and len(starts) > 1:
+            which = torch.bucketize(batches, starts_t[1:], right=True)
+            order = torch.argsort(which, dim=1, stable=True)
+            which = which.gather(1, order)
+            rows = batches.gather(1, order) - starts_t[which]
+            counts = torch.stack([(which == w).sum(1) for w in range(len(starts))], dim=1)        # (nb, groups)
+        else:
+            rows, counts = batches, torch.full((batches.shape[0], 1), batches.shape[1], dtype=torch.int64)
+        groups = [[(w, int(c)) for w, c in enumerate(row) if c] for row in counts.tolist()]
+        coins = [[bool(torch.rand(1) < coin_p) for _ in g] for g in groups]
+        plans.append((e, rows, groups, coins))
+        n_steps += sum(len(g) for g in groups)
+        e += 1
+    flat = torch.cat([p[1].reshape(-1) for p in plans]) if plans else torch.empty(0, dtype=torch.int64)
+    return plans, flat

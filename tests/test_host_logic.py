@@ -12,7 +12,7 @@ import pytest
 import torch
 
 from datafactory.dataloader import (AlternatingDataset, custom_collate_fn, epoch_index_batches, group_by_dataset,
-                                    loader_provider, resident_tables)
+                                    loader_provider, plan_epochs, resident_tables)
 from datafactory.dataset import SyntheticT2SDataset
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -56,6 +56,48 @@ def test_epoch_index_batches_is_one_pass_over_the_loader(mix, bs):
     assert len(real) == len(got) == 3 * len(loader)
     for a, b in zip(real, got):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("mix,bs,n_rows,epochs,min_steps", [(True, 7, 11, 9, 10), (False, 4, 11, 7, 5), (True, 5, 3, 12, 4)])
+def test_epoch_plans_replay_the_loader_passes_and_coins_across_plan_boundaries(mix, bs, n_rows, epochs, min_steps):
+    """train.py's resident path uploads index batches as multi-epoch PLANS (datafactory.plan_epochs).  Walking plan after
+    plan must visit, step by step, the rows the reference-style loop visits -- `for epoch: for data in loader: for group in
+    data: coin = torch.rand(1) < 0.3` (train.py:52-95 / 101-131) -- with the same coins, across epoch AND plan boundaries
+    (plans of several epochs, a plan that ends exactly at an epoch, more plans than one), and leave the CPU generator in the
+    same state."""
+    args = _args(mix_train=mix, batch_size=bs, dataset_name="ETTh1" if mix else "ETTh1_24", synthetic=n_rows)
+    ds, loader = loader_provider(args, "train")
+    tabs = resident_tables(ds)
+    starts = [st for _, _, st in tabs]
+    torch.manual_seed(5)
+    want = []                                                     # (epoch, rows of the group as series, coin)
+    for e in range(epochs):
+        for data in loader:
+            for g in (data if mix else [data]):
+                want.append((e, g[1].numpy(), bool(torch.rand(1) < 0.3)))
+    after_real = float(torch.rand(1))
+    torch.manual_seed(5)
+    got, e, n_plans = [], 0, 0
+    while e < epochs:
+        plans, flat = plan_epochs(loader, starts, mix, e, epochs, min_steps)
+        assert plans and [p[0] for p in plans] == list(range(e, e + len(plans)))
+        assert sum(len(g) for p in plans[:-1] for g in p[2]) < min_steps          # stops as soon as the plan is long enough
+        off = 0
+        for ep, rows, groups, coins in plans:
+            for b in range(rows.shape[0]):
+                o = off + b * rows.shape[1]
+                for (w, c), coin in zip(groups[b], coins[b]):
+                    got.append((ep, tabs[w][0][flat[o:o + c].numpy()], coin))
+                    o += c
+                assert o == off + (b + 1) * rows.shape[1]
+            off += rows.numel()
+        assert off == flat.numel()
+        e += len(plans)
+        n_plans += 1
+    assert float(torch.rand(1)) == after_real
+    assert n_plans > 1 and len(got) == len(want) > 0
+    for (ea, ra, ca), (eb, rb, cb) in zip(want, got):
+        assert ea == eb and ca == cb and np.array_equal(ra, rb)
 
 
 def test_group_by_dataset_is_the_collate_grouping():

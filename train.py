@@ -29,7 +29,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-from datafactory.dataloader import epoch_index_batches, group_by_dataset, loader_provider, resident_tables   # noqa: E402
+from datafactory.dataloader import loader_provider, plan_epochs, resident_tables   # noqa: E402
 from model.backbone.DDPM import DDPM                          # noqa: E402
 from model.backbone.rectified_flow import RectifiedFlow      # noqa: E402
 from model.denoiser.transformer import Transformer            # noqa: E402
@@ -260,26 +260,6 @@ def train(args):
     # optimisation steps even for a set with one batch per epoch -- and a step slices it in place.
     PLAN_STEPS = 64
 
-    def plan_epochs(first_epoch):
-        plans, n_steps, e = [], 0, first_epoch
-        while e < args.epochs and (not plans or n_steps < PLAN_STEPS):
-            batches = epoch_index_batches(dataloader)                                   # (nb, B) rows of the concatenation
-            if args.mix_train and len(starts) > 1:
-                which = torch.bucketize(batches, torch.as_tensor(starts[1:], dtype=torch.int64), right=True)
-                order = torch.argsort(which, dim=1, stable=True)
-                which = which.gather(1, order)
-                rows = batches.gather(1, order) - torch.as_tensor(starts, dtype=torch.int64)[which]
-                counts = torch.stack([(which == w).sum(1) for w in range(len(starts))], dim=1)   # (nb, groups)
-            else:
-                rows, counts = batches, torch.full((batches.shape[0], 1), batches.shape[1], dtype=torch.int64)
-            groups = [[(w, int(c)) for w, c in enumerate(row) if c] for row in counts.tolist()]
-            coins = [[bool(torch.rand(1) < 0.3) for _ in g] for g in groups]            # train.py:120-122, in visiting order
-            plans.append((e, rows, groups, coins))
-            n_steps += sum(len(g) for g in groups)
-            e += 1
-        flat = torch.cat([p[1].reshape(-1) for p in plans]) if plans else torch.empty(0, dtype=torch.int64)
-        return plans, _h2d(flat, device)
-
     def epoch_batches(first_epoch):
         """-> (epoch, batch index, [(x_1, emb, latents, idx, emb_table, coin)]) for every loader batch from `first_epoch` on."""
         if not resident:
@@ -291,7 +271,8 @@ def train(args):
             return
         e = first_epoch
         while e < args.epochs:
-            plans, flat_dev = plan_epochs(e)
+            plans, flat = plan_epochs(dataloader, starts, args.mix_train, e, args.epochs, PLAN_STEPS)
+            flat_dev = _h2d(flat, device)
             off = 0
             for ep, rows, groups, coins in plans:
                 for b in range(rows.shape[0]):
