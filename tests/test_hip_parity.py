@@ -669,6 +669,41 @@ def test_infer_driver_run_multi_layout(dev, tmp_path, monkeypatch):
             assert not np.array_equal(gens[a], gens[b]), (a, b)
 
 
+def test_evaluation_driver_reads_the_infer_layout_and_writes_the_reference_json(dev, tmp_path, monkeypatch):
+    """evaluation.py (drop-in for the reference's, evaluation.py:269-314) on what `infer.py --run_multi True` wrote: the two
+    JSON files under {save_path}/evaluation/{model_name}/ with the reference's keys, the values equal to the metric kernels
+    called directly on the files the reference pairs (x_1 of run_0 with the base x_t; x_1 of run_9 with the ten stacked
+    runs); `--align_runs` pairs every run's rows with their own ground truth."""
+    import glob
+    import json
+    import evaluation as ev
+    import infer as drv
+    from t2ms_amd import metrics as M
+    monkeypatch.chdir(tmp_path)
+    save = str(tmp_path / "results")
+    drv.main(["--dataset_name", "ETTh1_24", "--total_step", "2", "--cfg_scale", "7", "--batch_size", "4", "--save_path", save,
+              "--synthetic", "13", "--random_init", "--seed", "3", "--run_multi", "True", "--no_figs"])
+    argv = ["--dataset_name", "ETTh1_24", "--cfg_scale", "7", "--total_step", "2", "--save_path", save, "--method_list",
+            "MSE,WAPE,MRR,CRPS,ED"]
+    single, multi = ev.main(argv)
+    name = "flowmatching_DiT_ETTh1_24_7.0_2"
+    g = os.path.join(save, "generation", name)
+    x1 = np.load(os.path.join(g, "run_0", "x_1.npy"))
+    xt = np.load(os.path.join(g, "x_t.npy"))
+    mse, wape, _ = M.mse_wape(x1, xt)
+    assert set(single) == {"MSE", "WAPE", "ED"} and single["MSE"] == mse and single["WAPE"] == wape
+    x1_9 = np.load(os.path.join(g, "run_9", "x_1.npy"))
+    gens = np.concatenate([np.load(os.path.join(g, f"run_{r}", "x_t.npy"))[..., None] for r in range(10)], axis=-1)
+    assert set(multi) == {"MRR", "CRPS"} and multi["MRR"] == M.mrr(x1_9, gens)[0] and multi["CRPS"] == M.crps(x1_9, gens)[0]
+    files = sorted(glob.glob(os.path.join(save, "evaluation", name, f"{name}_ETTh1_24_*.json")))
+    assert len(files) == 2 and files[1].endswith("_multi.json")
+    assert json.load(open(files[0])) == single and json.load(open(files[1])) == multi
+    # aligned: rows of every run paired with their own ground truth -> the base run's MSE is that of its OWN (x_1, x_t)
+    aligned, _ = ev.main(argv + ["--align_runs"])
+    own = M.mse_wape(np.load(os.path.join(g, "x_1.npy")), xt)[0]
+    assert abs(aligned["MSE"] - own) <= 1e-6 * max(1.0, own)
+
+
 def test_config3_rectified_flow_full_batch(dev, vae):
     """BASELINE config 3 shape: B=1024 (2048 sequences per CFG pass), rectified flow, cfg 5, whole
     step in one hipGraph -- at 3 steps; rows must equal the same rows sampled in a 4-row batch
