@@ -361,6 +361,8 @@ class Transformer(nn.Module):
             if keys == (key_x, key_t, _tensor_key(text_input)) and stamp == self._param_stamp():
                 return out_c                                   # the pass of the text-free call already computed this branch
             pair["armed"] = False                              # speculation missed: back to plain forwards
+        if text is None and pair["stash"] is not None:
+            pair["stash"], pair["armed"] = None, False         # the last pass's conditional half was never asked for: stop guessing
         with torch.cuda.device(dev):
             speculate = (text is None and pair["armed"] and pair["text"] is not None and pair["text"].shape[0] == B
                          and pair["text"].device == dev and not os.environ.get("T2S_NO_PAIRING"))

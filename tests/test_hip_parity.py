@@ -543,9 +543,14 @@ def test_class_api_pairs_the_two_cfg_calls_without_changing_a_bit(dev):
         x.mul_(0.5)
         c = m(input=x, t=t, text_input=emb)
         assert torch.equal(c, plain(x, t, emb))
-        # lone text-free calls (e.g. an unconditional sampler) stay correct, armed or not
-        for _ in range(3):
+        # lone text-free calls (e.g. an unconditional sampler) stay correct, and an unclaimed pass disarms the guessing
+        # (otherwise every such call would pay for a conditional half nobody asks for)
+        for _ in range(2):
+            m(input=x, t=t, text_input=None)
+            m(input=x, t=t, text_input=emb)
+        for i in range(3):
             assert torch.equal(m(input=x, t=t, text_input=None), plain(x, t, None))
+            assert m.__dict__["_t2s_pair"]["armed"] == (i == 0) and (m.__dict__["_t2s_pair"]["stash"] is not None) == (i == 0)
         # new weights between the two calls of a pair: the stash is stale and must be dropped
         for _ in range(2):
             m(input=x, t=t, text_input=None)
