@@ -41,8 +41,12 @@ def main():
                 x, t, text = inputs[B]
                 with torch.cuda.stream(side):          # HBM / L2 noise from another queue
                     junk.mul_(1.0000001)
-                c = model(input=x, t=t, text_input=text)
-                u = model(input=x, t=t, text_input=None)
+                if r % 4 < 2:           # conditional first: two plain forwards
+                    c = model(input=x, t=t, text_input=text)
+                    u = model(input=x, t=t, text_input=None)
+                else:                   # the reference loop's order: the mirror runs the pair as ONE 2B-sequence CFG pass
+                    u = model(input=x, t=t, text_input=None)
+                    c = model(input=x, t=t, text_input=text)
                 if not (torch.equal(c, first[B][0]) and torch.equal(u, first[B][1])):
                     bad += 1
                     print(f"MISMATCH round {r} B={B}: max diff {float((c - first[B][0]).abs().max()):.3e}", flush=True)
