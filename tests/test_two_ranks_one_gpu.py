@@ -33,9 +33,9 @@ def _env(port, two_ranks):
     return env
 
 
-def _launch(script_and_args, port, two_ranks, cwd, timeout=420):
+def _launch(script_and_args, port, two_ranks, cwd, timeout=420, nproc=2):
     if two_ranks:
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
                "--master-addr", "127.0.0.1", "--master-port", str(port)] + script_and_args
     else:
         cmd = [sys.executable] + script_and_args
@@ -143,6 +143,27 @@ def test_two_rank_sampling_with_empty_shards_and_coalesced_launches(tmp_path):
             for f, a in zip(files, want):
                 assert np.array_equal(a, np.load(tmp_path / f"two{bs}_{lb}" / sub / f)), (bs, lb, f)
         port += 1
+
+
+def test_four_ranks_with_fewer_rows_than_ranks(tmp_path):
+    """Four ranks on the one test GPU (the most this box allows beside the test process), a launch of THREE rows: ranks 0-2
+    sample one row each, rank 3 none -- in infer.py (final gather with an empty-handed rank, files bitwise equal to the
+    single-process run) and in train.py's own loop (length groups of 1-3 rows: up to three ranks contribute zero buckets to
+    the all-reduce and still step their optimizer; the run finishes and writes the checkpoint)."""
+    base = ["--dataset_name", "ETTh1_24", "--backbone", "flowmatching", "--denoiser", "DiT", "--total_step", "3", "--cfg_scale", "7",
+            "--synthetic", "3", "--random_init", "--seed", "8", "--batch_size", "3"]
+    sub = os.path.join("generation", "flowmatching_DiT_ETTh1_24_7.0_3")
+    _launch([os.path.join(REPO, "infer.py")] + base + ["--save_path", str(tmp_path / "one")], 29570, False, str(tmp_path))
+    _launch([os.path.join(REPO, "infer.py")] + base + ["--save_path", str(tmp_path / "four")], 29571, True, str(tmp_path), nproc=4)
+    for f in ("x_1.npy", "x_t.npy", "x_t_latent_dec_array.npy", "x_t_latent_enc_array.npy"):
+        a, b = np.load(tmp_path / "one" / sub / f), np.load(tmp_path / "four" / sub / f)
+        assert a.shape[0] == 3 and np.array_equal(a, b), f
+    argv = ["--dataset_name", "ETTh1", "--backbone", "ddpm", "--denoiser", "DiT", "--total_step", "100", "--batch_size", "4",
+            "--epochs", "2", "--save_path", str(tmp_path / "res"), "--synthetic", "4", "--random_init", "--checkpoint_path", "",
+            "--bf16"]
+    _launch([os.path.join(REPO, "train.py")] + argv, 29572, True, str(tmp_path), timeout=600, nproc=4)
+    ck = torch.load(tmp_path / "res" / "checkpoints" / "ddpm_DiT_ETTh1" / "model_1.pth", map_location="cpu")
+    assert ck["epoch"] == 1 and len(ck["loss_list"]) >= 6 and np.isfinite(ck["loss_list"]).all()
 
 
 def test_two_rank_default_seed_is_rank0s(tmp_path):
