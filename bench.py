@@ -624,6 +624,9 @@ def main():
     ap.add_argument("--no-strong", action="store_true",
                     help="skip the strong-scaling figures (N = 1: `strong_shards`, the per-GPU shards 128 / 64 / 32 of a "
                          "256-series job timed on this GPU; N > 1: `strong`, the 256 series split over the ranks)")
+    ap.add_argument("--legs", action="store_true",
+                    help="run the driver legs at N > 1 too (default: N = 1 only -- a leg is a whole driver run with collectives of "
+                         "its own, and the scaling record should not depend on it)")
     ap.add_argument("--no-legs", action="store_true",
                     help="skip the driver legs: `infer_driver` (infer.py at the authors' flags), `train_driver` (train.py's own "
                          "mix-train loop) and `class_api` (the reference-style loop against the mirrored classes)")
@@ -698,7 +701,7 @@ def main():
             traceback.print_exc()
             train = {"error": f"{type(e).__name__}: {e}"}
     legs = {}
-    if not args.no_legs:
+    if not args.no_legs and (world == 1 or args.legs):
         for name, fn in (("infer_driver", lambda *a: infer_driver_leg(*a, rows=args.infer_driver_rows)),
                          ("train_driver", lambda *a: train_driver_leg(*a, rows_per_length=args.train_driver_rows,
                                                                      batch=args.train_driver_batch))):

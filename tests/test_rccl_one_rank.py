@@ -120,7 +120,7 @@ def test_bench_distributed_branch_through_rccl_one_rank(tmp_path):
     with and without the gradient all-reduce) at world size 1 through RCCL."""
     r = _run([os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--diffusion-steps", "20",
               "--batch", "64", "--no-cpu-baseline", "--no-alt-math", "--train-batch", "32", "--train-steps", "3",
-              "--infer-driver-rows", "300", "--train-driver-rows", "2000", "--train-driver-batch", "96"],
+              "--legs", "--infer-driver-rows", "300", "--train-driver-rows", "2000", "--train-driver-batch", "96"],
              29563, True, REPO)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]

@@ -222,7 +222,7 @@ def test_plain_bench_command_starts_its_own_ranks(tmp_path):
 def test_bench_two_ranks_prints_one_json_line(tmp_path):
     r = _launch([os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--diffusion-steps", "20",
                  "--batch", "64", "--no-cpu-baseline", "--train-batch", "32", "--train-steps", "3",
-                 "--infer-driver-rows", "300", "--train-driver-rows", "2000", "--train-driver-batch", "96"], 29556, True, REPO)
+                 "--legs", "--infer-driver-rows", "300", "--train-driver-rows", "2000", "--train-driver-batch", "96"], 29556, True, REPO)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
