@@ -18,8 +18,13 @@ literally is STRONG scaling (256 series at 1/2/4/8 GPUs), so the line also carri
   * at N > 1: `strong` -- the same 256 series split over the ranks (their union equals the one-GPU batch bit for bit).
 
 The same JSON line carries, as extra keys: `roofline` (dominant kernel, in-situ HIP-event timing), `cpu_baseline` (the
-oracle on the host cores, N=1 only: 3 warm + 10 measured CFG steps), `alt_math` (the opt-in bf16x3 arithmetic, N=1 only) and
-`train` (BASELINE configs[3] shape: the bf16 DiT training step of train.py at B=1152 per GPU with the gradient all-reduce at N>1).
+oracle on the host cores, N=1 only: 3 warm + 10 measured CFG steps), `alt_math` (the opt-in bf16x3 arithmetic, N=1 only),
+`train` (BASELINE configs[3] shape: the bf16 DiT training step of train.py at B=1152 per GPU with the gradient all-reduce at
+N>1; its `roofline` prints mfma_frac, the designed and the measured HBM fraction and bytes_vs_minimal; `mix_train_shard` = the
+384-row step of an 8-GPU mix-train run) and the DRIVER legs (N=1; at N>1 on --legs): `infer_driver` = infer.py itself at the
+authors' flags, `train_driver` = train.py's own mix-train loop, `class_api` = the reference-style loop against the mirrors.
+
+    python bench.py --gpus N        # without a torchrun environment: starts the N ranks itself (spawn_ranks)
 """
 import argparse
 import contextlib
