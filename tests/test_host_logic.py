@@ -100,6 +100,29 @@ def test_epoch_plans_replay_the_loader_passes_and_coins_across_plan_boundaries(m
         assert ea == eb and ca == cb and np.array_equal(ra, rb)
 
 
+def test_resident_tables_on_the_csv_dataset_equal_a_loader_pass(tmp_path, monkeypatch):
+    """The same order / table helpers on the real CSV path (T2SDataset, reference datafactory/dataset.py:10-104): rows and
+    embeddings gathered from resident_tables by epoch_index_batches equal what a pass over loader_provider's DataLoader
+    collates, float64 -> `.float()` included (the conversion infer.py:70-71 / train.py:104-105 apply per batch)."""
+    import shutil
+    root = tmp_path / "Data" / "our"
+    os.makedirs(root)
+    shutil.copy(os.path.join(REPO, "tests", "golden", "dataset_csv", "embedding_cleaned_ETTh1_24.csv"),
+                root / "embedding_cleaned_ETTh1_24.csv")
+    monkeypatch.chdir(tmp_path)
+    ds, loader = loader_provider(_args(dataset_name="ETTh1_24", batch_size=7, synthetic=0), "train")
+    (series, emb, start), = resident_tables(ds)
+    assert start == 0 and series.shape == (60, 24) and emb.shape == (60, 128)
+    torch.manual_seed(3)
+    real = [(x.float(), e.float()) for _, x, e in loader]
+    torch.manual_seed(3)
+    batches = epoch_index_batches(loader)
+    assert len(real) == batches.shape[0] == 60 // 7
+    xs, es = torch.as_tensor(series).float(), torch.as_tensor(emb).float()
+    for (x, e), idx in zip(real, batches):
+        assert torch.equal(x, xs[idx]) and torch.equal(e, es[idx])
+
+
 def test_group_by_dataset_is_the_collate_grouping():
     """custom_collate_fn (dataloader.py:115-133) groups a mixed batch by source dataset, keeping batch order inside a
     group and skipping empty groups: the index-space version must give the same rows and embeddings."""
