@@ -523,17 +523,25 @@ def train_driver_leg(dev, dist, rank, world, rows_per_length=200_000, batch=9216
             "--synthetic", str(rows_per_length), "--random_init", "--checkpoint_path", "", "--seed", "2025", "--bf16",
             "--max_steps", str(3 * (warm_batches + timed_batches))]
     a = drv.get_args(argv)
+    a.max_steps += 3                 # three more steps after the clock stops, event-timed kernel by kernel
     clock = {}
 
-    def on_step(n, n_rows):
+    def on_step(n, n_rows, model):
+        import ctypes as C
+        from t2ms_amd import _lib as L
         if n == 3 * warm_batches:
             torch.cuda.synchronize(dev)
             clock["t0"], clock["rows"] = time.perf_counter(), 0
-        elif n > 3 * warm_batches:
+        elif 3 * warm_batches < n <= 3 * (warm_batches + timed_batches):
             clock["rows"] += n_rows
             if n == 3 * (warm_batches + timed_batches):
                 torch.cuda.synchronize(dev)
                 clock["t1"] = time.perf_counter()
+                L.check(L.lib().t2s_dit_timing_begin(model.t2s_handle(dev, 1)))      # is a step the sum of its kernels?
+        elif n == 3 * (warm_batches + timed_batches) + 3:
+            buf = (C.c_double * 18)()
+            L.check(L.lib().t2s_dit_timing_end_ex(model.t2s_handle(dev, 1), buf, 9))
+            clock["kernel_ms"] = sum(buf[2 * i] for i in range(3, 9)) / 3
 
     a.on_step = on_step
     try:
@@ -546,6 +554,9 @@ def train_driver_leg(dev, dist, rank, world, rows_per_length=200_000, batch=9216
     return {"metric": "train.py's own loop: mix-train, --batch_size 9216 (three length groups per batch), latent cache, bf16, DDPM T=100",
             "value": clock["rows"] / el, "unit": "samples/s", "ms_per_step": el / steps * 1e3, "steps": steps,
             "rows_per_step": clock["rows"] / steps, "rows_per_step_and_gpu": clock["rows"] / steps / world,
+            "kernel_ms_per_step": clock.get("kernel_ms"),
+            "kernels_note": "sum of HIP-event launch durations of the DiT training kernels over the 3 steps after the clock stopped: "
+                            "ms_per_step well above it means the loop stalled on the host side, both high means slow kernels",
             "dataset_rows": 3 * rows_per_length, "n_gpus": world, "loss": losses[-1] if losses else None,
             "data": "synthetic", "data_path": "resident tables (datafactory.epoch_index_batches; train.py --loader_batches walks the DataLoader instead)"}
 

@@ -146,7 +146,7 @@ def test_train_driver_resident_batches_equal_the_loader_pass(dev, tmp_path, monk
                          str(tmp_path / "short"), "--synthetic", "9", "--random_init", "--checkpoint_path", "", "--seed", "5",
                          "--bf16", "--max_steps", "4"])
     ticks = []
-    args.on_step = lambda n, rows: ticks.append((n, rows))
+    args.on_step = lambda n, rows, model: ticks.append((n, rows))
     short = drv.train(args)
     assert short == la[:4] and [n for n, _ in ticks] == [1, 2, 3, 4] and all(r > 0 for _, r in ticks)
 

@@ -306,7 +306,7 @@ def train(args):
             seen += n_rows
             pending.append(loss.detach())           # .item() here (train.py:126) would drain the GPU at every step
             if on_step is not None:
-                on_step(steps_done, n_rows)
+                on_step(steps_done, n_rows, model)
             # the reference prints at batch 0 of EVERY epoch (train.py:128-129): with the 1-2 batches per epoch of an
             # ETTh1-sized set that would be a device sync per step -- report on a step count instead
             if steps_done == 1 or steps_done % 100 == 0:
