@@ -744,6 +744,14 @@ int ensure_ws(t2s_dit* h, int S) {
     if (h->train && h->train->cap_seqs >= S && h->train->dtype == dtype) return T2S_OK;
     t2s::train_free(h);
     t2s_train_ws* w = new t2s_train_ws();
+    // Grow with 12.5 % headroom (within the handle's capacity): the length groups of a mix-train batch fluctuate by a few
+    // per cent from step to step (train.py:60-87), and a workspace rebuilt at every new maximum costs a device-wide
+    // hipFree + a multi-GB hipMalloc each time -- seconds in a long-lived process (found in round 4: train.py's loop at
+    // 65-180 ms per 28 ms step).  Everything below is sized for `S` = the capacity.
+    {
+        const int want = (S + S / 8 + 63) / 64 * 64;
+        S = want < h->max_seqs ? want : (S > h->max_seqs ? S : h->max_seqs);
+    }
     w->cap_seqs = S;
     w->dtype = dtype;
     const bool bf = dtype == T2S_TRAIN_BF16;

@@ -257,9 +257,11 @@ class Transformer(nn.Module):
             self.__dict__["_t2s_ws"] = (device, w, keep, stamp)
         return w, keep, stamp
 
-    def t2s_handle(self, device, n_seqs: int):
+    def t2s_handle(self, device, n_seqs: int, headroom: bool = False):
         """(Re)build or refresh the packed-weight handle: weights are re-packed whenever a parameter
-        was modified in place (optimizer step, load_state_dict) or re-allocated (.to())."""
+        was modified in place (optimizer step, load_state_dict) or re-allocated (.to()).
+        `headroom` (the training path): when the handle has to GROW, size it 12.5 % above the request -- the length groups
+        of a mix-train batch fluctuate from step to step, and every rebuild is a device-wide free + multi-GB allocation."""
         device = torch.device(device)
         w, keep, stamp = self._weights_struct(device)
         h = self.__dict__.get("_t2s_h")
@@ -267,6 +269,8 @@ class Transformer(nn.Module):
             if h is not None:
                 h.close()
             cap = max(n_seqs, h.max_seqs if h is not None else 0)
+            if headroom:
+                cap = max(cap, (n_seqs + n_seqs // 8 + 63) // 64 * 64)
             torch.cuda.synchronize(device)
             with torch.cuda.device(device):
                 h = _DitHandle(w, keep, cap)

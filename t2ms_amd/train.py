@@ -112,7 +112,7 @@ class _DitTrainFn(torch.autograd.Function):
         dev = x.device
         B = x.shape[0]
         with torch.cuda.device(dev):
-            h = model.t2s_handle(dev, B)                    # refreshes the packed weights if they changed
+            h = model.t2s_handle(dev, B, headroom=True)     # refreshes the packed weights if they changed
             w, keep, _ = model._weights_struct(dev)
             dt = L.TRAIN_BF16 if model.__dict__.get("_t2s_train_dtype", "f32") == "bf16" else L.TRAIN_F32
             L.check(L.lib().t2s_dit_set_train_dtype(h, dt), "t2s_dit_set_train_dtype")
