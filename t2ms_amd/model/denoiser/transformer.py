@@ -359,10 +359,11 @@ class Transformer(nn.Module):
         if text is not None and pair["stash"] is not None:
             # the stash HOLDS the tensors the pass read: their storage cannot have been handed to another tensor meanwhile,
             # so equal (address, version, geometry) means equal contents
-            held, keys, stamp, out_c = pair["stash"]        # `held` only keeps the storages alive; `keys` were taken at the pass
+            held, keys, stamp, out_c, stream_id = pair["stash"]   # `held` only keeps the storages alive; `keys` were taken at the pass
             pair["stash"] = None
             del held
-            if keys == (key_x, key_t, _tensor_key(text_input)) and stamp == self._param_stamp():
+            if (keys == (key_x, key_t, _tensor_key(text_input)) and stamp == self._param_stamp()
+                    and stream_id == torch.cuda.current_stream(dev).cuda_stream):       # same stream: ordered after the pass
                 return out_c                                   # the pass of the text-free call already computed this branch
             pair["armed"] = False                              # speculation missed: back to plain forwards
         if text is None and pair["stash"] is not None:
@@ -381,7 +382,8 @@ class Transformer(nn.Module):
                 out_c = torch.empty_like(out)
                 L.check(lib.t2s_dit_forward_cfg_rows(h, L.dev_ptr(x, "input"), L.dev_ptr(temb), B, L.dev_ptr(L.as_f32(ptext)),
                                                      L.dev_ptr(out), L.dev_ptr(out_c), B, st), "t2s_dit_forward_cfg_rows")
-                pair["stash"] = ((input, t, ptext), (key_x, key_t, _tensor_key(ptext)), self.__dict__.get("_t2s_stamp"), out_c)
+                pair["stash"] = ((input, t, ptext), (key_x, key_t, _tensor_key(ptext)), self.__dict__.get("_t2s_stamp"), out_c,
+                                 torch.cuda.current_stream(dev).cuda_stream)
             else:
                 L.check(lib.t2s_dit_forward(h, L.dev_ptr(x, "input"), L.dev_ptr(temb), B, L.dev_ptr(text, "text_input"),
                                             L.dev_ptr(out), B, st), "t2s_dit_forward")
