@@ -377,7 +377,9 @@ void t2s_sampler_destroy(t2s_sampler* s);
  * Threads: one sampler is driven by one thread at a time, and so is the t2s_dit it was created on (its workspace).  Two
  *          threads may drive two samplers on two t2s_dit handles of one device concurrently: runs that use the library's
  *          stream pool (several lanes, or stream NULL with use_graph) serialise their ENQUEUE on a per-device lock held
- *          for the length of the call (the GPU work stays asynchronous); a single-lane run captures on the caller's
+ *          for the length of the call (the GPU work stays asynchronous); t2s_sampler_create / _destroy take the same lock
+ *          (they allocate, copy synchronously and synchronise -- calls HIP may answer by invalidating another thread's
+ *          open capture); a single-lane run captures on the caller's
  *          `stream`, which -- like any HIP stream under capture -- must not be used by another thread meanwhile.
  *          The pool is created and calibrated by the first t2s_sampler_create on a device (not by a run), so a run
  *          never allocates or synchronises for it.

@@ -417,9 +417,9 @@ namespace {
 // queues, and because lane 0 runs on pool stream 0 too, the caller's stream -- whatever queue it sits on -- only carries
 // the fork and the join ...  (GPU_MAX_HW_QUEUES=8 / 16 did not help and cost 3-5 % at 128 / 256.)
 // ... in THEORY: measured, pool streams 0 and 2 of four created back to back still shared a queue (96 series as three
-// lanes: 57.9 against 62.3 series/s).  So the pool is CALIBRATED once per device: a 100 us spin kernel on each of two
+// lanes: 57.9 against 62.3 series/s).  So the pool is CALIBRATED once per device: a 400 us spin kernel on each of two
 // streams tells whether they overlap (the second started before the first ended); candidates are created until four
-// mutually concurrent streams are found (at most 12 candidates, ~10 ms once per process).
+// mutually concurrent streams are found (at most 12 candidates, ~10-40 ms once per process).
 __global__ void spin_kernel(unsigned long long ticks, unsigned long long* stamp) {
     const unsigned long long t0 = wall_clock64();      // constant 100 MHz
     if (threadIdx.x == 0) stamp[0] = t0;
@@ -428,12 +428,18 @@ __global__ void spin_kernel(unsigned long long ticks, unsigned long long* stamp)
 }
 
 bool streams_overlap(hipStream_t a, hipStream_t b, unsigned long long* stamps_dev) {
-    unsigned long long h[4] = {0, 0, 0, 0};
-    spin_kernel<<<1, 64, 0, a>>>(10000ull, stamps_dev);          // 100 us
-    spin_kernel<<<1, 64, 0, b>>>(10000ull, stamps_dev + 2);
-    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
-    if (hipMemcpy(h, stamps_dev, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return false;
-    return h[2] < h[1] && h[0] < h[3];
+    // 400 us spins, and a second look before a pair is declared serial: the test needs the host to issue the second launch
+    // while the first kernel still runs, and on a node where eight ranks calibrate at once a host hiccup of 100 us would
+    // have rejected a perfectly concurrent pair (the lane then shares a queue: correct, but the lanes no longer overlap)
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        unsigned long long h[4] = {0, 0, 0, 0};
+        spin_kernel<<<1, 64, 0, a>>>(40000ull, stamps_dev);          // 400 us at the 100 MHz wall clock
+        spin_kernel<<<1, 64, 0, b>>>(40000ull, stamps_dev + 2);
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+        if (hipMemcpy(h, stamps_dev, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return false;
+        if (h[2] < h[1] && h[0] < h[3]) return true;
+    }
+    return false;
 }
 
 int g_lane_pool_concurrent[16] = {};      // per device: mutually concurrent streams the calibration found
@@ -442,7 +448,7 @@ int g_lane_pool_concurrent[16] = {};      // per device: mutually concurrent str
 // would capture, record events and launch graphs on the SAME streams at once (one thread's work pulled into the other's
 // capture, or hipErrorStreamCaptureIsolation).  A run that uses pool streams holds this lock from its first event to its
 // join: the enqueue of a run is host work of a few ms, the GPU side stays asynchronous.
-std::mutex g_pool_use[16];
+std::recursive_mutex g_pool_use[16];     // recursive: a failing t2s_sampler_create destroys its half-built sampler under the lock
 
 hipStream_t* lane_streams() {
     constexpr int ML = t2s_sampler::MAX_LANES;
@@ -561,6 +567,12 @@ extern "C" int t2s_sampler_create(t2s_dit* dit, t2s_vae* vae, const t2s_sample_c
     T2S_REQUIRE(cfg->mode != T2S_MODE_DDPM || cfg->ddpm_coef, "t2s_sampler_create: DDPM needs ddpm_coef");
     T2S_REQUIRE(!vae || (cfg->length >= 4 && cfg->length % 4 == 0 && cfg->length <= (1 << 20)),
                 "t2s_sampler_create: length=%d unsupported", cfg->length);
+    // allocations, synchronous copies and a stream synchronisation follow: not while another thread's run has a capture open
+    // on the pool streams (same lock as t2s_sampler_run; see include/t2s.h "Threads")
+    int cur_dev = 0;
+    T2S_HIP_CHECK(hipGetDevice(&cur_dev));
+    T2S_REQUIRE(cur_dev >= 0 && cur_dev < 16, "t2s_sampler_create: device %d", cur_dev);
+    std::lock_guard<std::recursive_mutex> pool_lock(g_pool_use[cur_dev]);
     t2s_sampler* s = new t2s_sampler();
     s->dit = dit; s->vae = vae; s->cfg = *cfg;
     s->cfg.ddpm_coef = nullptr; s->cfg.t_values = nullptr;  // host pointers are not retained
@@ -640,6 +652,9 @@ extern "C" int t2s_sampler_graph_lanes(const t2s_sampler* s) { return (s && s->e
 
 extern "C" void t2s_sampler_destroy(t2s_sampler* s) {
     if (!s) return;
+    int cur_dev = 0;
+    std::unique_lock<std::recursive_mutex> pool_lock;  // hipFree synchronises the device: not inside another thread's capture
+    if (hipGetDevice(&cur_dev) == hipSuccess && cur_dev >= 0 && cur_dev < 16) pool_lock = std::unique_lock<std::recursive_mutex>(g_pool_use[cur_dev]);
     drop_graph(s);
     for (int l = 0; l < t2s_sampler::MAX_LANES; ++l)
         if (s->ev_join[l]) (void)hipEventDestroy(s->ev_join[l]);
@@ -669,12 +684,12 @@ extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, cons
     // (distinct hardware queues): the caller's stream then only carries the fork and the join
     hipStream_t const caller = st;
     const bool via_own = (graph_ok && st == nullptr) || lanes > 1;
-    std::unique_lock<std::mutex> pool_lock;             // held to the end of the call when this run touches pool streams
+    std::unique_lock<std::recursive_mutex> pool_lock;   // held to the end of the call when this run touches pool streams
     if (via_own) {
         int dev = 0;
         T2S_HIP_CHECK(hipGetDevice(&dev));
         T2S_REQUIRE(dev >= 0 && dev < 16, "t2s_sampler_run: device %d", dev);
-        pool_lock = std::unique_lock<std::mutex>(g_pool_use[dev]);
+        pool_lock = std::unique_lock<std::recursive_mutex>(g_pool_use[dev]);
         if (!s->own) {
             hipStream_t* pool = lane_streams();
             T2S_REQUIRE(pool, "t2s_sampler_run: cannot create the lane streams");

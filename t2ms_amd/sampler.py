@@ -37,9 +37,14 @@ _STREAMS = {}
 _RUN_LOCKS = {}          # per device: the Samplers of a process share one capture stream (below), so one run enqueues at a time
 
 
-def _run_lock(device) -> "threading.Lock":
+def _run_lock(device) -> "threading.RLock":
+    """Per device, re-entrant.  Held for EVERYTHING a Sampler does on the GPU -- building its handle and C sampler
+    (allocations, synchronous copies, a device synchronize), staging inputs, the run itself: while one thread's run has a
+    stream capture open, another thread's allocation / synchronous copy / device synchronize is exactly the kind of call HIP
+    may answer by invalidating that capture (thread-local capture mode allows it on paper; a two-thread test failed once in
+    a few runs until the whole sequence was serialised).  Foreign GPU work of other threads is not covered."""
     import threading
-    return _RUN_LOCKS.setdefault(str(torch.device(device)), threading.Lock())
+    return _RUN_LOCKS.setdefault(str(torch.device(device)), threading.RLock())
 
 
 def _sampler_stream(device) -> "torch.cuda.Stream":
@@ -51,6 +56,12 @@ def _sampler_stream(device) -> "torch.cuda.Stream":
     if key not in _STREAMS:
         _STREAMS[key] = torch.cuda.Stream(torch.device(device))
     return _STREAMS[key]
+
+
+def _destroy_locked(device_key, ptr):
+    """t2s_sampler_destroy frees device memory (a device-wide synchronisation): not while another thread's run is capturing."""
+    with _RUN_LOCKS.setdefault(device_key, __import__("threading").RLock()):
+        L.lib().t2s_sampler_destroy(ptr)
 
 
 def philox_normal(n_rows: int, row_elems: int, seed: int, stream_id: int, row0: int, device) -> torch.Tensor:
@@ -97,6 +108,10 @@ class Sampler:
 
     def _create(self):
         """(Re)build the C sampler against the model's CURRENT t2s_dit handle."""
+        with _run_lock(self.device):
+            self._create_locked()
+
+    def _create_locked(self):
         if self.ptr is not None:
             self._fin()
         model, decoder, backbone, use_graph = self.model, self.decoder, self.backbone, self.use_graph
@@ -119,7 +134,7 @@ class Sampler:
             L.check(L.lib().t2s_sampler_create(dit, vae, C.byref(cfg), C.byref(self.ptr)), "t2s_sampler_create")
             L.check(L.lib().t2s_sampler_set_lanes(self.ptr, self.lanes), "t2s_sampler_set_lanes")
             L.check(L.lib().t2s_sampler_set_loop_graph(self.ptr, self.loop_graph), "t2s_sampler_set_loop_graph")
-        self._fin = weakref.finalize(self, L.lib().t2s_sampler_destroy, self.ptr)
+        self._fin = weakref.finalize(self, _destroy_locked, str(self.device), self.ptr)
         self._keep = (tvals, coef)
 
     def set_row0(self, row0: int):
@@ -141,6 +156,10 @@ class Sampler:
             decode: bool = True, trace: bool = False):
         """Returns (latent (B,64,30), series (B,L) or None, trace (steps,L) or None).
         ``noise`` (steps,B,64,30) injects the per-step draws (parity mode)."""
+        with _run_lock(self.device):
+            return self._run_locked(text, x_T, noise, decode, trace)
+
+    def _run_locked(self, text, x_T, noise, decode, trace):
         dev = self.device
         text = L.as_f32(text.to(dev))
         if tuple(text.shape) != (self.batch, L.D_MODEL):
@@ -170,12 +189,11 @@ class Sampler:
             if self.model.t2s_handle_id() != self._dit_uid:
                 self._create()  # the model re-created its handle (capacity grew / device moved): drop the graph
             cur = torch.cuda.current_stream(dev)
-            with _run_lock(dev):        # two host threads must not capture / launch on the shared stream at once
-                self.stream.wait_stream(cur)
-                L.check(L.lib().t2s_sampler_run(self.ptr, L.dev_ptr(self._x), L.dev_ptr(self._text), L.dev_ptr(noise),
-                                                L.dev_ptr(self._series) if decode else None, L.dev_ptr(tr),
-                                                self.stream.cuda_stream), "t2s_sampler_run")
-                cur.wait_stream(self.stream)
+            self.stream.wait_stream(cur)
+            L.check(L.lib().t2s_sampler_run(self.ptr, L.dev_ptr(self._x), L.dev_ptr(self._text), L.dev_ptr(noise),
+                                            L.dev_ptr(self._series) if decode else None, L.dev_ptr(tr),
+                                            self.stream.cuda_stream), "t2s_sampler_run")
+            cur.wait_stream(self.stream)
         self._last = (noise, tr)  # keep caller-provided buffers alive until the stream has consumed them
         return self._x.clone(), (self._series.clone() if decode else None), tr
 
@@ -188,12 +206,12 @@ class Sampler:
         """Benchmark entry: x_T from Philox into the persistent buffers, no output copies.
         Requires one prior run() (buffers + text in place).  Returns (latent, series) views."""
         dev = self.device
-        with torch.cuda.device(dev):
+        with _run_lock(dev), torch.cuda.device(dev):
             if self.model.t2s_handle_id() != self._dit_uid:
                 self._create()
             self.draw_xT(self._x)
             cur = torch.cuda.current_stream(dev)
-            with _run_lock(dev):
+            if True:
                 self.stream.wait_stream(cur)
                 L.check(L.lib().t2s_sampler_run(self.ptr, L.dev_ptr(self._x), L.dev_ptr(self._text), None,
                                                 L.dev_ptr(self._series) if decode else None, None,

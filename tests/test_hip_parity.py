@@ -1021,7 +1021,7 @@ def test_two_host_threads_drive_two_samplers_on_one_device(dev, vae):
     def work(i):
         try:
             torch.cuda.set_device(dev)
-            for rep in range(4):
+            for rep in range(6):
                 s = Sampler(models[i], vae.decoder, "ddpm", 5, 9.0, 64, 48, dev, seed=100 + i, lanes=2)    # fresh: captures
                 for _ in range(2):
                     lat, ser, _ = s.run(texts[i])
@@ -1035,7 +1035,7 @@ def test_two_host_threads_drive_two_samplers_on_one_device(dev, vae):
     [t.join() for t in threads]
     assert not errors, errors
     for i in range(2):
-        assert len(got[i]) == 8
+        assert len(got[i]) == 12
         for lat, ser in got[i]:
             assert torch.equal(lat, want[i][0]) and torch.equal(ser, want[i][1]), i
 
