@@ -130,7 +130,7 @@ def test_two_rank_sampling_with_empty_shards_and_coalesced_launches(tmp_path):
             "--synthetic", "7", "--random_init", "--seed", "4"]
     sub = os.path.join("generation", "ddpm_DiT_ETTh1_24_9.0_3")
     files = ("x_1.npy", "x_t.npy", "x_t_latent_dec_array.npy", "x_t_latent_enc_array.npy")
-    port = 29560
+    port = 29580
     for bs in ("1", "2"):
         _launch([os.path.join(REPO, "infer.py")] + base + ["--batch_size", bs, "--save_path", str(tmp_path / f"one{bs}")],
                 port, False, str(tmp_path))
