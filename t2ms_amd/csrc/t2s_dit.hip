@@ -455,7 +455,8 @@ int dit_adaln_table(t2s_dit* h, const float* temb_table, int steps, const float*
 extern "C" {
 
 const char* t2s_last_error(void) { return t2s::g_err; }
-const char* t2s_version(void) { return "t2s 0.3 gfx950 fp32-mfma";   // 0.3: + t2s_philox_uniform, t2s_dit_forward_cfg_rows, t2s_sampler_set_loop_graph (additions only) }
+// 0.3: + t2s_philox_uniform, t2s_dit_forward_cfg_rows, t2s_sampler_set_loop_graph (additions only)
+const char* t2s_version(void) { return "t2s 0.3 gfx950 fp32-mfma"; }
 
 int t2s_dit_create(const t2s_dit_weights* w, int max_seqs, t2s_dit** out) {
     T2S_REQUIRE(w && out, "t2s_dit_create: NULL argument");
