@@ -108,17 +108,46 @@ def epoch_index_batches(loader) -> torch.Tensor:
     resident tensors instead of running `__getitem__` + collate per row (tests/test_host_logic.py pins this against a
     real pass)."""
     n, bs = len(loader.dataset), int(loader.batch_size)
-    torch.empty((), dtype=torch.int64).random_(generator=loader.generator)          # _BaseDataLoaderIter._base_seed
-    if loader.generator is None:
-        g = torch.Generator()
-        g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))     # RandomSampler.__iter__
-    else:
-        g = loader.generator
+    if loader.generator is not None or getattr(loader.sampler, "generator", None) is not None:
+        # with an explicit generator RandomSampler also draws a trailing randperm from it: not mirrored here -- walk the
+        # loader instead (walk_index_batches) rather than emulate a shape the T2S drivers never build
+        raise ValueError("epoch_index_batches: loaders with an explicit generator are not supported; use walk_index_batches")
+    torch.empty((), dtype=torch.int64).random_()                                    # _BaseDataLoaderIter._base_seed
+    g = torch.Generator()
+    g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))         # RandomSampler.__iter__
     perm = torch.randperm(n, generator=g)
     nb = n // bs if loader.drop_last else -(-n // bs)
     if nb * bs > n:          # drop_last=False with a ragged tail: not a shape the T2S drivers build
         raise ValueError("epoch_index_batches: ragged last batch (drop_last=False) is not supported")
     return perm[: nb * bs].view(nb, bs)
+
+
+class _RowIndex(torch.utils.data.Dataset):
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return i
+
+
+def walk_index_batches(loader) -> torch.Tensor:
+    """The same (n_batches, batch_size) index batches obtained by WALKING a DataLoader of the same shape over the row numbers
+    -- public torch API only, no knowledge of how DataLoader / RandomSampler draw.  The draws of a pass do not depend on what
+    the dataset returns, so this consumes the CPU generator exactly as a pass over `loader` does; it costs one Python call per
+    row (0.2 s per 600 K rows), which is why the drivers default to epoch_index_batches and keep this as the cross-check
+    (`--loader_batches`; tests/test_host_logic.py holds the two and a real pass equal)."""
+    if not loader.drop_last and len(loader.dataset) % int(loader.batch_size):
+        raise ValueError("walk_index_batches: ragged last batch (drop_last=False) is not supported")
+    shuffle = isinstance(loader.sampler, torch.utils.data.RandomSampler)
+    twin = DataLoader(_RowIndex(len(loader.dataset)), batch_size=int(loader.batch_size), shuffle=shuffle,
+                      drop_last=loader.drop_last, generator=loader.generator)
+    rows = [b for b in twin]
+    if not rows:
+        return torch.empty(0, int(loader.batch_size), dtype=torch.int64)
+    return torch.stack(rows).to(torch.int64)
 
 
 def resident_tables(dataset):

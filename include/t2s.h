@@ -19,7 +19,15 @@
  *     human-readable message available from t2s_last_error();
  *   - the caller owns every buffer it passes in; the library owns only its
  *     packed weight copies, workspaces and hipGraph handles;
- *   - handles are not thread-safe; one process per GPU.
+ *   - threads: a handle (t2s_dit, t2s_vae, t2s_sampler) is driven by ONE thread at a
+ *     time -- a t2s_sampler together with the t2s_dit it was created on (it runs in
+ *     that handle's workspace).  Different handles may be driven by different threads
+ *     of one process on one device (what the library serialises for them: "Threads"
+ *     at t2s_sampler_run).  The handle-free entry points (t2s_ddpm_*, t2s_rf_*,
+ *     t2s_philox_*, t2s_mse_ws, t2s_mse_backward, t2s_adamw_*, t2s_attn_fwd*,
+ *     t2s_time_embedding_freqs, t2s_eval_*, t2s_ts2vec_encode) keep no state between
+ *     calls and may be called from any thread on any stream; t2s_mse lends a scratch
+ *     per (device, stream), see there.  The deployment model is one process per GPU.
  */
 #ifndef T2S_H
 #define T2S_H
@@ -86,6 +94,15 @@ typedef struct t2s_dit_weights {
  * sampling step over a batch of B series uses 2*B sequences).  Packs the
  * weights into the kernels' MFMA-fragment layout (synchronous). */
 int t2s_dit_create(const t2s_dit_weights* w, int max_seqs, t2s_dit** out);
+/* t2s_dit_weights is T2S_DIT_N_TENSORS device pointers: 10 top-level fields in declaration order, then the 10 fields of each
+ * of the 4 blocks.  The ABI carries no sizes, so: n_floats[i] (HOST array, n_entries == T2S_DIT_N_TENSORS, or NULL) = the
+ * number of floats the caller holds behind pointer i; the call returns T2S_E_INVALID -- naming the tensor by its state-dict
+ * key -- when one is NULL, holds fewer floats than the kernels read (the shapes in the struct comments above), or lies in a
+ * device allocation that ends before those floats do (hipMemGetAddressRange; pointers HIP cannot place are passed through).
+ * t2s_dit_create and t2s_dit_update_weights run the allocation-extent part themselves: an undersized buffer is an error
+ * code, never a memory fault.  The host mirror calls this with the numel() of every parameter before it hands a new struct over. */
+#define T2S_DIT_N_TENSORS (10 + 10 * T2S_N_BLOCKS)
+int t2s_dit_weights_check(const t2s_dit_weights* w, const uint64_t* n_floats, int n_entries);
 /* Re-pack after the caller changed the weights (load_state_dict, optimizer step). */
 int t2s_dit_update_weights(t2s_dit* h, const t2s_dit_weights* w, void* stream);
 void t2s_dit_destroy(t2s_dit* h);
@@ -108,6 +125,9 @@ int t2s_dit_set_math(t2s_dit* h, int math);
  * converted to fp32 by the host mirror exactly as `t * 100.0` promotes them);
  * out: (B,128) = [sin(100 t / f) | cos(100 t / f)]. */
 int t2s_time_embedding(const t2s_dit* h, const float* t, float* out, int B, void* stream);
+/* The same without a handle (the module TimeEmbedding is parameter-free, transformer.py:25-40): freqs (64) =
+ * 10000^linspace(0,1,64) as the caller evaluated it (the host mirror uses the reference's own fp32 torch ops, :34). */
+int t2s_time_embedding_freqs(const float* freqs, const float* t, float* out, int B, void* stream);
 
 /* Transformer.forward, transformer.py:158-193.
  *   x    (B,64,30)   latent
@@ -126,7 +146,10 @@ int t2s_dit_forward_cfg(t2s_dit* h, const float* x, const float* temb, const flo
                         float* out_uncond, float* out_cond, int B, void* stream);
 /* The same pass with one time-embedding row PER series (temb_rows == B; 1 = shared): what the pair of calls
  * `model(x_t, t, None)`, `model(x_t, t, emb)` at infer.py:79-80 / 85-86 computes for a per-row t.  The class-API mirror
- * runs such a pair as ONE pass once it has seen the pattern (t2ms_amd/model/denoiser/transformer.py). */
+ * runs such a pair as ONE pass once it has seen the pattern (t2ms_amd/model/denoiser/transformer.py) -- speculation on
+ * torch tensor identity, which cannot see a raw-pointer write: a caller that updates x_t IN PLACE through this ABI
+ * (t2s_ddpm_step, t2s_rf_step) between the two calls of a mirror Transformer switches the pairing off
+ * (Transformer.set_pairing(False), or T2S_NO_PAIRING=1 in the environment). */
 int t2s_dit_forward_cfg_rows(t2s_dit* h, const float* x, const float* temb, int temb_rows, const float* text,
                              float* out_uncond, float* out_cond, int B, void* stream);
 
@@ -256,7 +279,15 @@ int t2s_ddpm_p_sample_n(const float* xt, const float* eps_hat, const int32_t* t,
 int t2s_ddpm_q_sample_n(const float* x0, const float* eps, const int32_t* t, const float* sqrt_ab,
                         const float* sqrt_1mab, float* out, int B, int row_elems, int n_steps, void* stream);
 /* DDPM.loss / RectifiedFlow.loss = F.mse_loss(a, b) (DDPM.py:37-38, rectified_flow.py:13-16):
- * mean over n elements into out[0]; fixed summation order (deterministic). */
+ * mean over n elements into out[0]; fixed summation order (deterministic, two launches: per-workgroup partials, then
+ * their sum in index order).  scratch: T2S_MSE_SCRATCH_FLOATS floats of the CALLER's device memory, contents irrelevant
+ * before and after; no state is kept anywhere else, so concurrent calls (other streams, other threads) only need
+ * different scratch. */
+#define T2S_MSE_SCRATCH_FLOATS 1024
+int t2s_mse_ws(const float* a, const float* b, float* out, uint64_t n, float* scratch, void* stream);
+/* The same with a scratch the library lends per (device, stream): allocated (hipMalloc, kept for the life of the
+ * process) the first time a stream calls -- that first call is not capturable, later ones are.  Calls on one stream
+ * are ordered by the stream; calls on different streams use different scratch. */
 int t2s_mse(const float* a, const float* b, float* out, uint64_t n, void* stream);
 /* RectifiedFlow.euler (rectified_flow.py:5-7) fused with the CFG combine (infer.py:81-82):
  *   x <- x + (u + cfg*(c-u)) * dt */
@@ -374,13 +405,15 @@ void t2s_sampler_destroy(t2s_sampler* s);
  *          (t2s_sampler_set_lanes) execute on the library's own pool of streams in the same way for ANY `stream`: the
  *          run is ordered after everything queued on `stream` before the call and joined back to it before the call
  *          returns.
- * Threads: one sampler is driven by one thread at a time, and so is the t2s_dit it was created on (its workspace).  Two
- *          threads may drive two samplers on two t2s_dit handles of one device concurrently: runs that use the library's
- *          stream pool (several lanes, or stream NULL with use_graph) serialise their ENQUEUE on a per-device lock held
- *          for the length of the call (the GPU work stays asynchronous); t2s_sampler_create / _destroy take the same lock
- *          (they allocate, copy synchronously and synchronise -- calls HIP may answer by invalidating another thread's
- *          open capture); a single-lane run captures on the caller's
- *          `stream`, which -- like any HIP stream under capture -- must not be used by another thread meanwhile.
+ * Threads: (the header's convention: one thread per handle at a time.)  Two threads may drive two samplers on two t2s_dit
+ *          handles of one device concurrently.  Every run that opens a stream capture (use_graph) or uses the library's
+ *          stream pool (several lanes, or stream NULL with use_graph) holds a per-device lock for the length of its
+ *          ENQUEUE (host work of a few ms; the GPU work stays asynchronous), and t2s_sampler_create / _destroy take the
+ *          same lock: they allocate, copy synchronously and synchronise, and the library does not rely on such calls
+ *          being harmless to another thread's open capture (DESIGN.md 4.5 says what is known about that and what is
+ *          inferred).  What the lock cannot cover is the CALLER's own allocations / synchronous copies / device
+ *          synchronisations on other threads while a run is being enqueued, and a `stream` handed to a single-lane run,
+ *          which -- like any HIP stream under capture -- must not be used by another thread meanwhile.
  *          The pool is created and calibrated by the first t2s_sampler_create on a device (not by a run), so a run
  *          never allocates or synchronises for it.
  * Memory:  t2s_sampler_create also allocates a whole-run adaLN table (steps x (batch + 1) x 3072 floats: 3.2 GB at

@@ -32,7 +32,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-from datafactory.dataloader import epoch_index_batches, loader_provider, resident_tables   # noqa: E402
+from datafactory.dataloader import epoch_index_batches, loader_provider, resident_tables, walk_index_batches   # noqa: E402
 from model.backbone.DDPM import DDPM                          # noqa: E402,F401  (API parity)
 from model.backbone.rectified_flow import RectifiedFlow      # noqa: E402,F401
 from model.denoiser.transformer import Transformer            # noqa: E402
@@ -140,7 +140,8 @@ def infer(args):
     # The loader's ORDER without the loader's per-row work (datafactory.epoch_index_batches draws what one pass over
     # the DataLoader draws): output row i is dataset row order[i], exactly the concatenation of the reference's batches
     # (shuffle=True, drop_last=True, infer.py:66; N = floor(test / B) * B rows).  The test split lives in HBM.
-    batches = epoch_index_batches(dataloader)
+    # (--loader_batches: the same order from a real DataLoader walk over the row numbers -- public torch API only)
+    batches = walk_index_batches(dataloader) if getattr(args, "loader_batches", False) else epoch_index_batches(dataloader)
     if rank == 0:
         print("dataset length:", batches.shape[0])
     if batches.shape[0] == 0:
@@ -264,6 +265,9 @@ def build_parser():
     p.add_argument("--launch_batch", type=int, default=256,
                    help="series per GPU and sampler launch: loader batches are coalesced into launches of this size (same "
                         "rows, same order, same bytes in the files); 0 = one launch per loader batch as the reference")
+    p.add_argument("--loader_batches", action="store_true",
+                   help="take the row order from a real DataLoader walk (public torch API) instead of the emulated draws of "
+                        "datafactory.epoch_index_batches -- same order, same files; the cross-check after a torch upgrade")
     p.add_argument("--math", default="f32", choices=["f32", "bf16x3"],
                    help="matrix arithmetic of the DiT: f32 MFMA (default) or fp32-accurate split-bf16 products (faster)")
     return p

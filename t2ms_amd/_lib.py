@@ -19,6 +19,8 @@ LAT_C, LAT_W, LAT = 64, 30, 1920
 D_MODEL, N_TOK = 128, 480
 TRAIN_F32, TRAIN_BF16 = 0, 1   # t2s.h: T2S_TRAIN_F32 / T2S_TRAIN_BF16
 MATH_F32, MATH_BF16X3 = 0, 1    # t2s.h: T2S_MATH_F32 / T2S_MATH_BF16X3
+DIT_N_TENSORS = 10 + 10 * N_BLOCKS   # t2s.h: T2S_DIT_N_TENSORS (pointers of t2s_dit_weights, declaration order)
+MSE_SCRATCH_FLOATS = 1024       # t2s.h: T2S_MSE_SCRATCH_FLOATS
 
 c_float_p = C.c_void_p  # device pointers travel as opaque addresses
 
@@ -87,6 +89,8 @@ SYMBOLS = {
     "t2s_dit_destroy": (None, [_VP]),
     "t2s_dit_max_seqs": (_I, [_VP]),
     "t2s_time_embedding": (_I, [_VP, _VP, _VP, _I, _VP]),
+    "t2s_time_embedding_freqs": (_I, [_VP, _VP, _VP, _I, _VP]),
+    "t2s_dit_weights_check": (_I, [C.POINTER(DitWeights), C.POINTER(C.c_uint64), _I]),
     "t2s_dit_forward": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP]),
     "t2s_dit_forward_cfg": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_dit_forward_cfg_rows": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _I, _VP]),
@@ -118,6 +122,7 @@ SYMBOLS = {
     "t2s_ddpm_q_sample_n": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
     "t2s_vae_decode_w": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
     "t2s_mse": (_I, [_VP, _VP, _VP, _U64, _VP]),
+    "t2s_mse_ws": (_I, [_VP, _VP, _VP, _U64, _VP, _VP]),
     "t2s_rf_step": (_I, [_VP, _VP, _VP, _F, _F, _I, _VP]),
     "t2s_ddpm_q_sample": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP]),
     "t2s_rf_create_flow": (_I, [_VP, _VP, _VP, _VP, _I, _VP]),

@@ -238,6 +238,51 @@ int pack_x3_weights(t2s_dit* h, hipStream_t st) {
     return T2S_OK;
 }
 
+// Floats the kernels read behind every pointer of t2s_dit_weights, in declaration order (10 top-level, then 10 per block)
+struct WeightNeed {
+    const char* name;
+    size_t floats;
+};
+constexpr WeightNeed TOP_NEED[10] = {{"conv.weight", 16}, {"conv.bias", 4}, {"patch_emb.weight", 512}, {"patch_emb.bias", 128},
+                                     {"pos_embed", (size_t)NTOK * D}, {"ln.weight", D}, {"ln.bias", D},
+                                     {"linear_emb_to_patch.weight", 4 * D}, {"linear_emb_to_patch.bias", 4}, {"time_freqs", 64}};
+constexpr WeightNeed BLK_NEED[10] = {{"attn.qkv.weight", 3 * D * D}, {"attn.qkv.bias", 3 * D}, {"attn.proj.weight", D * D},
+                                     {"attn.proj.bias", D}, {"mlp.fc1.weight", 2 * D * D}, {"mlp.fc1.bias", 2 * D},
+                                     {"mlp.fc2.weight", 2 * D * D}, {"mlp.fc2.bias", D}, {"adaLN_modulation.1.weight", (size_t)MODW * D},
+                                     {"adaLN_modulation.1.bias", MODW}};
+static_assert(sizeof(t2s_dit_weights) == sizeof(void*) * T2S_DIT_N_TENSORS, "t2s_dit_weights is T2S_DIT_N_TENSORS pointers");
+
+// Every tensor must be at least as large as what t2s_dit_create / _update_weights read from it: by the caller's own count
+// (n_floats, may be NULL) and -- what no caller can get wrong -- by the extent of the device allocation the pointer lies in
+// (hipMemGetAddressRange; a pointer HIP cannot place is passed through: nothing known, nothing refused).  An undersized
+// tensor is T2S_E_INVALID here, not a memory fault in a pack kernel (round 4: a 480 x 128 dummy behind the (768,128) adaLN
+// matrix read 148 KB past its buffer and faulted only when that happened to end an allocator segment).
+int check_weights(const t2s_dit_weights* w, const uint64_t* n_floats, bool ranges) {
+    const float* const* ptrs = reinterpret_cast<const float* const*>(w);
+    for (int i = 0; i < T2S_DIT_N_TENSORS; ++i) {
+        const WeightNeed& need = i < 10 ? TOP_NEED[i] : BLK_NEED[(i - 10) % 10];
+        const int blk = i < 10 ? -1 : (i - 10) / 10;
+        char name[96];
+        if (blk < 0) snprintf(name, sizeof(name), "%s", need.name);
+        else snprintf(name, sizeof(name), "layers.%d.%s", blk, need.name);
+        T2S_REQUIRE(ptrs[i], "t2s_dit weights: %s is NULL", name);
+        T2S_REQUIRE(!n_floats || n_floats[i] >= need.floats, "t2s_dit weights: %s holds %llu floats, the kernels read %zu", name,
+                    (unsigned long long)n_floats[i], need.floats);
+        if (ranges) {
+            hipDeviceptr_t base = nullptr;
+            size_t size = 0;
+            if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptrs[i]) != hipSuccess) {
+                (void)hipGetLastError();
+                continue;
+            }
+            const size_t left = (size_t)((const char*)base + size - (const char*)ptrs[i]);
+            T2S_REQUIRE(left >= need.floats * sizeof(float), "t2s_dit weights: %s needs %zu bytes but its device allocation ends after %zu",
+                        name, need.floats * sizeof(float), left);
+        }
+    }
+    return T2S_OK;
+}
+
 int upload_weights(t2s_dit* h, const t2s_dit_weights* w, hipStream_t st) {
     T2S_REQUIRE(w->conv_w && w->conv_b && w->patch_w && w->patch_b && w->pos_embed && w->ln_w &&
                     w->ln_b && w->out_w && w->out_b && w->time_freqs,
@@ -456,11 +501,16 @@ extern "C" {
 
 const char* t2s_last_error(void) { return t2s::g_err; }
 // 0.3: + t2s_philox_uniform, t2s_dit_forward_cfg_rows, t2s_sampler_set_loop_graph (additions only)
-const char* t2s_version(void) { return "t2s 0.3 gfx950 fp32-mfma"; }
+// 0.4: + t2s_time_embedding_freqs, t2s_dit_weights_check, t2s_mse_ws (additions only)
+const char* t2s_version(void) { return "t2s 0.4 gfx950 fp32-mfma"; }
 
 int t2s_dit_create(const t2s_dit_weights* w, int max_seqs, t2s_dit** out) {
     T2S_REQUIRE(w && out, "t2s_dit_create: NULL argument");
     T2S_REQUIRE(max_seqs > 0 && max_seqs <= 65536, "t2s_dit_create: max_seqs=%d out of range", max_seqs);
+    {
+        const int rc_w = check_weights(w, nullptr, /*ranges=*/true);
+        if (rc_w != T2S_OK) return rc_w;
+    }
     t2s_dit* h = new t2s_dit();
     h->max_seqs = max_seqs;
     ArenaPlan p;
@@ -532,6 +582,8 @@ int t2s_dit_create(const t2s_dit_weights* w, int max_seqs, t2s_dit** out) {
 
 int t2s_dit_update_weights(t2s_dit* h, const t2s_dit_weights* w, void* stream) {
     T2S_REQUIRE(h && w, "t2s_dit_update_weights: NULL argument");
+    const int rc_w = check_weights(w, nullptr, /*ranges=*/true);
+    if (rc_w != T2S_OK) return rc_w;
     return upload_weights(h, w, (hipStream_t)stream);
 }
 
@@ -586,6 +638,20 @@ int t2s_time_embedding(const t2s_dit* h, const float* t, float* out, int B, void
     time_embedding_kernel<<<(B * 64 + 255) / 256, 256, 0, (hipStream_t)stream>>>(t, h->freqs, out, B);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
+}
+
+int t2s_time_embedding_freqs(const float* freqs, const float* t, float* out, int B, void* stream) {
+    T2S_REQUIRE(freqs && t && out && B > 0, "t2s_time_embedding_freqs: bad argument");
+    time_embedding_kernel<<<(B * 64 + 255) / 256, 256, 0, (hipStream_t)stream>>>(t, freqs, out, B);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+int t2s_dit_weights_check(const t2s_dit_weights* w, const uint64_t* n_floats, int n_entries) {
+    T2S_REQUIRE(w, "t2s_dit_weights_check: NULL weights");
+    T2S_REQUIRE(!n_floats || n_entries == T2S_DIT_N_TENSORS, "t2s_dit_weights_check: n_entries=%d, t2s_dit_weights has %d tensors", n_entries,
+                T2S_DIT_N_TENSORS);
+    return check_weights(w, n_floats, /*ranges=*/true);
 }
 
 int t2s_dit_forward(t2s_dit* h, const float* x, const float* temb, int temb_rows, const float* text,

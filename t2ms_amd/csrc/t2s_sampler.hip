@@ -212,17 +212,16 @@ __global__ __launch_bounds__(256) void p_sample_rows_kernel(const float* __restr
     reinterpret_cast<f32x4*>(out)[idx] = c0 * (x - c1 * e) + c2 * z;
 }
 
-// F.mse_loss (mean over all elements), deterministic: every workgroup sums a fixed contiguous
-// chunk in a fixed order into mse_part[], the last one to finish adds the partials in index order.
-// The scratch is per device and shared by all calls: t2s_mse calls on ONE device must not overlap
-// (they never do on a single stream).
+// F.mse_loss (mean over all elements), deterministic and STATELESS: stage 1, every workgroup sums a fixed contiguous
+// chunk in a fixed order into part[blockIdx.x] of the CALLER's scratch; stage 2, one workgroup adds the partials in index
+// order.  No device globals, no arrival counter, nothing to zero: calls on different streams / from different threads
+// cannot meet (until round 5 the partials lived in one __device__ array per device and two overlapping calls raced
+// silently).
 constexpr int MSE_MAX_WGS = 1024;
-__device__ float mse_part[MSE_MAX_WGS];
-__device__ unsigned int mse_done = 0;
-__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                  float* __restrict__ out, size_t n) {
+static_assert(MSE_MAX_WGS <= T2S_MSE_SCRATCH_FLOATS, "t2s.h: T2S_MSE_SCRATCH_FLOATS too small");
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          float* __restrict__ part_out, size_t n) {
     __shared__ float part[4];
-    __shared__ bool last;
     const size_t n4 = n >> 2;
     const size_t per = (n4 + gridDim.x - 1) / gridDim.x;          // float4 per workgroup
     const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < n4 ? lo + per : n4;
@@ -240,27 +239,19 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, c
     for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&mse_part[blockIdx.x], (part[0] + part[1]) + (part[2] + part[3]), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        last = atomicAdd(&mse_done, 1u) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
+    if (threadIdx.x == 0) part_out[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void mse_final_kernel(const float* __restrict__ part_in, int n_part, float* __restrict__ out,
+                                                        size_t n) {
+    __shared__ float part[4];
     float s = 0.f;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)        // fixed assignment, fixed order below
-        s += __hip_atomic_load(&mse_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = threadIdx.x; i < n_part; i += 256) s += part_in[i];      // fixed assignment, fixed order below
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-    __syncthreads();
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        *out = ((part[0] + part[1]) + (part[2] + part[3])) / (float)n;
-        mse_done = 0;
-    }
+    if (threadIdx.x == 0) *out = ((part[0] + part[1]) + (part[2] + part[3])) / (float)n;
 }
 
 // step[0] = loop index, step[1] = global row index of the lane's first series (Philox key), step[2] = arrival counter
@@ -352,13 +343,37 @@ extern "C" int t2s_ddpm_p_sample(const float* xt, const float* eps_hat, const in
     return t2s_ddpm_p_sample_n(xt, eps_hat, t, noise, coef, out, B, LAT, n_steps, stream);
 }
 
-extern "C" int t2s_mse(const float* a, const float* b, float* out, uint64_t n, void* stream) {
-    T2S_REQUIRE(a && b && out && n > 0, "t2s_mse: bad argument");
+extern "C" int t2s_mse_ws(const float* a, const float* b, float* out, uint64_t n, float* scratch, void* stream) {
+    T2S_REQUIRE(a && b && out && scratch && n > 0, "t2s_mse_ws: bad argument");
     const size_t n4 = n / 4;
     const int wgs = (int)(n4 / 1024 < 1 ? 1 : (n4 / 1024 > MSE_MAX_WGS ? MSE_MAX_WGS : n4 / 1024));   // >= 4 float4 per thread
-    mse_kernel<<<wgs, 256, 0, (hipStream_t)stream>>>(a, b, out, (size_t)n);
+    mse_partial_kernel<<<wgs, 256, 0, (hipStream_t)stream>>>(a, b, scratch, (size_t)n);
+    T2S_LAUNCH_CHECK();
+    mse_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>(scratch, wgs, out, (size_t)n);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
+}
+
+// t2s_mse keeps its scratch-free signature: the library lends one scratch per (device, stream), allocated the first time that
+// stream calls (so: not capturable THEN; later calls on the stream are).  Calls on one stream are ordered by the stream,
+// calls on different streams use different scratch.
+extern "C" int t2s_mse(const float* a, const float* b, float* out, uint64_t n, void* stream) {
+    T2S_REQUIRE(a && b && out && n > 0, "t2s_mse: bad argument");
+    static std::mutex guard;
+    static std::vector<std::pair<std::pair<int, void*>, float*>> lent;
+    int dev = 0;
+    T2S_HIP_CHECK(hipGetDevice(&dev));
+    float* scratch = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(guard);
+        for (auto& e : lent)
+            if (e.first.first == dev && e.first.second == stream) scratch = e.second;
+        if (!scratch) {
+            T2S_HIP_CHECK(hipMalloc((void**)&scratch, T2S_MSE_SCRATCH_FLOATS * sizeof(float)));
+            lent.push_back({{dev, stream}, scratch});
+        }
+    }
+    return t2s_mse_ws(a, b, out, n, scratch, stream);
 }
 
 extern "C" int t2s_rf_create_flow(const float* x1, const float* x0, const float* t, float* out, int B, void* stream) {
@@ -678,18 +693,23 @@ extern "C" int t2s_sampler_run(t2s_sampler* s, float* x, const float* text, cons
     const t2s_sample_config& c = s->cfg;
     int rc;
     int lanes = pick_lanes(s, trace0 != nullptr);
-    if (lanes > 1 && !lane_streams()) lanes = 1;      // no stream pool on this device: one chain, same results
     const bool graph_ok = c.use_graph && !trace0;
-    // the default stream cannot be captured (never a silent eager run), and several lanes run on streams created TOGETHER
-    // (distinct hardware queues): the caller's stream then only carries the fork and the join
-    hipStream_t const caller = st;
-    const bool via_own = (graph_ok && st == nullptr) || lanes > 1;
-    std::unique_lock<std::recursive_mutex> pool_lock;   // held to the end of the call when this run touches pool streams
-    if (via_own) {
+    // Held to the end of the call by EVERY run that opens a stream capture or touches the pool streams -- a single-lane run
+    // capturing on the caller's own stream included: another thread's t2s_sampler_create / _destroy (allocations, synchronous
+    // copies, synchronisation) and the pool's calibration are then never concurrent with an open capture of this library.
+    std::unique_lock<std::recursive_mutex> pool_lock;
+    if (graph_ok || lanes > 1) {
         int dev = 0;
         T2S_HIP_CHECK(hipGetDevice(&dev));
         T2S_REQUIRE(dev >= 0 && dev < 16, "t2s_sampler_run: device %d", dev);
         pool_lock = std::unique_lock<std::recursive_mutex>(g_pool_use[dev]);
+    }
+    if (lanes > 1 && !lane_streams()) lanes = 1;      // no stream pool on this device: one chain, same results
+    // the default stream cannot be captured (never a silent eager run), and several lanes run on streams created TOGETHER
+    // (distinct hardware queues): the caller's stream then only carries the fork and the join
+    hipStream_t const caller = st;
+    const bool via_own = (graph_ok && st == nullptr) || lanes > 1;
+    if (via_own) {
         if (!s->own) {
             hipStream_t* pool = lane_streams();
             T2S_REQUIRE(pool, "t2s_sampler_run: cannot create the lane streams");

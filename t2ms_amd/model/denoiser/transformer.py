@@ -59,11 +59,9 @@ class TimeEmbedding(nn.Module):
             raise L.T2SError("TimeEmbedding: t must live on a GPU (no CPU fallback)")
         freqs = _freqs_on(tf.device)
         out = torch.empty(tf.shape[0], EMB, device=tf.device, dtype=torch.float32)
-        # t2s_time_embedding only needs the freqs table, which lives in a DiT handle; use a tiny one
-        h = _scratch_handle(tf.device)
-        L.check(L.lib().t2s_time_embedding(h, L.dev_ptr(tf, "t"), L.dev_ptr(out), tf.shape[0],
-                                           L.stream_ptr(tf.device)), "t2s_time_embedding")
-        del freqs
+        with torch.cuda.device(tf.device):
+            L.check(L.lib().t2s_time_embedding_freqs(L.dev_ptr(freqs), L.dev_ptr(tf, "t"), L.dev_ptr(out), tf.shape[0],
+                                                     L.stream_ptr(tf.device)), "t2s_time_embedding_freqs")
         return out
 
 
@@ -130,7 +128,6 @@ class InverseLatentEmbedding(nn.Module):
 
 # ---------------------------------------------------------------------------- device-side state
 _FREQS = {}
-_SCRATCH = {}
 
 
 def _freqs_on(device) -> torch.Tensor:
@@ -160,25 +157,6 @@ class _DitHandle:
 
     def close(self):
         self._fin()
-
-
-def _scratch_handle(device):
-    """A 1-sequence handle with dummy weights, used only for its time-frequency table."""
-    key = str(device)
-    if key not in _SCRATCH:
-        # every dummy pointer must cover the LARGEST tensor t2s_dit_create packs from it: adaLN_modulation.1.weight is
-        # (768,128) = 98,304 floats.  (Until round 4 this was 480 * 128: the pack kernels read 148 KB past the buffer, a
-        # memory fault whenever the block happened to end a 2 MB allocator segment.)
-        z = torch.zeros(768 * 128, device=device)
-        w = L.DitWeights()
-        for name, _ in L.DitWeights._fields_[:-1]:
-            setattr(w, name, z.data_ptr())
-        w.time_freqs = _freqs_on(device).data_ptr()
-        for b in w.blk:
-            for name, _ in L.DitBlockWeights._fields_:
-                setattr(b, name, z.data_ptr())
-        _SCRATCH[key] = _DitHandle(w, (z,), 1)
-    return _SCRATCH[key].ptr
 
 
 class Transformer(nn.Module):
@@ -235,15 +213,17 @@ class Transformer(nn.Module):
         is handed back (the reference-style loop calls the model twice per diffusion step: building 49 detached views
         and 59 ctypes fields each time cost 150 us of host time per forward, more than a small batch's kernels)."""
         ts = self._dit_tensors()
-        stamp = tuple([(t.data_ptr(), t._version) for t in ts])
+        stamp = _stamp_of(ts)
         cached = self.__dict__.get("_t2s_ws")
-        if cached is not None and cached[0] == device and cached[3] == stamp:
+        if cached is not None and stamp is not None and cached[0] == device and cached[3] == stamp:
             return cached[1], cached[2], stamp
         for t in ts:
             if t.device != device:
                 raise L.T2SError(f"Transformer parameters live on {t.device} but the input is on {device}; "
                                  f"call model.to(device) first")
         keep = [L.as_f32(t.detach()) for t in ts]
+        for t in keep:
+            L.dev_ptr(t, "Transformer parameter")          # on a GPU, fp32, contiguous -- or T2SError
         w = L.DitWeights()
         names = [n for n, _ in L.DitWeights._fields_ if n not in ("blk", "time_freqs")]
         for n, t in zip(names, keep[:9]):
@@ -253,6 +233,13 @@ class Transformer(nn.Module):
         for i in range(DEPTH):
             for n, t in zip(bnames, keep[9 + 10 * i: 19 + 10 * i]):
                 setattr(w.blk[i], n, t.data_ptr())
+        # the C ABI carries no sizes: hand over every tensor's float count in t2s_dit_weights order (time_freqs is field 9) so an
+        # undersized parameter (a foreign checkpoint assigned tensor by tensor, a sliced view) is T2S_E_INVALID with the
+        # state-dict key in the message -- not an out-of-bounds read in a pack kernel
+        counts = [t.numel() for t in keep[:9]] + [_freqs_on(device).numel()] + [t.numel() for t in keep[9:]]
+        with torch.cuda.device(device):
+            L.check(L.lib().t2s_dit_weights_check(C.byref(w), (C.c_uint64 * L.DIT_N_TENSORS)(*counts), L.DIT_N_TENSORS),
+                    "t2s_dit_weights_check")
         if all(k.data_ptr() == t.data_ptr() for k, t in zip(keep, ts)):      # fp32 contiguous parameters: no copies made
             self.__dict__["_t2s_ws"] = (device, w, keep, stamp)
         return w, keep, stamp
@@ -276,7 +263,7 @@ class Transformer(nn.Module):
                 h = _DitHandle(w, keep, cap)
             self.__dict__["_t2s_h"], self.__dict__["_t2s_dev"], self.__dict__["_t2s_stamp"] = h, device, stamp
             self.__dict__.pop("_t2s_math_applied", None)
-        elif self.__dict__.get("_t2s_stamp") != stamp:
+        elif stamp is None or self.__dict__.get("_t2s_stamp") != stamp:
             L.check(L.lib().t2s_dit_update_weights(h.ptr, C.byref(w), L.stream_ptr(device)),
                     "t2s_dit_update_weights")
             h.keep = keep
@@ -303,6 +290,18 @@ class Transformer(nn.Module):
         self.__dict__["_t2s_math"] = math
         return self
 
+    def set_pairing(self, enabled: bool = True):
+        """Pairing of the class-API calls `model(x_t, t, None)`, `model(x_t, t, emb)` of one diffusion step into ONE
+        classifier-free-guidance pass (see _forward_nograd).  It is host-side speculation on tensor IDENTITY -- storage
+        address, torch's in-place version counter, geometry -- so it cannot see a write that bypasses that counter: a
+        raw-pointer kernel (this library's own in-place C entries t2s_ddpm_step / t2s_rf_step called on x_t through ctypes,
+        any other ctypes / hipGraph write) or `x.data.copy_()` between the two calls.  A caller that updates x_t that way
+        between the text-free and the conditional call switches pairing off here (or with T2S_NO_PAIRING=1 in the
+        environment) and gets plain forwards: same results, two launch chains per step."""
+        self.__dict__["_t2s_pairing"] = bool(enabled)
+        self.__dict__.pop("_t2s_pair", None)
+        return self
+
     def set_train_dtype(self, dtype: str):
         """Arithmetic of forward-under-autograd / backward: "f32" (default; gradients equal the fp32
         reference's) or "bf16" (BASELINE config 4: bf16 MFMA operands and saved activations, fp32
@@ -315,7 +314,7 @@ class Transformer(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         for k in ("_t2s_h", "_t2s_dev", "_t2s_stamp", "_t2s_math_applied", "_t2s_bucket", "_t2s_flat_grad", "_t2s_fwd_gen",
-                  "_t2s_ws", "_t2s_pair"):
+                  "_t2s_ws", "_t2s_pair", "_t2s_pairing"):
             state.pop(k, None)
         return state
 
@@ -356,21 +355,29 @@ class Transformer(nn.Module):
                 raise L.T2SError(f"Transformer.forward: text_input must be ({B},128), got {tuple(text.shape)}")
         pair = self.__dict__.setdefault("_t2s_pair", {"armed": False, "last_uncond": None, "text": None, "stash": None})
         key_x, key_t = _tensor_key(input), _tensor_key(t)
+        key_text = _tensor_key(text_input) if text_input is not None else None
+        # no key (a tensor made under torch.inference_mode() has no version counter), pairing switched off: never arm, never
+        # hand out a stash -- plain forwards
+        pairing = (key_x is not None and key_t is not None and (text_input is None or key_text is not None)
+                   and self.__dict__.get("_t2s_pairing", True) and not os.environ.get("T2S_NO_PAIRING"))
+        if not pairing:
+            pair["armed"], pair["last_uncond"], pair["text"], pair["stash"] = False, None, None, None
         if text is not None and pair["stash"] is not None:
             # the stash HOLDS the tensors the pass read: their storage cannot have been handed to another tensor meanwhile,
             # so equal (address, version, geometry) means equal contents
-            held, keys, stamp, out_c, stream_id = pair["stash"]   # `held` only keeps the storages alive; `keys` were taken at the pass
+            held, keys, stamp, out_c, stream_id, mode = pair["stash"]   # `held` only keeps the storages alive; `keys` were taken at the pass
             pair["stash"] = None
             del held
-            if (keys == (key_x, key_t, _tensor_key(text_input)) and stamp == self._param_stamp()
+            if (keys == (key_x, key_t, key_text) and stamp is not None and stamp == self._param_stamp()
+                    and mode == (self.t2s_handle_id(), self.__dict__.get("_t2s_math", "f32"))   # same handle, same arithmetic
                     and stream_id == torch.cuda.current_stream(dev).cuda_stream):       # same stream: ordered after the pass
                 return out_c                                   # the pass of the text-free call already computed this branch
             pair["armed"] = False                              # speculation missed: back to plain forwards
         if text is None and pair["stash"] is not None:
             pair["stash"], pair["armed"] = None, False         # the last pass's conditional half was never asked for: stop guessing
         with torch.cuda.device(dev):
-            speculate = (text is None and pair["armed"] and pair["text"] is not None and pair["text"].shape[0] == B
-                         and pair["text"].device == dev and not os.environ.get("T2S_NO_PAIRING"))
+            speculate = (pairing and text is None and pair["armed"] and pair["text"] is not None and pair["text"].shape[0] == B
+                         and pair["text"].device == dev and _tensor_key(pair["text"]) is not None)
             h = self.t2s_handle(dev, 2 * B if speculate else B)
             st = L.stream_ptr(dev)
             temb = torch.empty(B, EMB, device=dev, dtype=torch.float32)
@@ -383,10 +390,13 @@ class Transformer(nn.Module):
                 L.check(lib.t2s_dit_forward_cfg_rows(h, L.dev_ptr(x, "input"), L.dev_ptr(temb), B, L.dev_ptr(L.as_f32(ptext)),
                                                      L.dev_ptr(out), L.dev_ptr(out_c), B, st), "t2s_dit_forward_cfg_rows")
                 pair["stash"] = ((input, t, ptext), (key_x, key_t, _tensor_key(ptext)), self.__dict__.get("_t2s_stamp"), out_c,
-                                 torch.cuda.current_stream(dev).cuda_stream)
+                                 torch.cuda.current_stream(dev).cuda_stream,
+                                 (self.t2s_handle_id(), self.__dict__.get("_t2s_math", "f32")))
             else:
                 L.check(lib.t2s_dit_forward(h, L.dev_ptr(x, "input"), L.dev_ptr(temb), B, L.dev_ptr(text, "text_input"),
                                             L.dev_ptr(out), B, st), "t2s_dit_forward")
+        if not pairing:
+            return out
         if text is None:
             pair["last_uncond"] = (key_x, key_t)
         else:
@@ -396,11 +406,23 @@ class Transformer(nn.Module):
         return out
 
     def _param_stamp(self):
-        return tuple([(p.data_ptr(), p._version) for p in self._dit_tensors()])
+        return _stamp_of(self._dit_tensors())
+
+
+def _stamp_of(ts):
+    """(data_ptr, in-place version) per tensor, or None when torch keeps no version counter for one of them (parameters
+    created under torch.inference_mode()): nothing can then be cached against the stamp -- every call re-packs."""
+    if any(t.is_inference() for t in ts):
+        return None
+    return tuple([(t.data_ptr(), t._version) for t in ts])
 
 
 def _tensor_key(t):
-    """Identity of a tensor's contents as far as the host can know it: storage address, in-place version, geometry."""
+    """Identity of a tensor's contents as far as the host can know it: storage address, in-place version, geometry.  None
+    when torch keeps no version counter for it (tensors created under torch.inference_mode(): `._version` raises) -- the
+    caller then has nothing to speculate on."""
+    if t.is_inference():
+        return None
     return (t.data_ptr(), t._version, tuple(t.shape), t.dtype, tuple(t.stride()))
 
 

@@ -211,12 +211,11 @@ class Sampler:
                 self._create()
             self.draw_xT(self._x)
             cur = torch.cuda.current_stream(dev)
-            if True:
-                self.stream.wait_stream(cur)
-                L.check(L.lib().t2s_sampler_run(self.ptr, L.dev_ptr(self._x), L.dev_ptr(self._text), None,
-                                                L.dev_ptr(self._series) if decode else None, None,
-                                                self.stream.cuda_stream), "t2s_sampler_run")
-                cur.wait_stream(self.stream)
+            self.stream.wait_stream(cur)
+            L.check(L.lib().t2s_sampler_run(self.ptr, L.dev_ptr(self._x), L.dev_ptr(self._text), None,
+                                            L.dev_ptr(self._series) if decode else None, None,
+                                            self.stream.cuda_stream), "t2s_sampler_run")
+            cur.wait_stream(self.stream)
         return self._x, self._series
 
 

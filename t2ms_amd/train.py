@@ -32,9 +32,12 @@ def mse_loss(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 def _mse_value(a, b):
     ac, bc = L.as_f32(a.detach()), L.as_f32(b.detach())
     out = torch.empty((), device=a.device, dtype=torch.float32)
+    # the reduction's partials live in the CALLER's scratch (stream-ordered torch memory): no state in the library, so
+    # losses computed on other streams / by other threads cannot meet
+    scratch = torch.empty(L.MSE_SCRATCH_FLOATS, device=a.device, dtype=torch.float32)
     with torch.cuda.device(a.device):
-        L.check(L.lib().t2s_mse(L.dev_ptr(ac), L.dev_ptr(bc), out.data_ptr(), ac.numel(),
-                                L.stream_ptr(a.device)), "t2s_mse")
+        L.check(L.lib().t2s_mse_ws(L.dev_ptr(ac), L.dev_ptr(bc), out.data_ptr(), ac.numel(), L.dev_ptr(scratch),
+                                   L.stream_ptr(a.device)), "t2s_mse_ws")
     return out
 
 

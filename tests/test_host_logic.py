@@ -12,7 +12,7 @@ import pytest
 import torch
 
 from datafactory.dataloader import (AlternatingDataset, custom_collate_fn, epoch_index_batches, group_by_dataset,
-                                    loader_provider, plan_epochs, resident_tables)
+                                    loader_provider, plan_epochs, resident_tables, walk_index_batches)
 from datafactory.dataset import SyntheticT2SDataset
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -56,6 +56,41 @@ def test_epoch_index_batches_is_one_pass_over_the_loader(mix, bs):
     assert len(real) == len(got) == 3 * len(loader)
     for a, b in zip(real, got):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("bs", [4, 1])
+def test_walked_index_batches_equal_the_emulated_draws_and_a_real_pass(bs):
+    """`--loader_batches` of infer.py: the order from a DataLoader WALK over the row numbers (public torch API only) is the
+    order epoch_index_batches emulates and the order of a real pass, over consecutive passes, generator state included --
+    the hard gate against a torch upgrade that changes how DataLoader / RandomSampler draw."""
+    ds, loader = loader_provider(_args(batch_size=bs), "test")
+    tab = resident_tables(ds)[0][0]
+    runs = {}
+    for name, fn in (("emulated", epoch_index_batches), ("walked", walk_index_batches)):
+        torch.manual_seed(123)
+        runs[name] = ([fn(loader) for _ in range(3)], float(torch.rand(1)))
+    torch.manual_seed(123)
+    real = [np.stack([d[1].numpy() for d in loader]) for _ in range(3)]
+    after_real = float(torch.rand(1))
+    assert runs["emulated"][1] == runs["walked"][1] == after_real
+    for a, b, r in zip(runs["emulated"][0], runs["walked"][0], real):
+        assert a.dtype == b.dtype == torch.int64 and torch.equal(a, b)
+        assert np.array_equal(tab[a.numpy()], r)
+
+
+def test_emulated_draws_refuse_a_loader_with_its_own_generator():
+    """RandomSampler with an explicit generator draws differently (a trailing randperm from it): not emulated, refused --
+    walk_index_batches serves that shape."""
+    ds = SyntheticT2SDataset(11, 24)
+    g = torch.Generator().manual_seed(3)
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=True, drop_last=True, generator=g)
+    with pytest.raises(ValueError, match="explicit generator"):
+        epoch_index_batches(loader)
+    g.manual_seed(3)
+    walked = walk_index_batches(loader)
+    g.manual_seed(3)
+    real = np.stack([d[1].numpy() for d in loader])
+    assert np.array_equal(ds.samples[walked.numpy()], real)
 
 
 @pytest.mark.parametrize("mix,bs,n_rows,epochs,min_steps", [(True, 7, 11, 9, 10), (False, 4, 11, 7, 5), (True, 5, 3, 12, 4)])
