@@ -17,8 +17,10 @@ literally is STRONG scaling (256 series at 1/2/4/8 GPUs), so the line also carri
     strong efficiency rate(256/N) / rate(256) (no collective: N x rate(256/N) is the N-GPU rate);
   * at N > 1: `strong` -- the same 256 series split over the ranks (their union equals the one-GPU batch bit for bit).
 
-The same JSON line carries, as extra keys: `roofline` (dominant kernel, in-situ HIP-event timing), `cpu_baseline` (the
-oracle on the host cores, N=1 only: 3 warm + 10 measured CFG steps), `alt_math` (the opt-in bf16x3 arithmetic, N=1 only),
+The same JSON line carries, as extra keys: `roofline` (dominant kernel, in-situ HIP-event timing), `roofline_rows` (the three
+row-chain kernel instances, same timing), `cpu_baseline` (the oracle on the host cores, N=1 only: 3 warm + 10 measured CFG steps),
+`config3` / `config5` (BASELINE configs[2] and configs[4] under this clock, N=1 only), `alt_math` (the bf16x3 arithmetic with its
+own roofline against the bf16 peak / 6 and an in-run `accuracy_vs_fp64` block, N=1 only),
 `train` (BASELINE configs[3] shape: the bf16 DiT training step of train.py at B=1152 per GPU with the gradient all-reduce at
 N>1; its `roofline` prints mfma_frac, the designed and the measured HBM fraction and bytes_vs_minimal; `mix_train_shard` = the
 384-row step of an 8-GPU mix-train run) and the DRIVER legs (N=1; at N>1 on --legs): `infer_driver` = infer.py itself at the
@@ -79,12 +81,40 @@ def time_kernels_in_situ(model, dev, x, text, n_steps=8):
         for _ in range(n_steps):
             L.check(lib.t2s_dit_forward_cfg(h, x.data_ptr(), temb.data_ptr(), text.data_ptr(), ou.data_ptr(),
                                             oc.data_ptr(), B, st))
-        out = (C.c_double * 6)()
-        L.check(lib.t2s_dit_timing_end(h, out))
+        out = (C.c_double * 22)()
+        L.check(lib.t2s_dit_timing_end_ex(h, out, 11))       # classes 9 / 10: the first / last row-chain launch (also in class 1)
+    mid_ms, mid_n = out[2] - out[18] - out[20], out[3] - out[19] - out[21]
     return {"attn_us": out[0] / out[1] * 1e3, "attn_calls": int(out[1]),
             "rows_us": out[2] / out[3] * 1e3, "rows_calls": int(out[3]),
-            "other_us": out[4] / out[5] * 1e3, "other_calls": int(out[5]),
+            "rows_first_us": out[18] / max(out[19], 1) * 1e3, "rows_mid_us": mid_ms / max(mid_n, 1) * 1e3,
+            "rows_last_us": out[20] / max(out[21], 1) * 1e3, "rows_mid_calls": int(mid_n),
+            "other_us": out[4] / max(out[5], 1) * 1e3, "other_calls": int(out[5]),
             "forward_us": (out[0] + out[2] + out[4]) / n_steps * 1e3}
+
+
+# algorithmic FLOPs of the three row-chain instances per sequence (480 tokens x 128 inputs x output columns x 2)
+FLOP_ROWS_PER_SEQ = {
+    "dit_rows_kernel<false,true> (block 0: patchify prologue + LN1.mod + qkv)": 2 * 480 * 128 * 384 + 2 * 480 * (16 + 512),
+    "dit_rows_kernel<true,true> (x3 per forward: proj + MLP of block i, LN1.mod + qkv of block i+1)": 2 * 480 * 128 * (128 + 256 + 256 + 384),
+    "dit_rows_kernel<true,false> (block 3: proj + MLP + final LayerNorm / Linear 128->4 / unpatchify)": 2 * 480 * 128 * (128 + 256 + 256 + 4),
+}
+
+
+def roofline_rows(kt, n_seq):
+    """The row chain is 53 % of a sampling step: its three kernel instances against the fp32 MFMA peak, from the same in-situ
+    HIP-event timing as `roofline` (each kernel alone on the chip, 512-sequence CFG passes)."""
+    us = dict(zip(FLOP_ROWS_PER_SEQ, (kt["rows_first_us"], kt["rows_mid_us"], kt["rows_last_us"])))
+    inst, flops, t = {}, 0.0, 0.0
+    for (name, per_seq), mult in zip(FLOP_ROWS_PER_SEQ.items(), (1, 3, 1)):
+        f = per_seq * n_seq
+        ach = f / (us[name] * 1e-6) / 1e12
+        inst[name] = {"avg_launch_us": us[name], "flop_per_launch": f, "achieved": ach, "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+                      "launches_per_forward": mult}
+        flops += mult * f
+        t += mult * us[name] * 1e-6
+    return {"bound": "mfma", "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "instances": inst,
+            "achieved": flops / t / 1e12, "frac": flops / t / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "timing": "HIP events around every row-chain launch of the same 8 eager 512-sequence CFG forwards as `roofline`"}
 
 
 def usable_cores() -> int:
@@ -578,11 +608,114 @@ def alt_math_run(model, vae, args, dev, text):
         kt = time_kernels_in_situ(model, dev, torch.randn(args.batch, 64, 30, device=dev), text)
     finally:
         model.set_math("f32")
+    # its own roofline: an fp32-accurate product costs SIX bf16 MFMAs, so the ceiling of this arithmetic is the dense bf16
+    # matrix peak / 6 in algorithmic (fp32-equivalent) FLOPs; `achieved` counts the algorithmic FLOPs of the attention kernel
+    ach = FLOP_ATTN_PER_SEQ_BLOCK * 2 * args.batch / (kt["attn_us"] * 1e-6) / 1e12
+    whole = FLOP_FORWARD_PER_SEQ * 2 * args.batch * args.diffusion_steps / el / 1e12
     return {"math": "bf16x3: every product of the attention and the row chain as six bf16 MFMAs, fp32-accurate (include/t2s.h T2S_MATH_BF16X3)",
             "value": args.batch / el, "unit": "series/s", "ms_per_step": el * 1e3,
             "attention_us": kt["attn_us"], "row_chain_us": kt["rows_us"],
-            "attention_bf16_tflops_executed": 6 * FLOP_ATTN_PER_SEQ_BLOCK * 2 * args.batch / (kt["attn_us"] * 1e-6) / 1e12,
-            "bf16_dense_peak_tflops": 2500.0}
+            "attention_bf16_tflops_executed": 6 * ach, "bf16_dense_peak_tflops": PEAK_BF16_MFMA_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "attn_x3_kernel (six bf16 MFMAs per fp32-accurate product)", "achieved": ach,
+                         "peak": PEAK_BF16_MFMA_TFLOPS / 6, "unit": "TFLOP/s (algorithmic, fp32-equivalent)",
+                         "frac": ach / (PEAK_BF16_MFMA_TFLOPS / 6), "avg_launch_us": kt["attn_us"],
+                         "whole_path_tflops": whole, "whole_path_frac": whole / (PEAK_BF16_MFMA_TFLOPS / 6)}}
+
+
+def config3_leg(dev, batch=1024, steps=100, cfg=5.0, length=96, timed=2):
+    """BASELINE configs[2] under this clock: rectified flow, B = 1024, 100 steps (infer.py:135 default), cfg 5 (the traffic
+    rows of scripts/script.sh:31-33), the WHOLE loop of each lane in one hipGraph: one warm (capturing) batch + `timed` batches."""
+    from t2ms_amd import synth
+    from t2ms_amd.sampler import Sampler
+    model, vae = build_models(dev)            # its own handle (2048 sequences): the headline's samplers keep theirs
+    s = Sampler(model, vae.decoder, "flowmatching", steps, cfg, batch, length, dev, use_graph=True, seed=2025, row0=0, loop_graph=1)
+    s.run(synth.make_text_embeddings(2025, batch).to(dev), decode=True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        lat, series = s.run_inplace(decode=True)
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    assert bool(torch.isfinite(series).all())
+    tflops = FLOP_FORWARD_PER_SEQ * 2 * batch * steps * timed / el / 1e12
+    return {"metric": f"generated series/sec (configs[2]: B={batch}, L={length}, {steps}-step rectified flow, cfg {cfg}, whole loop in one hipGraph per lane)",
+            "value": batch * timed / el, "unit": "series/s", "ms_per_batch": el / timed * 1e3, "batches_timed": timed,
+            "graph_lanes": s.graph_lanes, "whole_path_tflops": tflops, "whole_path_frac_of_fp32_mfma_peak": tflops / PEAK_FP32_MFMA_TFLOPS,
+            "dtype": "f32", "data": "synthetic"}
+
+
+def config5_leg(dev, model, vae, sampler96, text, batch=256, steps=1000, cfg=9.0):
+    """BASELINE configs[4] under this clock: variable-length groups L in {24, 48, 96} (the collate's length groups,
+    dataloader.py:115-133), each END TO END on one GPU -- LA-VAE encode of the (B, L) series (infer.py:73-74), the 1000-step
+    CFG DDPM loop on the (B,64,30) latent, LA-VAE decode to (B, L): one timed batch per length after that length's
+    capturing batch (L = 96 reuses the headline's warm sampler).  The DiT works on the (64,30) latent whatever L is, so the
+    three rates differ only by the codec."""
+    from t2ms_amd import synth
+    from t2ms_amd.sampler import Sampler
+    out, total_t = {"lengths": {}}, 0.0
+    for L_ in (24, 48, 96):
+        if L_ == 96:
+            s = sampler96
+        else:
+            s = Sampler(model, vae.decoder, "ddpm", steps, cfg, batch, L_, dev, use_graph=True, seed=2025, row0=0)
+            s.run(text, decode=True)
+        x1 = synth.make_series(7, batch, L_).to(dev)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            z_enc, _ = vae.encoder(x1)                      # infer.py:73-74 (model.encoder IS pretrained_model.encoder, :47)
+        lat, series = s.run_inplace(decode=True)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        assert tuple(z_enc.shape) == (batch, 64, 30) and tuple(series.shape) == (batch, L_) and bool(torch.isfinite(series).all())
+        out["lengths"][str(L_)] = {"series_per_s": batch / el, "ms_per_batch": el * 1e3}
+        total_t += el
+        if L_ != 96:
+            del s
+    tflops = FLOP_FORWARD_PER_SEQ * 2 * batch * steps * 3 / total_t / 1e12
+    out.update({"metric": f"generated series/sec (configs[4]: encode + {steps}-step DDPM + decode, B={batch} per length group, L in 24/48/96)",
+                "value": 3 * batch / total_t, "unit": "series/s", "whole_path_tflops": tflops,
+                "whole_path_frac_of_fp32_mfma_peak": tflops / PEAK_FP32_MFMA_TFLOPS, "dtype": "f32", "data": "synthetic",
+                "sample": "one timed batch per length, each after a capturing batch of the same sampler"})
+    return out
+
+
+def accuracy_vs_fp64(dev, batch=32):
+    """The evidence beside `alt_math`: ONE conditional forward at B = 32, t = 500, in the three fp32
+    arithmetics -- f32 MFMA, bf16x3, and the CPU fp32 oracle (the reference's PyTorch-CPU arithmetic) -- against the fp64
+    arithmetic of the oracle on the same fp32 data (tools/accuracy_table.py is the full table: 768 rows per entry, chains,
+    the 1000-step taps; profiles/r05_accuracy.md).  Part of the cpu_baseline leg: the oracle is the checker here too."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import numpy as np
+    from accuracy_table import dbl, fp64_arithmetic
+    from oracle import t2s_oracle as O
+    from t2ms_amd import synth
+    from model.denoiser.transformer import Transformer
+    sd = synth.make_dit_state_dict(2025)
+    x, text = synth.make_latents(41, batch), synth.make_text_embeddings(41, batch)
+    t = torch.full((batch,), 500, dtype=torch.long)
+    with torch.no_grad():
+        cpu32 = O.dit_forward(sd, x, t, text)
+        with fp64_arithmetic():
+            ref = O.dit_forward(dbl(sd), x.double(), t, text.double())
+        cols = {"cpu_fp32_oracle": cpu32.double()}
+        for math, key in (("f32", "f32_mfma"), ("bf16x3", "bf16x3")):
+            m = Transformer()
+            m.load_state_dict(sd, strict=True)
+            m = m.to(dev).eval().set_math(math)
+            cols[key] = m(input=x.to(dev), t=t.to(dev), text_input=text.to(dev)).cpu().double()
+            del m
+    res = {}
+    for k, v in cols.items():
+        d = (v - ref).abs()
+        res[k] = {"rms": float(np.sqrt(float((d ** 2).mean()))), "max_abs": float(d.max())}
+    res["bf16x3_over_oracle"] = {"rms": res["bf16x3"]["rms"] / res["cpu_fp32_oracle"]["rms"],
+                                 "max_abs": res["bf16x3"]["max_abs"] / res["cpu_fp32_oracle"]["max_abs"]}
+    res["f32_mfma_over_oracle"] = {"rms": res["f32_mfma"]["rms"] / res["cpu_fp32_oracle"]["rms"],
+                                   "max_abs": res["f32_mfma"]["max_abs"] / res["cpu_fp32_oracle"]["max_abs"]}
+    res["sample"] = (f"one conditional forward, B={batch} (61,440 outputs), t=500; reference = fp64 arithmetic of the oracle on the "
+                     f"fp32 weights / inputs / time embedding; max |ref| {float(ref.abs().max()):.2f}")
+    return res
 
 
 def spawn_ranks(n_gpus, argv=None):
@@ -652,6 +785,9 @@ def main():
     ap.add_argument("--train-batch", type=int, default=1152, help="per-GPU batch of the training leg")
     ap.add_argument("--train-steps", type=int, default=30)
     ap.add_argument("--no-alt-math", action="store_true", help="skip the extra bf16x3 measurement reported as alt_math")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip `config3` (BASELINE configs[2]: rectified flow, B=1024, 100 steps, whole-loop graph) and `config5` "
+                         "(configs[4]: encode + 1000-step DDPM + decode at L = 24 / 48 / 96)")
     ap.add_argument("--math", default="f32", choices=["f32", "bf16x3"],
                     help="matrix arithmetic: f32 MFMA (headline) or fp32-accurate split-bf16 products (include/t2s.h)")
     args = ap.parse_args()
@@ -764,6 +900,7 @@ def main():
                                      "as two 256-sequence launches that time-share the CUs with the other lane's kernels; "
                                      "per-launch durations there are not a kernel property, the pipelined figure is "
                                      "whole_path_frac_of_fp32_mfma_peak"}
+        out["roofline_rows"] = roofline_rows(kt, 2 * B)
         out["kernel_breakdown_us"] = {"attention_x4": kt["attn_us"], "row_chain_x5": kt["rows_us"],
                                       "other_x1_adaln": kt["other_us"], "forward_total": kt["forward_us"]}
         # whole-step figure for context: all DiT FLOPs / wall time
@@ -774,11 +911,27 @@ def main():
             out["strong"] = strong
         if world == 1 and not args.no_strong and B % 8 == 0 and B >= 64:
             out["strong_shards"] = strong_shards(model, vae, args, dev, value)
+        if world == 1 and not args.no_configs and (args.backbone, args.diffusion_steps, B, args.length) == ("ddpm", 1000, 256, 96):
+            for name, fn in (("config5", lambda: config5_leg(dev, model, vae, sampler, text, B, args.diffusion_steps, args.cfg_scale)),
+                             ("config3", lambda: config3_leg(dev))):
+                try:
+                    out[name] = fn()
+                except Exception as e:      # the headline line must still be printed; the failure is reported in it
+                    import traceback
+                    traceback.print_exc()
+                    out[name] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and args.math == "f32" and not args.no_alt_math:
             out["alt_math"] = alt_math_run(model, vae, args, dev, text)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, args.diffusion_steps, args.cfg_scale, args.length)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            if "alt_math" in out:
+                try:
+                    out["alt_math"]["accuracy_vs_fp64"] = accuracy_vs_fp64(dev)
+                except Exception as e:
+                    import traceback
+                    traceback.print_exc()
+                    out["alt_math"]["accuracy_vs_fp64"] = {"error": f"{type(e).__name__}: {e}"}
         if train is not None:
             out["train"] = train
             if "value" in train and "value" in legs.get("train_driver", {}):

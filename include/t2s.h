@@ -162,7 +162,9 @@ int t2s_dit_timing_end(t2s_dit* h, double* out6);
 /* The same with the launches of the training step (t2s_dit_train_forward / _backward) in classes 3..8: out holds
  * n_classes pairs {ms, launches}: 0 attention, 1 row chain, 2 other (inference forward); 3 streaming GEMMs / fused row
  * kernels, 4 attention forward, 5 attention backward, 6 weight gradients, 7 gate / LayerNorm elementwise kernels,
- * 8 everything else of the step (packs, patchify, final layer, adaLN linear).  n_classes <= 9. */
+ * 8 everything else of the step (packs, patchify, final layer, adaLN linear); 9 / 10 the first (block 0's qkv with the
+ * patchify prologue) and the last (block 3's proj + MLP with the final layer) row-chain launch of an inference forward,
+ * which class 1 contains as well.  n_classes <= 11. */
 int t2s_dit_timing_end_ex(t2s_dit* h, double* out, int n_classes);
 
 /* Test tap: copy out the residual stream (S,480,128) the last forward left in the

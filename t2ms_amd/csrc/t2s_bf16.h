@@ -284,6 +284,17 @@ __device__ __forceinline__ void lnbwd_epilogue(f32x16 (&acc)[4], const float* __
     }
 }
 
+// -DT2S_CHAIN_BOUND (tools/chain_bound.sh; results INVALID, timing only): the forward GEMMs stop reading exactly the tensors
+// a register-resident forward chain per half block (proj -> gate/res -> LN -> fc1 -> GELU -> fc2 -> gate/res -> LN -> qkv)
+// would keep in registers -- p in fc1's prologue, u in fc2's, x_mid and f in the next qkv's -- while every byte the backward
+// pass needs is still WRITTEN.  Whatever such a chain costs on top (weights through a ring or from L2, fewer waves per SIMD),
+// it cannot beat these launches by more than their four launch boundaries per block: an UPPER bound of its gain, measured.
+#ifdef T2S_CHAIN_BOUND
+#define T2S_BOUND(...) __VA_ARGS__
+#else
+#define T2S_BOUND(...)
+#endif
+
 template <int K, int N, int PRO, int EPI>
 __global__ __launch_bounds__(bg_threads(EPI)) T2S_NO_PK_F32 void bgemm_kernel(const BGemmArgs a) {
     constexpr int KS = K / 16, NT = N / 32, THREADS = bg_threads(EPI);
@@ -318,6 +329,15 @@ __global__ __launch_bounds__(bg_threads(EPI)) T2S_NO_PK_F32 void bgemm_kernel(co
             float s = 0.f;
 #pragma unroll
             for (int t = 0; t < KS; ++t) {
+#ifdef T2S_CHAIN_BOUND
+                if constexpr (PRO == BPRO_LN_RES && N == 384) {        // the next block's qkv: x_mid would be in registers
+                    const float c = (float)((lane + 3 * t) & 15) * 0.125f;
+                    v[t][0] = f32x4{c, -c, c + 1.f, 0.5f};
+                    v[t][1] = f32x4{-c, c, 0.25f, c - 1.f};
+                    (void)xr;
+                    continue;
+                }
+#endif
                 v[t][0] = *reinterpret_cast<const f32x4*>(xr + 16 * t);
                 v[t][1] = *reinterpret_cast<const f32x4*>(xr + 16 * t + 4);
             }
@@ -329,7 +349,12 @@ __global__ __launch_bounds__(bg_threads(EPI)) T2S_NO_PK_F32 void bgemm_kernel(co
                 float* xo = a.x_out + (size_t)tile * 32 * K;
 #pragma unroll
                 for (int t = 0; t < KS; ++t) {
+#ifdef T2S_CHAIN_BOUND
+                    (void)rr;                                           // p (fc1) / f (qkv): the chain has them in registers
+                    const f32x8 b = {0.5f, -0.5f, 0.25f, 1.f, -1.f, 0.125f, 0.f, 0.75f};
+#else
                     const f32x8 b = unpack8(*reinterpret_cast<const bf16x8*>(rr + 16 * t));
+#endif
                     const f32x4 g0 = *reinterpret_cast<const f32x4*>(grow + 16 * t);
                     const f32x4 g1 = *reinterpret_cast<const f32x4*>(grow + 16 * t + 4);
                     const f32x4 b0 = {b[0], b[1], b[2], b[3]}, b1 = {b[4], b[5], b[6], b[7]};
@@ -387,6 +412,14 @@ __global__ __launch_bounds__(bg_threads(EPI)) T2S_NO_PK_F32 void bgemm_kernel(co
             }
         } else {
             const __bf16* ar = reinterpret_cast<const __bf16*>(a.A) + row * K + 8 * h;
+#ifdef T2S_CHAIN_BOUND
+            if constexpr (PRO == BPRO_GELU) {                           // fc2: u would be in registers
+                const f32x8 c = {0.5f, -0.5f, 0.25f, 1.f, -1.f, 0.125f, 0.f, 0.75f};
+#pragma unroll
+                for (int t = 0; t < KS; ++t) xf[t] = __builtin_convertvector(c * (float)(1 + ((lane + t) & 3)), bf16x8);
+                (void)ar;
+            } else
+#endif
 #pragma unroll
             for (int t = 0; t < KS; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(ar + 16 * t);
             if constexpr (PRO == BPRO_GELU) {

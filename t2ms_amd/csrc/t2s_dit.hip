@@ -440,7 +440,7 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
         return a;
     };
     {
-        TimeScope ts(h, TC_ROWS, st);
+        TimeScope ts(h, TC_ROWS_FIRST, st);
         rc = x3 ? launch_dit_rows_x3<false, true>(rows_args_x3(-1, 0), st)
                 : (use16 ? launch_dit_rows16<false, true>(rows_args16(-1, 0), st) : launch_dit_rows<false, true>(rows_args(-1, 0), st));
         if (rc != T2S_OK) return rc;
@@ -452,7 +452,7 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
                     : launch_attn_packed(w_q, w_k, w_v, w_ao, S * NH, st);
             if (rc != T2S_OK) return rc;
         }
-        TimeScope ts(h, TC_ROWS, st);
+        TimeScope ts(h, i + 1 < NBLK ? TC_ROWS : TC_ROWS_LAST, st);
         if (i + 1 < NBLK)
             rc = x3 ? launch_dit_rows_x3<true, true>(rows_args_x3(i, i + 1), st)
                     : (use16 ? launch_dit_rows16<true, true>(rows_args16(i, i + 1), st) : launch_dit_rows<true, true>(rows_args(i, i + 1), st));
@@ -701,9 +701,13 @@ int t2s_dit_timing_end_ex(t2s_dit* h, double* out, int n_classes) {
         T2S_HIP_CHECK(hipEventSynchronize(h->ev_pool[2 * i + 1]));
         float ms = 0.f;
         T2S_HIP_CHECK(hipEventElapsedTime(&ms, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]));
-        if (h->ev_class[i] >= n_classes) continue;
-        out[2 * h->ev_class[i]] += ms;
-        out[2 * h->ev_class[i] + 1] += 1.0;
+        const int cls = h->ev_class[i];
+        if (cls == TC_ROWS_FIRST || cls == TC_ROWS_LAST) {      // class 1 = every row-chain launch
+            if (n_classes > TC_ROWS) out[2 * TC_ROWS] += ms, out[2 * TC_ROWS + 1] += 1.0;
+        }
+        if (cls >= n_classes) continue;
+        out[2 * cls] += ms;
+        out[2 * cls + 1] += 1.0;
     }
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     h->ev_pool.clear();

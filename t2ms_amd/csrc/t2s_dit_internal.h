@@ -35,8 +35,10 @@ struct t2s_dit {
 
 namespace t2s {
 // launch classes of the in-situ timing (t2s_dit_timing_begin / _end[_ex]): inference forward 0-2, training step 3-8
+// 9 / 10: the first (<qkv only>, with patchify) and the last (<proj + MLP> + final layer) row-chain launch of a forward; they
+// are ALSO counted in class 1, which stays "every row-chain launch"
 enum { TC_ATTN = 0, TC_ROWS = 1, TC_OTHER = 2, TC_TR_GEMM = 3, TC_TR_ATTN_FWD = 4, TC_TR_ATTN_BWD = 5, TC_TR_WGRAD = 6,
-       TC_TR_ELEM = 7, TC_TR_TAIL = 8, TC_COUNT = 9 };
+       TC_TR_ELEM = 7, TC_TR_TAIL = 8, TC_ROWS_FIRST = 9, TC_ROWS_LAST = 10, TC_COUNT = 11 };
 struct TimeScope {   // records an event pair around the launches issued in its scope when timing is on
     t2s_dit* h; hipStream_t st; bool on;
     TimeScope(t2s_dit* h_, int cls, hipStream_t st_) : h(h_), st(st_), on(h_->timing) {

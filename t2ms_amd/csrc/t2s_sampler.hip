@@ -517,6 +517,11 @@ int enqueue_step(t2s_sampler* s, float* x, const float* text, const float* noise
     int rc = dit_forward_cfg_step(s->dit, xl, s->temb_table, step, text + (size_t)r0 * D, eu, ec, n, st, 2 * r0,
                                   s->mod_table, c.batch + 1, r0);
     if (rc != T2S_OK) return rc;
+    // T2S_SKIP_UPDATE=1 (TIMING ONLY, results invalid: the state and the loop index never advance): the sampler without its
+    // update launch -- the upper bound of what fusing the DDPM / RF update into the last row kernel could save (VERDICT r04
+    // item 7; profiles/EXPERIMENTS.md section 1)
+    static const bool skip_update = getenv("T2S_SKIP_UPDATE") && atoi(getenv("T2S_SKIP_UPDATE")) != 0;
+    if (skip_update) return T2S_OK;
     if (c.mode == T2S_MODE_DDPM) {
         StepArgs a{};
         a.x = xl; a.eps_u = eu; a.eps_c = ec; a.noise = noise ? noise + (size_t)r0 * LAT : nullptr; a.coef = s->coef;

@@ -189,7 +189,7 @@ HOST = {}
 
 
 def gpu_model(sd, dev, math):
-    import model.denoiser.transformer as T
+    import t2ms_amd.model.denoiser.transformer as T       # (model.denoiser.transformer is an alias package of this module)
     sd = dict(sd)
     if HOST:          # the reference box's host-evaluated tables (host_tables)
         sd["pos_embed"] = torch.from_numpy(HOST["pos_embed"])
