@@ -366,6 +366,29 @@ int t2s_vae_decode_w(t2s_vae* h, const float* z, float* recon, float* after, int
 int t2s_vae_encode(t2s_vae* h, const float* x, float* z, float* before, int B, int L,
                    void* stream);
 
+/* Re-copy the weights into an existing handle (same hyper-parameters, same encoder / decoder presence): what a training
+ * step does after the optimizer changed encoder.* (train.py:31-33 with usepretrainedvae false) -- no allocation, stream-ordered. */
+int t2s_vae_update_weights(t2s_vae* h, const t2s_vae_weights* w, void* stream);
+
+/* Backward of Encoder.forward (vqvae.py:57-71) for the one reference configuration that TRAINS the LA-VAE encoder (train.py:31-33,
+ * `usepretrainedvae` false: the encoder is grafted into the denoiser and its parameters join the optimizer).
+ *   x (B,L) the forward's input; dz (B,64,30) = dLoss/dz; dbefore (B,64,L/4) = dLoss/dbefore or NULL (train.py uses z only);
+ *   g: one gradient tensor per encoder.* parameter, same shapes as t2s_vae_weights' enc_* fields; every one is OVERWRITTEN.
+ * The forward is recomputed from x (nothing is saved by t2s_vae_encode); data gradients run per series in LDS, weight gradients
+ * as exact-fp32 MFMA GEMMs over all (series, position) rows with a fixed two-stage reduction: bit-reproducible.
+ * Default LA-VAE shape only (hidden 128, res_hidden 128 / 256, emb 64) and L <= 128; allocates its row blocks on first use /
+ * when B * L grows (not capturable then). */
+typedef struct t2s_vae_enc_grads {
+    float *conv1_w, *conv1_b;   /* encoder._conv_1 (hidden/2,1,4), (hidden/2) */
+    float *conv2_w, *conv2_b;   /* encoder._conv_2 (hidden,hidden/2,4), (hidden) */
+    float *conv3_w, *conv3_b;   /* encoder._conv_3 (hidden,hidden,3), (hidden) */
+    float* stack_conv3_w[4];    /* encoder._residual_stack._layers.i._block.1.weight (res_hidden,hidden,3) */
+    float* stack_conv1_w[4];    /* encoder._residual_stack._layers.i._block.3.weight (hidden,res_hidden,1) */
+    float *prevq_w, *prevq_b;   /* encoder._pre_vq_conv (emb,hidden,1), (emb) */
+} t2s_vae_enc_grads;
+int t2s_vae_encode_backward(t2s_vae* h, const float* x, const float* dz, const float* dbefore, const t2s_vae_enc_grads* g, int B,
+                            int L, void* stream);
+
 /* ------------------------------------------------------------------------ *
  * Fused sampling loop: infer.py:75-95 (x_T -> steps x [2 DiT forwards + CFG +
  * sampler update] -> LA-VAE decode), one hipGraph per step replayed `steps`

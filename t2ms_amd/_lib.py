@@ -60,6 +60,12 @@ class VaeWeights(C.Structure):
                 ("enc_stack", VaeStackWeights), ("enc_prevq_w", C.c_void_p), ("enc_prevq_b", C.c_void_p)]
 
 
+class VaeEncGrads(C.Structure):
+    _fields_ = [("conv1_w", C.c_void_p), ("conv1_b", C.c_void_p), ("conv2_w", C.c_void_p), ("conv2_b", C.c_void_p),
+                ("conv3_w", C.c_void_p), ("conv3_b", C.c_void_p), ("stack_conv3_w", C.c_void_p * 4), ("stack_conv1_w", C.c_void_p * 4),
+                ("prevq_w", C.c_void_p), ("prevq_b", C.c_void_p)]
+
+
 TS2VEC_MAX_BLOCKS = 16
 
 
@@ -130,6 +136,8 @@ SYMBOLS = {
     "t2s_philox_uniform": (_I, [_VP, _U64, _U32, _U32, _I, _I, _VP]),
     "t2s_vae_create": (_I, [C.POINTER(VaeWeights), C.POINTER(_VP)]),
     "t2s_vae_destroy": (None, [_VP]),
+    "t2s_vae_update_weights": (_I, [_VP, C.POINTER(VaeWeights), _VP]),
+    "t2s_vae_encode_backward": (_I, [_VP, _VP, _VP, _VP, C.POINTER(VaeEncGrads), _I, _I, _VP]),
     "t2s_vae_decode": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP]),
     "t2s_vae_encode": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP]),
     "t2s_sampler_create": (_I, [_VP, _VP, C.POINTER(SampleConfig), C.POINTER(_VP)]),

@@ -16,7 +16,7 @@
 // reference-generated fixture tests/golden/train_step.npz.
 #include <vector>
 
-#include "t2s_bf16.h"
+#include "t2s_wgrad.h"
 #include "t2s_dit_internal.h"
 
 using namespace t2s;
@@ -227,63 +227,6 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ Y
         float acc = 0.f;
         for (int r = r0; r < r1; ++r) acc += Y[(size_t)r * N + n];
         atomicAdd(out + n, acc);
-    }
-}
-
-// dW[n][k] += sum_rows dY[row][n] * X[row][k]   and   db[n] += sum_rows dY[row][n]
-// (weight + bias gradient of a linear; N % 32 == 0, K % 128 == 0).
-// A operand = dY^T straight from row-major global memory (lane = output feature n: 128-B coalesced
-// segments, two token rows per MFMA); B operand = X rows, staged ONCE per workgroup in LDS
-// (64-row sub-slabs, coalesced float4) and shared by the 4 waves, which own different n-tiles of
-// the same 128-wide k-chunk.  Partial tiles are added to the gradient with fp32 atomics (full
-// 128-B rows per wave instruction).  The bias gradient falls out of the A operand for free.
-constexpr int WG_ROWS = 64;   // rows staged per LDS pass
-__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dY, const float* __restrict__ X,
-                                                    float* __restrict__ part, float* __restrict__ bpart, int M, int N,
-                                                    int K, int rows_per_wg) {
-    __shared__ __attribute__((aligned(16))) float xs[WG_ROWS * 132];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int half = lane >> 5, j = lane & 31;
-    const int kc = blockIdx.z;                        // 128-wide k-chunk
-    const int nt = blockIdx.y * 4 + wave;             // this wave's n-tile (N % 128 == 0)
-    const int r0 = blockIdx.x * rows_per_wg;
-    const int r1 = min(M, r0 + rows_per_wg);
-    f32x16 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    float bsum = 0.f;
-    const float* ya = dY + nt * 32 + j;
-    for (int rs = r0; rs < r1; rs += WG_ROWS) {
-        __syncthreads();   // previous sub-slab fully consumed
-        for (int idx = threadIdx.x; idx < WG_ROWS * 32; idx += 256) {
-            const int rr = idx >> 5, c4 = idx & 31;
-            const int row = rs + rr;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < r1) v = *reinterpret_cast<const f32x4*>(X + (size_t)row * K + kc * 128 + c4 * 4);
-            *reinterpret_cast<f32x4*>(xs + rr * 132 + c4 * 4) = v;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int rr = 0; rr < WG_ROWS; rr += 2) {
-            const int row = rs + rr + half;
-            const float a = row < r1 ? ya[(size_t)row * N] : 0.f;
-            bsum += a;
-            const float* xb = xs + (rr + half) * 132 + j;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = mfma32(a, xb[t * 32], acc[t]);
-        }
-    }
-    // partial tile of this workgroup (summed over the row slabs by wgrad16_reduce_kernel, t2s_bf16.h)
-    float* pt = part + ((size_t)(blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * (128 * 128);
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pt[(wave * 32 + acc_row(r, half)) * 128 + t * 32 + j] = acc[t][r];
-    if (kc == 0) {
-        bsum += xhalf(bsum);
-        if (half == 0) bpart[(size_t)(blockIdx.x * gridDim.y + blockIdx.y) * 128 + wave * 32 + j] = bsum;
     }
 }
 
@@ -920,19 +863,7 @@ int gemm(const float* A, const f32x4* Wp, const float* bias, float* out, int M, 
 
 // weight (and, if db != NULL, bias) gradient of a linear layer
 int wgrad(t2s_train_ws* ws, const float* dY, const float* X, float* dW, float* db, int M, int N, int K, hipStream_t st) {
-    T2S_REQUIRE(N % 128 == 0 && K % 128 == 0 && M > 0, "wgrad: unsupported shape M=%d N=%d K=%d", M, N, K);
-    int rows_per_wg, gx;
-    wgrad16_plan(M, N, K, ws->n_cu, &rows_per_wg, &gx);
-    const int gy = N / 128, gz = K / 128;
-    const size_t part_floats = (size_t)gx * gy * gz * (128 * 128);
-    T2S_REQUIRE(part_floats + (size_t)gx * gy * 128 <= ws->wg_scratch_floats, "wgrad: scratch too small for M=%d N=%d K=%d", M, N, K);
-    float* part = ws->wg_scratch;
-    float* bpart = ws->wg_scratch + part_floats;
-    wgrad_kernel<<<dim3(gx, gy, gz), 256, 0, st>>>(dY, X, part, bpart, M, N, K, rows_per_wg);
-    T2S_LAUNCH_CHECK();
-    wgrad16_reduce_kernel<<<dim3(65, gy * gz), 256, 0, st>>>(part, bpart, dW, db, gx, gy, gz, K);
-    T2S_LAUNCH_CHECK();
-    return T2S_OK;
+    return launch_wgrad32(dY, X, dW, db, M, N, K, ws->wg_scratch, ws->wg_scratch_floats, ws->n_cu, st);
 }
 
 int colsum(const float* Y, float* out, int M, int N, hipStream_t st) {

@@ -4,12 +4,14 @@ Class and attribute names equal the reference's, so its whole-module pickles
 (``final_model.pth``, loaded with weights_only=False at infer.py:39 / train.py:22)
 resolve to these classes and their tensors are used as-is.  ``Encoder.forward``
 and ``Decoder.forward`` run single-launch HIP kernels (t2s_vae.hip); the
-nn.Conv1d objects only hold weights.  Inference only (the reference freezes
-the VAE while training the DiT, train.py:31-33); no CPU fallback.
+nn.Conv1d objects only hold weights.  The reference freezes the VAE while training
+the DiT (train.py:31-33); with `usepretrainedvae` false the encoder trains and its
+backward is t2s_vae_encode_backward.  No CPU fallback.
 """
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -83,21 +85,32 @@ class _Codec(nn.Module):
         for t in ts:
             if t.device != device:
                 raise L.T2SError(f"LA-VAE parameters live on {t.device} but the input is on {device}")
-        stamp = (str(device),) + tuple((t.data_ptr(), t._version) for t in ts)
+        inference = any(t.is_inference() for t in ts)          # no version counters: nothing to cache against
+        stamp = None if inference else (str(device),) + tuple((t.data_ptr(), t._version) for t in ts)
+        shape = (str(device),) + tuple(tuple(t.shape) for t in ts)
         h = self.__dict__.get("_t2s_h")
-        if h is None or self.__dict__.get("_t2s_stamp") != stamp:
+        if h is None or self.__dict__.get("_t2s_shape") != shape:
             if h is not None:
                 h.close()
             w, keep = self._weights_struct()
             h = _VaeHandle(w, device)
             del keep  # the library made its own copies
-            self.__dict__["_t2s_h"], self.__dict__["_t2s_stamp"] = h, stamp
+            self.__dict__["_t2s_h"], self.__dict__["_t2s_stamp"], self.__dict__["_t2s_shape"] = h, stamp, shape
+        elif stamp is None or self.__dict__.get("_t2s_stamp") != stamp:
+            # same tensors' shapes, new contents (an optimizer step on a trainable encoder, load_state_dict): re-copy into the
+            # handle's own buffers -- no allocation, stream-ordered (t2s_vae_update_weights)
+            w, keep = self._weights_struct()
+            with torch.cuda.device(device):
+                L.check(L.lib().t2s_vae_update_weights(h.ptr, C.byref(w), L.stream_ptr(device)), "t2s_vae_update_weights")
+            h.keep = keep          # the copies are stream-ordered: keep the sources alive until the next refresh
+            self.__dict__["_t2s_stamp"] = stamp
         return h.ptr
 
     def __getstate__(self):
         state = self.__dict__.copy()
         state.pop("_t2s_h", None)
         state.pop("_t2s_stamp", None)
+        state.pop("_t2s_shape", None)
         return state
 
 
@@ -127,11 +140,25 @@ class Encoder(_Codec):
             setattr(w, name, c.data_ptr())
         return w, keep
 
+    def _hip_backward_ok(self, Ln):
+        """t2s_vae_encode_backward covers the reference's default LA-VAE (pretrained_lavae_unified.py:119-122: hidden 128,
+        res_hidden 128 / 256, emb 64) on the BASELINE lengths (L <= 128)."""
+        rh = self._residual_stack._layers[0]._block[1].out_channels if len(self._residual_stack._layers) else 128
+        return (self._conv_2.out_channels == 128 and rh % 128 == 0 and self._pre_vq_conv.out_channels == 64
+                and len(self._residual_stack._layers) <= 4 and 8 <= Ln <= 128 and Ln % 4 == 0)
+
+    def _grad_params(self):
+        """The 12 encoder tensors in t2s_vae_enc_grads order."""
+        ps = [self._conv_1.weight, self._conv_1.bias, self._conv_2.weight, self._conv_2.bias, self._conv_3.weight, self._conv_3.bias]
+        ps += [layer._block[1].weight for layer in self._residual_stack._layers]
+        ps += [layer._block[3].weight for layer in self._residual_stack._layers]
+        return ps + [self._pre_vq_conv.weight, self._pre_vq_conv.bias]
+
     def _forward_autograd(self, inputs):
-        """The same forward as torch ops UNDER AUTOGRAD, for the one case that needs the encoder's gradients: train.py:31-33 with
-        `usepretrainedvae` false (the LA-VAE encoder trained jointly with the denoiser).  Host-level plumbing like the MLP
-        denoiser: no scripted configuration of the reference trains the encoder; the frozen / inference path is the HIP kernel
-        below.  nn.ReLU(True) of the reference's Residual mutates the block input, so the skip carries relu(x) (vqvae.py:10-21)."""
+        """The same forward as torch ops UNDER AUTOGRAD: only for LA-VAE shapes t2s_vae_encode_backward does not cover
+        (non-default hyper-parameters, L > 128) when the encoder trains (train.py:31-33 with `usepretrainedvae` false) --
+        host-level plumbing like the MLP denoiser.  The default shape runs forward AND backward in the HIP kernels (_EncodeFn).
+        nn.ReLU(True) of the reference's Residual mutates the block input, so the skip carries relu(x) (vqvae.py:10-21)."""
         import torch.nn.functional as F
         B, Ln = inputs.shape[0], inputs.shape[-1]
         h = inputs.float().reshape(B, 1, Ln)
@@ -150,7 +177,12 @@ class Encoder(_Codec):
         if not inputs.is_cuda:
             raise L.T2SError("Encoder.forward: input must live on a GPU; the HIP path has no CPU fallback")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if self._hip_backward_ok(inputs.shape[-1]) and os.environ.get("T2S_ENCODER_TORCH_AUTOGRAD", "0") in ("", "0"):
+                return _EncodeFn.apply(self, inputs, *self._grad_params())
             return self._forward_autograd(inputs)
+        return self._forward_hip(inputs)
+
+    def _forward_hip(self, inputs):
         B, Ln = inputs.shape[0], inputs.shape[-1]
         x = L.as_f32(inputs).reshape(B, Ln)
         dev = x.device
@@ -162,6 +194,46 @@ class Encoder(_Codec):
             L.check(L.lib().t2s_vae_encode(h, L.dev_ptr(x, "inputs"), L.dev_ptr(z), L.dev_ptr(before), B, Ln,
                                            L.stream_ptr(dev)), "t2s_vae_encode")
         return z, before
+
+
+class _EncodeFn(torch.autograd.Function):
+    """Encoder.forward under autograd, both directions in the HIP kernels: t2s_vae_encode now, t2s_vae_encode_backward for the
+    12 parameter gradients (the forward is recomputed from x there; nothing but x is saved).  The input series gets no
+    gradient (it is data, train.py:104-106)."""
+
+    @staticmethod
+    def forward(ctx, enc, inputs, *params):
+        with torch.no_grad():
+            z, before = enc._forward_hip(inputs)
+        ctx.enc = enc
+        ctx.save_for_backward(L.as_f32(inputs).reshape(inputs.shape[0], inputs.shape[-1]))
+        ctx.n_layers = len(enc._residual_stack._layers)
+        ctx.set_materialize_grads(False)      # train.py uses z only: `before` then arrives as None, not as a zero tensor
+        return z, before
+
+    @staticmethod
+    def backward(ctx, dz, dbefore):
+        (x,) = ctx.saved_tensors
+        enc, n = ctx.enc, ctx.n_layers
+        dev = x.device
+        params = enc._grad_params()
+        grads = [torch.empty_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for p in params]
+        g = L.VaeEncGrads()
+        names = ["conv1_w", "conv1_b", "conv2_w", "conv2_b", "conv3_w", "conv3_b"]
+        for nm, t in zip(names, grads[:6]):
+            setattr(g, nm, t.data_ptr())
+        for i in range(n):
+            g.stack_conv3_w[i] = grads[6 + i].data_ptr()
+            g.stack_conv1_w[i] = grads[6 + n + i].data_ptr()
+        g.prevq_w, g.prevq_b = grads[6 + 2 * n].data_ptr(), grads[7 + 2 * n].data_ptr()
+        dzc = L.as_f32(dz) if dz is not None else torch.zeros(x.shape[0], 64, L.LAT_W, device=dev)
+        dbc = L.as_f32(dbefore) if dbefore is not None else None
+        with torch.cuda.device(dev):
+            h = enc._handle(dev)           # (the weights of the forward: no optimizer step happens between the two)
+            L.check(L.lib().t2s_vae_encode_backward(h, L.dev_ptr(x), L.dev_ptr(dzc), L.dev_ptr(dbc), C.byref(g), x.shape[0],
+                                                    x.shape[1], L.stream_ptr(dev)), "t2s_vae_encode_backward")
+        out = [gr if p.requires_grad else None for gr, p in zip(grads, params)]
+        return (None, None, *out)
 
 
 class Decoder(_Codec):

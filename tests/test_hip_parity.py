@@ -1033,11 +1033,24 @@ def test_two_host_threads_drive_two_samplers_on_one_device(dev, vae):
     threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
     [t.start() for t in threads]
     [t.join() for t in threads]
+    mismatches = [(i, k) for i in range(2) for k, (lat, ser) in enumerate(got[i])
+                  if not (torch.equal(lat, want[i][0]) and torch.equal(ser, want[i][1]))]
+    if errors or mismatches or any(len(g) != 12 for g in got):
+        # KEEP the evidence (round 4 saw one failure of this test and kept none of its output: which call failed with which
+        # error stayed unknown): the T2SError texts carry the failing entry point and HIP's error string
+        import json
+        import time
+        os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
+                            f"two_thread_failure_{int(time.time())}.json")
+        json.dump({"errors": errors, "mismatches": mismatches, "runs_done": [len(g) for g in got],
+                   "last_error": L.lib().t2s_last_error().decode("utf-8", "replace"), "lane_pool": int(L.lib().t2s_sampler_lane_pool())},
+                  open(path, "w"), indent=1)
+        print("two-thread failure recorded in", path)
     assert not errors, errors
     for i in range(2):
         assert len(got[i]) == 12
-        for lat, ser in got[i]:
-            assert torch.equal(lat, want[i][0]) and torch.equal(ser, want[i][1]), i
+    assert not mismatches, mismatches
 
 
 # ---------------------------------------------------------------- 1000-step chain at the headline schedule

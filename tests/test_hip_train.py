@@ -552,8 +552,9 @@ def test_drop_in_chain_vae_pickle_train_infer_metrics(dev, tmp_path, monkeypatch
 
 
 def test_unfrozen_encoder_gradients_match_oracle(dev):
-    """train.py:31-33 with `usepretrainedvae` false: the LA-VAE encoder trains jointly.  The encoder then runs as torch ops
-    under autograd, q_sample as torch glue, and the DiT returns the gradient of its input latent
+    """train.py:31-33 with `usepretrainedvae` false: the LA-VAE encoder trains jointly.  The encoder runs forward AND backward
+    in the HIP kernels (t2s_vae_encode / t2s_vae_encode_backward behind an autograd.Function; round 5 -- until then torch conv
+    ops under autograd), q_sample as torch glue, and the DiT returns the gradient of its input latent
     (t2s_dit_train_input_grad, patchify backwards): all 12 encoder gradients and the 48 DiT gradients against autograd
     through the oracle (encoder -> q_sample -> DiT -> MSE), 2e-4 of each tensor's largest gradient."""
     import types
@@ -579,6 +580,7 @@ def test_unfrozen_encoder_gradients_match_oracle(dev):
     m.encoder = v.encoder.to(dev)
     z, _ = m.encoder(xs.to(dev))
     assert z.requires_grad and float((z.detach().cpu() - z_ref.detach()).abs().max()) < 1e-5
+    assert type(z.grad_fn).__name__ == "_EncodeFnBackward"          # the HIP pair, not torch conv ops
     ab = tab["alpha_bar"].to(dev).gather(-1, t.to(dev)).reshape(-1, 1, 1)
     x_t = ab ** 0.5 * z + (1 - ab) ** 0.5 * noise.to(dev)
     loss = mse_loss(m(input=x_t, t=t.to(dev), text_input=text.to(dev)), noise.to(dev))
@@ -599,6 +601,83 @@ def test_unfrozen_encoder_gradients_match_oracle(dev):
         p.requires_grad = False
     z2, _ = m.encoder(xs.to(dev))
     assert not z2.requires_grad and float((z2 - z.detach()).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("Ls,B", [(24, 5), (48, 2), (96, 3), (128, 1)])
+def test_encoder_backward_kernel_vs_oracle_autograd(dev, Ls, B, monkeypatch):
+    """t2s_vae_encode_backward (vqvae.py:57-71 backwards) on its own: loss = <z, G> + <before, H> with random G, H, so both
+    outputs carry a gradient.  All 12 encoder.* gradients against autograd through the oracle (2e-4 of each tensor's largest
+    gradient; measured ~1e-6), bit-reproducible from run to run, equal (to rounding) to the torch-op path it replaced, and
+    fresh weights after an in-place update are picked up without rebuilding the handle (t2s_vae_update_weights)."""
+    import types
+    from model.pretrained.vqvae import vqvae
+    xs = synth.make_series(300 + Ls, B, Ls)
+    rs = np.random.RandomState(Ls)
+    G = torch.from_numpy(rs.randn(B, 64, 30).astype(np.float32))
+    Hh = torch.from_numpy(rs.randn(B, 64, Ls // 4).astype(np.float32))
+    vsd = {k: v.clone().requires_grad_(k.startswith("encoder.")) for k, v in synth.make_vae_state_dict(2025).items()}
+    z_ref, before_ref = O.vae_encode(vsd, xs)
+    ((z_ref * G).sum() + (before_ref * Hh).sum()).backward()
+    v = vqvae(types.SimpleNamespace(block_hidden_size=128, num_residual_layers=2, res_hidden_size=256, embedding_dim=64))
+    v.load_state_dict(synth.make_vae_state_dict(2025), strict=True)
+    enc = v.encoder.to(dev)
+
+    def run():
+        enc.zero_grad(set_to_none=True)
+        z, before = enc(xs.to(dev))
+        ((z * G.to(dev)).sum() + (before * Hh.to(dev)).sum()).backward()
+        return z, {n: p.grad.detach().clone() for n, p in enc.named_parameters()}
+
+    z, g1 = run()
+    assert type(z.grad_fn).__name__ == "_EncodeFnBackward"
+    _, g2 = run()
+    assert len(g1) == 12
+    for n, got in g1.items():
+        ref = vsd["encoder." + n].grad
+        scale = float(ref.abs().max()) + 1e-12
+        assert got.shape == ref.shape
+        assert float((got.cpu() - ref).abs().max()) < 2e-4 * scale, (n, float((got.cpu() - ref).abs().max()), scale)
+        assert torch.equal(got, g2[n]), n                                   # fixed summation order
+    h_before = enc.__dict__["_t2s_h"]
+    monkeypatch.setenv("T2S_ENCODER_TORCH_AUTOGRAD", "1")                    # the torch-op path this kernel replaced
+    zt, g3 = run()
+    assert type(zt.grad_fn).__name__ != "_EncodeFnBackward"
+    for n in g1:
+        scale = float(g3[n].abs().max()) + 1e-12
+        assert float((g1[n] - g3[n]).abs().max()) < 2e-4 * scale, n
+    monkeypatch.delenv("T2S_ENCODER_TORCH_AUTOGRAD")
+    # an optimizer-style in-place update: same handle, new contents
+    with torch.no_grad():
+        for p in enc.parameters():
+            p.mul_(1.01)
+    z2, g4 = run()
+    assert enc.__dict__["_t2s_h"] is h_before
+    vsd2 = {k: (v.detach() * 1.01 if k.startswith("encoder.") else v.detach()).clone().requires_grad_(k.startswith("encoder."))
+            for k, v in vsd.items()}
+    z2_ref, b2_ref = O.vae_encode(vsd2, xs)
+    ((z2_ref * G).sum() + (b2_ref * Hh).sum()).backward()
+    assert float((z2.detach().cpu() - z2_ref.detach()).abs().max()) < 1e-5
+    for n, got in g4.items():
+        ref = vsd2["encoder." + n].grad
+        assert float((got.cpu() - ref).abs().max()) < 2e-4 * (float(ref.abs().max()) + 1e-12), n
+
+
+def test_encoder_backward_refuses_what_it_does_not_cover(dev):
+    """Non-default LA-VAE shapes keep the labelled torch-op path in the mirror; the C entry itself refuses them loudly."""
+    import ctypes as C
+    import types
+    from model.pretrained.vqvae import vqvae
+    from t2ms_amd import _lib as L
+    v = vqvae(types.SimpleNamespace(block_hidden_size=16, num_residual_layers=2, res_hidden_size=32, embedding_dim=64)).to(dev)
+    x = synth.make_series(1, 2, 24).to(dev)
+    z, _ = v.encoder(x)
+    assert z.requires_grad and type(z.grad_fn).__name__ != "_EncodeFnBackward"
+    z.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in v.encoder.parameters())
+    h = v.encoder._handle(dev)
+    g = L.VaeEncGrads()
+    rc = L.lib().t2s_vae_encode_backward(h, x.data_ptr(), z.detach().data_ptr(), None, C.byref(g), 2, 24, None)
+    assert rc == -1 and "unsupported" in L.lib().t2s_last_error().decode()
 
 
 def test_train_driver_with_unfrozen_encoder(dev, tmp_path, monkeypatch):
