@@ -57,6 +57,7 @@ def build_models(dev, seed=2025):
     v = vqvae(types.SimpleNamespace(block_hidden_size=128, num_residual_layers=2, res_hidden_size=256,
                                     embedding_dim=64))
     v.load_state_dict(synth.make_vae_state_dict(seed), strict=True)
+    m.set_math("f32")        # explicit: every figure of this file is on the exact f32 MFMA unless it says bf16x3 (alt_math, infer_driver)
     return m.to(dev).eval(), v.to(dev).eval()
 
 
@@ -461,7 +462,7 @@ def infer_driver_leg(dev, dist, rank, world, rows=2048):
         if rank == 0:
             shutil.rmtree(tmp, ignore_errors=True)
     out = {"metric": "infer.py at the authors' flags (scripts/script.sh:4): flowmatching, 100 steps, cfg 7, --batch_size 2, L=24",
-           "value": st["series"] / st["loop_s"], "unit": "series/s", "series": st["series"], "loop_s": st["loop_s"],
+           "math": a.math, "value": st["series"] / st["loop_s"], "unit": "series/s", "series": st["series"], "loop_s": st["loop_s"],
            "whole_main_s": wall, "whole_main_series_per_s": st["series"] / wall, "launches": st["launches"],
            "series_per_launch_and_gpu": st["series_per_launch_and_gpu"], "loader_batch": st["loader_batch"], "n_gpus": world,
            "data": f"synthetic ({rows} test rows)",
@@ -469,7 +470,7 @@ def infer_driver_leg(dev, dist, rank, world, rows=2048):
                    "whole_main adds model construction, hipGraph capture and np.save of the four files (the ten jpg plots skipped)"}
     if rank == 0:       # the kernels' own rate at this shape: one resident 256-series sampler, same steps / cfg / length
         model, vae = build_models(dev)
-        s = Sampler(model, vae.decoder, "flowmatching", 100, 7.0, 256, 24, dev, use_graph=True, seed=2025, row0=0)
+        s = Sampler(model, vae.decoder, "flowmatching", 100, 7.0, 256, 24, dev, use_graph=True, seed=2025, row0=0, math=a.math)
         s.run(synth.make_text_embeddings(2025, 256).to(dev), decode=True)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()

@@ -135,7 +135,11 @@ def infer(args):
     model, vae = _load_models(args, device)
     is_mlp = args.denoiser == "MLP"
     if not is_mlp:
-        model.set_math(getattr(args, "math", "f32"))
+        from t2ms_amd.sampler import default_math
+        args.math = getattr(args, "math", None) or default_math()
+        model.set_math(args.math)
+        if rank == 0:
+            print(f"matrix arithmetic: {args.math}" + (" (fp32-accurate split-bf16 products; --math f32 = exact f32 MFMA)" if args.math == "bf16x3" else ""))
 
     # The loader's ORDER without the loader's per-row work (datafactory.epoch_index_batches draws what one pass over
     # the DataLoader draws): output row i is dataset row order[i], exactly the concatenation of the reference's batches
@@ -268,8 +272,10 @@ def build_parser():
     p.add_argument("--loader_batches", action="store_true",
                    help="take the row order from a real DataLoader walk (public torch API) instead of the emulated draws of "
                         "datafactory.epoch_index_batches -- same order, same files; the cross-check after a torch upgrade")
-    p.add_argument("--math", default="f32", choices=["f32", "bf16x3"],
-                   help="matrix arithmetic of the DiT: f32 MFMA (default) or fp32-accurate split-bf16 products (faster)")
+    p.add_argument("--math", default=None, choices=["f32", "bf16x3"],
+                   help="matrix arithmetic of the DiT: bf16x3 (default; fp32-ACCURATE split-bf16 products on the bf16 matrix cores, "
+                        "+35 %%; its error against fp64 is not larger than the reference's PyTorch-CPU fp32 arithmetic, "
+                        "profiles/r05_accuracy.md) or f32 (exact f32 MFMA)")
     return p
 
 

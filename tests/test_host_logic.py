@@ -216,3 +216,19 @@ def test_bench_self_spawn_builds_a_fresh_rank_launcher(monkeypatch, capsys):
     seen["rc"] = 7                                 # a failing child: its code comes back, no result line is printed
     assert bench.spawn_ranks(4, ["--gpus", "4"]) == 7
     assert not [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
+
+
+def test_shipped_default_math_is_bf16x3_and_the_suite_pins_f32(monkeypatch):
+    """Round 5 made the fp32-accurate bf16x3 arithmetic the default of the Sampler and of infer.py (profiles/r05_accuracy.md);
+    the bench headline and the class API stay on the exact f32 MFMA.  The suite itself runs with T2S_DEFAULT_MATH=f32."""
+    import infer
+    from t2ms_amd import sampler
+    assert sampler.DEFAULT_MATH == "bf16x3"
+    assert os.environ.get("T2S_DEFAULT_MATH") == "f32" and sampler.default_math() == "f32"
+    monkeypatch.delenv("T2S_DEFAULT_MATH")
+    assert sampler.default_math() == "bf16x3"
+    assert infer.build_parser().parse_args([]).math is None                  # resolved by default_math() at run time
+    assert infer.build_parser().parse_args(["--math", "f32"]).math == "f32"
+    monkeypatch.setenv("T2S_DEFAULT_MATH", "tf32")
+    with pytest.raises(ValueError):
+        sampler.default_math()
