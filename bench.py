@@ -607,6 +607,10 @@ def alt_math_run(model, vae, args, dev, text):
         torch.cuda.synchronize(dev)
         el = time.perf_counter() - t0
         kt = time_kernels_in_situ(model, dev, torch.randn(args.batch, 64, 30, device=dev), text)
+        shards = None
+        if not args.no_strong and args.batch % 8 == 0 and args.batch >= 64:
+            # the drivers' default arithmetic on the per-GPU shards of a 256-series job (as `strong_shards` does for f32)
+            shards = strong_shards(model, vae, args, dev, args.batch / el)
     finally:
         model.set_math("f32")
     # its own roofline: an fp32-accurate product costs SIX bf16 MFMAs, so the ceiling of this arithmetic is the dense bf16
@@ -617,6 +621,7 @@ def alt_math_run(model, vae, args, dev, text):
             "value": args.batch / el, "unit": "series/s", "ms_per_step": el * 1e3,
             "attention_us": kt["attn_us"], "row_chain_us": kt["rows_us"],
             "attention_bf16_tflops_executed": 6 * ach, "bf16_dense_peak_tflops": PEAK_BF16_MFMA_TFLOPS,
+            "strong_shards": shards,
             "roofline": {"bound": "mfma", "kernel": "attn_x3_kernel (six bf16 MFMAs per fp32-accurate product)", "achieved": ach,
                          "peak": PEAK_BF16_MFMA_TFLOPS / 6, "unit": "TFLOP/s (algorithmic, fp32-equivalent)",
                          "frac": ach / (PEAK_BF16_MFMA_TFLOPS / 6), "avg_launch_us": kt["attn_us"],
