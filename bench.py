@@ -724,6 +724,73 @@ def accuracy_vs_fp64(dev, batch=32):
     return res
 
 
+def pmc_probe(dev):
+    """`bench.py --pmc-probe` (the CHILD of measure_pmc, under `rocprofv3 --pmc ...`): a few eager 512-sequence CFG forwards at
+    the headline shape, every kernel alone on the chip (the launch shape of `roofline`), nothing else."""
+    from t2ms_amd import _lib as L
+    from t2ms_amd import synth
+    model, _ = build_models(dev)
+    B = 256
+    x = synth.make_latents(3, B).to(dev)
+    text = synth.make_text_embeddings(2025, B).to(dev)
+    lib = L.lib()
+    with torch.cuda.device(dev):
+        h = model.t2s_handle(dev, 2 * B)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        temb = model.time_emb(torch.full((1,), 500, device=dev))
+        ou, oc = torch.empty_like(x), torch.empty_like(x)
+        for _ in range(4):
+            L.check(lib.t2s_dit_forward_cfg(h, x.data_ptr(), temb.data_ptr(), text.data_ptr(), ou.data_ptr(), oc.data_ptr(), B, st))
+        torch.cuda.synchronize(dev)
+
+
+def measure_pmc(passes, timeout_s=150):
+    """HBM bytes / matrix-busy cycles of the hot kernels measured BY THIS RUN: one `rocprofv3 --pmc <counters>` child per pass
+    (separate passes for FETCH_SIZE and WRITE_SIZE, as MI355X_MICROARCH.md prescribes; counters only, no trace domains) around
+    `bench.py --pmc-probe`.  The parent has initialised the GPU, so the profiler is STARTED AS A CHILD (never an exec), with the
+    interpreter itself after `--`.  -> {kernel name: {counter: average per dispatch}}; {} if rocprofv3 is missing or a pass fails
+    (the caller then falls back to the committed passes and says so)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}
+    out = {}
+    for counters in passes:
+        tmp = tempfile.mkdtemp(prefix="t2s_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.abspath(__file__), "--pmc-probe"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+            files = sorted(glob.glob(os.path.join(tmp, "*", "*counter_collection.csv")))
+            if r.returncode != 0 or not files:
+                print(f"bench.py: rocprofv3 --pmc {' '.join(counters)} failed (rc {r.returncode}): {r.stderr[-300:]}", file=sys.stderr)
+                return {}
+            agg = {}
+            for row in csv.DictReader(open(files[-1])):
+                a = agg.setdefault((row["Kernel_Name"], row["Counter_Name"]), [0.0, 0])
+                a[0] += float(row["Counter_Value"])
+                a[1] += 1
+            for (k, c), (v, n) in agg.items():
+                out.setdefault(k, {})[c] = v / n
+        except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+            print(f"bench.py: PMC pass {counters} failed: {type(e).__name__}: {e}", file=sys.stderr)
+            return {}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def _pmc_of(pm, part, counter):
+    for k, d in pm.items():
+        if part in k and counter in d:
+            return d[counter]
+    return None
+
+
 def spawn_ranks(n_gpus, argv=None):
     """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves, one FRESH process per
     GPU (`python -m torch.distributed.run --nproc-per-node N bench.py <same flags>` as a CHILD -- never an exec: this
@@ -796,7 +863,14 @@ def main():
                          "(configs[4]: encode + 1000-step DDPM + decode at L = 24 / 48 / 96)")
     ap.add_argument("--math", default="f32", choices=["f32", "bf16x3"],
                     help="matrix arithmetic: f32 MFMA (headline) or fp32-accurate split-bf16 products (include/t2s.h)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the in-run rocprofv3 --pmc passes (roofline.traffic / mfma_busy then come from the committed profiles)")
+    ap.add_argument("--pmc-probe", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_probe:
+        torch.cuda.set_device(0)
+        pmc_probe(torch.device("cuda", 0))
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -882,21 +956,36 @@ def main():
         t_attn = kt["attn_us"] * 1e-6
         flop_attn = FLOP_ATTN_PER_SEQ_BLOCK * 2 * B
         achieved = flop_attn / t_attn / 1e12
-        # HBM traffic / matrix-busy share of that kernel: NOT measured by this run (PMC counters need rocprofv3
-        # passes of their own); read from the committed summary of those passes, which names its source revision
-        pmc = {}
-        pfile = os.path.join(REPO, "profiles", "attn_pmc.json")
-        if os.path.exists(pfile) and B == 256:     # the PMC passes were taken at the headline shape
-            try:
-                pmc = json.load(open(pfile))
-            except (OSError, ValueError):
-                pmc = {}
-        traffic = pmc.get("hbm_bytes_per_launch")
+        # HBM traffic / matrix-busy share of that kernel: PMC counters need rocprofv3 passes of their own -- taken by THIS run as
+        # child processes around the same launch shape (measure_pmc; FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE x 2
+        # on gfx950, KB units: MI355X_MICROARCH.md "HBM"); if the profiler is not available, the committed passes, labelled
+        pm = {}
+        if world == 1 and B == 256 and not args.no_pmc:
+            pm = measure_pmc([["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES"]])
+        fa, wa = _pmc_of(pm, "attn_fwd_persistent", "FETCH_SIZE"), _pmc_of(pm, "attn_fwd_persistent", "WRITE_SIZE")
+        busy = _pmc_of(pm, "attn_fwd_persistent", "SQ_VALU_MFMA_BUSY_CYCLES")
+        if fa is not None and wa is not None:
+            traffic = (2 * fa + wa) * 1024
+            pmc = {"mfma_busy_frac": (busy / 1024 / (t_attn * 2.4e9)) if busy else None, "measured_by_this_run": True,
+                   "fetch_size_kb_raw": fa, "write_size_kb": wa, "mfma_busy_cycles_per_dispatch": busy,
+                   "source": "rocprofv3 --pmc passes started by this run around `bench.py --pmc-probe` (4 eager 512-sequence CFG forwards); "
+                             "traffic = (2 x FETCH_SIZE + WRITE_SIZE) KB; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / "
+                             "(in-situ launch duration x 2.4 GHz)"}
+        else:
+            pmc = {}
+            pfile = os.path.join(REPO, "profiles", "attn_pmc.json")
+            if os.path.exists(pfile) and B == 256:     # the committed PMC passes were taken at the headline shape
+                try:
+                    pmc = json.load(open(pfile))
+                    pmc["measured_by_this_run"] = False
+                except (OSError, ValueError):
+                    pmc = {}
+            traffic = pmc.get("hbm_bytes_per_launch")
         out["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_persistent_kernel", "achieved": achieved,
                            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                            "traffic": traffic, "hbm_gbps": (traffic / t_attn / 1e9) if traffic else None,
-                           "pmc": {"mfma_busy_frac": pmc.get("mfma_busy_frac"), "source": pmc.get("source"),
-                                   "measured_by_this_run": False} if pmc else None,
+                           "pmc": {k: pmc.get(k) for k in ("mfma_busy_frac", "measured_by_this_run", "fetch_size_kb_raw", "write_size_kb",
+                                                           "source")} if pmc else None,
                            "avg_launch_us": t_attn * 1e6,
                            "flop_per_launch": flop_attn, "launches_timed": kt["attn_calls"],
                            "timing": "HIP events on the launch stream around every attention launch of "
@@ -907,6 +996,16 @@ def main():
                                      "per-launch durations there are not a kernel property, the pipelined figure is "
                                      "whole_path_frac_of_fp32_mfma_peak"}
         out["roofline_rows"] = roofline_rows(kt, 2 * B)
+        if pm:   # the row-chain instances' HBM bytes and matrix-busy cycles from the same passes
+            rows_pm = {}
+            for k, d in pm.items():
+                if "dit_rows_kernel" in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+                    kk = k.replace(" ", "")
+                    inst = next((i for i in ("<false,true>", "<true,true>", "<true,false>") if i in kk or
+                                 {"<false,true>": "ILb0ELb1E", "<true,true>": "ILb1ELb1E", "<true,false>": "ILb1ELb0E"}[i] in kk), kk[:40])
+                    rows_pm[inst] = {"traffic": (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024,
+                                     "mfma_busy_cycles_per_dispatch": d.get("SQ_VALU_MFMA_BUSY_CYCLES")}
+            out["roofline_rows"]["pmc"] = {"instances": rows_pm, "measured_by_this_run": True}
         out["kernel_breakdown_us"] = {"attention_x4": kt["attn_us"], "row_chain_x5": kt["rows_us"],
                                       "other_x1_adaln": kt["other_us"], "forward_total": kt["forward_us"]}
         # whole-step figure for context: all DiT FLOPs / wall time
