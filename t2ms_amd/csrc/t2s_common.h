@@ -39,6 +39,25 @@ void set_error(const char* fmt, ...);
         }                                                                                      \
     } while (0)
 
+// The C ABI carries pointers without sizes.  Where the library reads a KNOWN number of bytes behind a caller's pointer
+// (weights at create / update), it first asks HIP for the extent of the allocation the pointer lies in: a buffer that ends
+// before those bytes do is T2S_E_INVALID with `what` in the message, never an out-of-bounds read (round 4's fault).  A pointer
+// HIP cannot place (not from hipMalloc) is passed through: nothing known, nothing refused.
+inline int check_device_extent(const void* p, size_t bytes, const char* what) {
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) != hipSuccess) {
+        (void)hipGetLastError();
+        return T2S_OK;
+    }
+    const size_t left = (size_t)((const char*)base + size - (const char*)p);
+    if (left < bytes) {
+        set_error("%s needs %zu bytes but its device allocation ends after %zu", what, bytes, left);
+        return T2S_E_INVALID;
+    }
+    return T2S_OK;
+}
+
 constexpr int D = T2S_D_MODEL;      // 128
 constexpr int NTOK = T2S_N_TOK;     // 480
 constexpr int NH = T2S_N_HEADS;     // 4

@@ -269,15 +269,10 @@ int check_weights(const t2s_dit_weights* w, const uint64_t* n_floats, bool range
         T2S_REQUIRE(!n_floats || n_floats[i] >= need.floats, "t2s_dit weights: %s holds %llu floats, the kernels read %zu", name,
                     (unsigned long long)n_floats[i], need.floats);
         if (ranges) {
-            hipDeviceptr_t base = nullptr;
-            size_t size = 0;
-            if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptrs[i]) != hipSuccess) {
-                (void)hipGetLastError();
-                continue;
-            }
-            const size_t left = (size_t)((const char*)base + size - (const char*)ptrs[i]);
-            T2S_REQUIRE(left >= need.floats * sizeof(float), "t2s_dit weights: %s needs %zu bytes but its device allocation ends after %zu",
-                        name, need.floats * sizeof(float), left);
+            char what[128];
+            snprintf(what, sizeof(what), "t2s_dit weights: %s", name);
+            const int rc = check_device_extent(ptrs[i], need.floats * sizeof(float), what);
+            if (rc != T2S_OK) return rc;
         }
     }
     return T2S_OK;

@@ -593,6 +593,13 @@ extern "C" int t2s_vae_create(const t2s_vae_weights* w, t2s_vae** out) {
             return rc_items;
         }
     }
+    for (auto& it : items) {      // sizes follow from hidden / res_hidden / emb: a tensor of another shape is an error code
+        const int rc_e = it.src ? check_device_extent(it.src, it.n * sizeof(float), "t2s_vae_create: a weight tensor (hyper-parameters vs tensor sizes)") : T2S_OK;
+        if (rc_e != T2S_OK) {
+            delete h;
+            return rc_e;
+        }
+    }
     size_t total = 0;
     for (auto& it : items) total += r64(it.n);
     hipError_t e = hipMalloc(&h->arena, total * sizeof(float));
@@ -650,6 +657,8 @@ extern "C" int t2s_vae_update_weights(t2s_vae* h, const t2s_vae_weights* w, void
     if (rc != T2S_OK) return rc;
     for (auto& it : items) {
         T2S_REQUIRE(it.src, "t2s_vae_update_weights: NULL weight pointer");
+        const int rc_e = check_device_extent(it.src, it.n * sizeof(float), "t2s_vae_update_weights: a weight tensor");
+        if (rc_e != T2S_OK) return rc_e;
         T2S_HIP_CHECK(hipMemcpyAsync(const_cast<float*>(*it.dst), it.src, it.n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     }
     return T2S_OK;

@@ -77,6 +77,38 @@ def test_undersized_weight_is_an_error_code_not_a_fault(dev):
         assert float((m(input=x, t=t, text_input=None).cpu() - O.dit_forward(synth.make_dit_state_dict(31337, gain=0.7), x.cpu(), t.cpu(), None)).abs().max()) < 1e-4
 
 
+def test_vae_weights_extent_is_checked_too(dev):
+    """t2s_vae_create / _update_weights derive every tensor's size from the hyper-parameters in the struct: a tensor whose
+    device allocation ends before that many floats is T2S_E_INVALID, not an out-of-bounds copy."""
+    import types
+    from model.pretrained.vqvae import vqvae
+    v = vqvae(types.SimpleNamespace(block_hidden_size=128, num_residual_layers=2, res_hidden_size=256, embedding_dim=64)).to(dev)
+    w, keep = v.encoder._weights_struct()
+    lib = L.lib()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes, hip.hipFree.argtypes = [C.POINTER(C.c_void_p), C.c_size_t], [C.c_void_p]
+    small = C.c_void_p()
+    assert hip.hipMalloc(C.byref(small), 1024) == 0
+    try:
+        good = C.c_void_p()
+        assert lib.t2s_vae_create(C.byref(w), C.byref(good)) == 0
+        w2 = L.VaeWeights.from_buffer_copy(w)
+        w2.enc_conv3_w = small.value                      # (128,128,3) floats expected
+        out = C.c_void_p()
+        assert lib.t2s_vae_create(C.byref(w2), C.byref(out)) == -1 and not out.value
+        assert "allocation ends" in lib.t2s_last_error().decode()
+        assert lib.t2s_vae_update_weights(good, C.byref(w2), None) == -1
+        w3 = L.VaeWeights.from_buffer_copy(w)
+        w3.hidden = 64                                    # hyper-parameters that are not the handle's
+        assert lib.t2s_vae_update_weights(good, C.byref(w3), None) == -1
+        assert lib.t2s_vae_update_weights(good, C.byref(w), None) == 0
+        lib.t2s_vae_destroy(good)
+    finally:
+        torch.cuda.synchronize()
+        hip.hipFree(small)
+    del keep
+
+
 def test_mirror_refuses_an_undersized_parameter(dev):
     """The mirror hands every parameter's numel() over with the pointers: a parameter re-assigned to a smaller tensor is a
     T2SError with its state-dict key, before anything is packed."""
