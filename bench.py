@@ -326,6 +326,10 @@ def train_leg(dev, dist, rank, world, batch=1152, length=96, steps=30, warmup=4,
                            "mfma_frac": tflops / PEAK_BF16_MFMA_TFLOPS,
                            "traffic_source": {"file": "profiles/train_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                                       "passes of tools/bench_train.py)", "measured_by_this_run": False},
+                           "traffic_note": "FETCH_SIZE counts Infinity-Cache hits (MI355X_MICROARCH.md, HBM): the forward's re-reads "
+                                           "of what the previous launch just wrote are such hits -- removing all 21 u of them changes the "
+                                           "step by +0.16 % (profiles/r05_chain_bound_ab.txt), so bytes_vs_minimal overstates what "
+                                           "byte-cutting can buy; DESIGN.md 4.3 'structural floor'",
                            "timing": f"sum of HIP-event launch durations over {n_t} eager steps = {kernel_ms:.2f} ms/step"}
     return out
 
