@@ -11,7 +11,8 @@ mkdir -p $out
 git_rev=$(cat .git_rev 2>/dev/null || echo unknown)
 echo "== bench"; timeout -k 10 600 python bench.py --gpus 1 --steps 3 --warmup 1 > $out/${tag}_bench.json 2> $out/${tag}_bench.err || exit 1
 tail -c 400 $out/${tag}_bench.json; echo
-S="--gpus 1 --steps 1 --warmup 1 --no-cpu-baseline --no-alt-math --no-train --no-strong --no-legs"
+# (--no-pmc: a profiled bench must not start profiler children of its own; --no-configs: the profile is of the headline shape)
+S="--gpus 1 --steps 1 --warmup 1 --no-cpu-baseline --no-alt-math --no-train --no-strong --no-legs --no-configs --no-pmc"
 echo "== rocprofv3 --kernel-trace --stats (sampling only, 1+1 batches; two sampler lanes = the default)"
 rm -rf /tmp/prof_$tag
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python3 bench.py $S > $out/${tag}_prof_bench.json 2> $out/${tag}_prof.err || exit 1

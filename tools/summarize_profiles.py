@@ -94,11 +94,44 @@ if mfma_busy:
 rows_busy = [(k, v) for (k, c), v in sq.items() if c == "SQ_VALU_MFMA_BUSY_CYCLES" and "dit_rows" in k]
 if rows_busy:
     lines += ["Row-chain kernels, same pass: " + "; ".join(f"`{k[:60]}` {v[1]:,.0f} busy cycles / dispatch" for k, v in rows_busy), ""]
+rr = b.get("roofline_rows")
+if rr:
+    lines += ["Row chain against the fp32 MFMA peak (`roofline_rows`, same in-situ timing): " +
+              "; ".join(f"`{k.split(' ')[0]}` {v['avg_launch_us']:.1f} us = {v['achieved']:.1f} TFLOP/s = **{v['frac']:.3f}**" for k, v in rr["instances"].items()) +
+              f"; all five launches of a forward: {rr['achieved']:.1f} TFLOP/s = **{rr['frac']:.3f}**.", ""]
+    if rr.get("pmc"):
+        lines += ["Their HBM bytes per launch, measured by the bench run itself (child `rocprofv3 --pmc` passes): " +
+                  "; ".join(f"`{k}` {v['traffic'] / 1e6:.0f} MB" for k, v in rr["pmc"]["instances"].items()) + ".", ""]
+pm_ = (rf.get("pmc") or {})
+if pm_.get("measured_by_this_run"):
+    lines += [f"The bench run's OWN PMC passes (`roofline.pmc.measured_by_this_run`): attention {rf['traffic'] / 1e6:.1f} MB per launch, matrix pipe busy "
+              f"{pm_['mfma_busy_frac']:.3f}.", ""]
+for key, title in (("config3", "BASELINE configs[2] under the bench clock"), ("config5", "BASELINE configs[4] under the bench clock")):
+    c = b.get(key)
+    if c and "value" in c:
+        lines += [f"## {title} (`{key}`)", f"{c['metric']}: **{c['value']:.1f} series/s**, whole path {c['whole_path_tflops']:.1f} TFLOP/s = "
+                  f"{c['whole_path_frac_of_fp32_mfma_peak']:.3f} of the fp32 MFMA peak." +
+                  ("  Per length: " + ", ".join(f"L={L_} {v['series_per_s']:.1f}" for L_, v in c["lengths"].items()) + " series/s." if "lengths" in c else ""), ""]
 if am:
-    lines += ["## Opt-in bf16x3 arithmetic (include/t2s.h T2S_MATH_BF16X3; DESIGN.md 4.4) -- not the headline",
+    lines += ["## bf16x3 arithmetic (include/t2s.h T2S_MATH_BF16X3; DESIGN.md 4.4): the drivers' default, not the bench headline",
               f"`bench.py` reports it as `alt_math`: **{am['value']:.1f} series/s** ({am['ms_per_step']:.0f} ms per batch); attention "
               f"{am['attention_us']:.0f} us alone on the chip, row chain {am['row_chain_us']:.0f} us average.  rocprofv3 kernel stats of "
               f"`bench.py --math bf16x3 --diffusion-steps 50` (`{tag}_x3_kernel_stats.csv`):", "", table(stats("x3_kernel_stats"), 6), ""]
+    if am.get("roofline"):
+        r3 = am["roofline"]
+        lines += [f"Its own roofline (dense bf16 peak / 6 = {r3['peak']:.0f} algorithmic TFLOP/s: an fp32-accurate product is six bf16 MFMAs): attention "
+                  f"{r3['achieved']:.1f} = **{r3['frac']:.3f}**, whole path {r3['whole_path_tflops']:.1f} = {r3['whole_path_frac']:.3f}.", ""]
+    if am.get("accuracy_vs_fp64") and "bf16x3" in am["accuracy_vs_fp64"]:
+        a = am["accuracy_vs_fp64"]
+        lines += ["In-run accuracy block (one conditional forward, B = 32, against the fp64 arithmetic of the oracle), rms / max: " +
+                  ", ".join(f"{k} {a[k]['rms']:.3e} / {a[k]['max_abs']:.3e}" for k in ("cpu_fp32_oracle", "f32_mfma", "bf16x3")) +
+                  f"; bf16x3 / oracle = {a['bf16x3_over_oracle']['rms']:.3f} (rms), {a['bf16x3_over_oracle']['max_abs']:.3f} (max).", ""]
+    if am.get("strong_shards"):
+        s3 = am["strong_shards"]
+        lines += ["Strong-scaling shards in this arithmetic (series/s on 128 / 64 / 32 series): " +
+                  " / ".join(f"{s3['shards'][n]['series_per_s']:.1f}" for n in ("128", "64", "32")) +
+                  "; predicted efficiency at 2 / 4 / 8 GPUs " + " / ".join(f"{s3['predicted_strong_efficiency'][w]:.3f}" for w in ("2", "4", "8")) +
+                  " (no 16-token row kernel in this arithmetic: a bf16 MFMA's internal summation cannot be made bit-identical across tile shapes).", ""]
 
 # ---- training
 tb_path = os.path.join(P, f"{tag}_train_bench.json")
