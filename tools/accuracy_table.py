@@ -111,7 +111,15 @@ def host_tables():
     that made the references and the box that runs the GPU columns is an INPUT difference of ~1e-7 relative -- it showed up as
     a uniform 4x error of both GPU columns when the two stages first ran on different machines.  Stage cpu records them,
     stage gpu feeds exactly these to the kernels (and reports how far its own host values are from them)."""
-    return {"pos_embed": synth.make_dit_state_dict(2025)["pos_embed"].numpy(), "time_freqs": O.time_freqs().numpy()}
+    from t2ms_amd.model.backbone.DDPM import ddpm_host_tables
+    out = {"pos_embed": synth.make_dit_state_dict(2025)["pos_embed"].numpy(), "time_freqs": O.time_freqs().numpy()}
+    # the DDPM schedule and the per-step coefficients the kernels read (DDPM.py:14-18,30-36: torch.linspace / cumprod / pow
+    # on the host): an ulp of difference in a coefficient is a multiplicative perturbation of the state at that step, and over
+    # 1000 steps of a state that grows to 1.5e3 it showed up as 4 x the error of BOTH GPU arithmetics at the late taps
+    for T in (20, 1000):
+        for k, v in ddpm_host_tables(T).items():
+            out[f"ddpm_{T}_{k}"] = v.numpy()
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ stage cpu
@@ -188,6 +196,20 @@ def err(x, ref):
 HOST = {}
 
 
+def use_reference_box_schedule():
+    """Make the mirrors' DDPM (class API) and the fused Sampler read the reference box's schedule tables."""
+    import t2ms_amd.model.backbone.DDPM as D
+    import t2ms_amd.sampler as S
+    real = D.ddpm_host_tables
+
+    def tables(total_steps):
+        if f"ddpm_{total_steps}_coef" not in HOST:
+            return real(total_steps)
+        return {k: torch.from_numpy(HOST[f"ddpm_{total_steps}_{k}"]) for k in ("beta", "alpha", "alpha_bar", "coef", "sqrt_ab", "sqrt_1mab")}
+    D.ddpm_host_tables = tables
+    S.ddpm_host_tables = tables
+
+
 def gpu_model(sd, dev, math):
     import t2ms_amd.model.denoiser.transformer as T       # (model.denoiser.transformer is an alias package of this module)
     sd = dict(sd)
@@ -217,8 +239,10 @@ def stage_gpu(args):
         HOST.update({k: v for k, v in np.load(ref_path("host_tables", args.small)).items()})
         mine = host_tables()
         host_diff = {k: {"max_abs_diff": float(np.abs(mine[k].astype(np.float64) - HOST[k]).max()),
-                         "elements_differing": int((mine[k] != HOST[k]).sum())} for k in HOST}
-        print("host-evaluated tables, this box vs the reference box:", host_diff, flush=True)
+                         "max_rel_diff": float((np.abs(mine[k].astype(np.float64) - HOST[k]) / np.maximum(np.abs(HOST[k]), 1e-30)).max()),
+                         "elements_differing": int((mine[k] != HOST[k]).sum()), "elements": int(HOST[k].size)} for k in HOST if k in mine}
+        print("host-evaluated tables, this box vs the reference box:", {k: v for k, v in host_diff.items() if v["elements_differing"]}, flush=True)
+        use_reference_box_schedule()
 
     def record(case, ref, f32, x3, cpu32):
         cat = lambda xs: np.concatenate([np.asarray(x, dtype=np.float64).reshape(-1) for x in xs])   # noqa: E731  (pooled over seeds)
