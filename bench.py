@@ -632,13 +632,14 @@ def alt_math_run(model, vae, args, dev, text):
                          "whole_path_tflops": whole, "whole_path_frac": whole / (PEAK_BF16_MFMA_TFLOPS / 6)}}
 
 
-def config3_leg(dev, batch=1024, steps=100, cfg=5.0, length=96, timed=2):
+def config3_leg(dev, batch=1024, steps=100, cfg=5.0, length=96, timed=2, math="f32"):
     """BASELINE configs[2] under this clock: rectified flow, B = 1024, 100 steps (infer.py:135 default), cfg 5 (the traffic
     rows of scripts/script.sh:31-33), the WHOLE loop of each lane in one hipGraph: one warm (capturing) batch + `timed` batches."""
     from t2ms_amd import synth
     from t2ms_amd.sampler import Sampler
     model, vae = build_models(dev)            # its own handle (2048 sequences): the headline's samplers keep theirs
-    s = Sampler(model, vae.decoder, "flowmatching", steps, cfg, batch, length, dev, use_graph=True, seed=2025, row0=0, loop_graph=1)
+    s = Sampler(model, vae.decoder, "flowmatching", steps, cfg, batch, length, dev, use_graph=True, seed=2025, row0=0, loop_graph=1,
+                math=math)
     s.run(synth.make_text_embeddings(2025, batch).to(dev), decode=True)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -651,7 +652,7 @@ def config3_leg(dev, batch=1024, steps=100, cfg=5.0, length=96, timed=2):
     return {"metric": f"generated series/sec (configs[2]: B={batch}, L={length}, {steps}-step rectified flow, cfg {cfg}, whole loop in one hipGraph per lane)",
             "value": batch * timed / el, "unit": "series/s", "ms_per_batch": el / timed * 1e3, "batches_timed": timed,
             "graph_lanes": s.graph_lanes, "whole_path_tflops": tflops, "whole_path_frac_of_fp32_mfma_peak": tflops / PEAK_FP32_MFMA_TFLOPS,
-            "dtype": "f32", "data": "synthetic"}
+            "dtype": "f32", "math": math, "data": "synthetic"}
 
 
 def config5_leg(dev, model, vae, sampler96, text, batch=256, steps=1000, cfg=9.0):
@@ -1035,6 +1036,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline(B, args.diffusion_steps, args.cfg_scale, args.length)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
             if "alt_math" in out:
+                if not args.no_configs:
+                    try:      # BASELINE configs[2] in the drivers' default arithmetic
+                        c3 = config3_leg(dev, math="bf16x3")
+                        out["alt_math"]["config3"] = {k: c3[k] for k in ("metric", "value", "unit", "ms_per_batch", "math")}
+                    except Exception as e:
+                        out["alt_math"]["config3"] = {"error": f"{type(e).__name__}: {e}"}
                 try:
                     out["alt_math"]["accuracy_vs_fp64"] = accuracy_vs_fp64(dev)
                 except Exception as e:

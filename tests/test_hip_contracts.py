@@ -281,3 +281,44 @@ def test_env_opt_out_and_math_switch_between_the_pair(dev, monkeypatch):
             assert m.__dict__["_t2s_pair"]["stash"] is None and not m.__dict__["_t2s_pair"]["armed"]
             c = m(input=x, t=t, text_input=emb)
         assert torch.equal(u, fresh(input=x, t=t, text_input=None)) and torch.equal(c, fresh(input=x, t=t, text_input=emb))
+
+
+# ------------------------------------------------------------------------------------------------ the shipped default arithmetic
+def test_infer_driver_at_its_shipped_default_math(dev, tmp_path, monkeypatch):
+    """The suite pins T2S_DEFAULT_MATH=f32 (tests/conftest.py) so the headline kernels stay covered; THIS test removes the pin
+    and runs infer.py exactly as a user gets it: the run reports bf16x3 (round 5: the drivers' default, profiles/r05_accuracy.md),
+    its four files equal the oracle's restatement of infer.py:65-123 within the same 1e-4 as the f32 run, and `--math f32` on the
+    same rows gives the exact-MFMA bits of the pinned suite (both arithmetics fp32-accurate: the two runs differ by < 1e-4)."""
+    import os
+    import infer as drv
+    from datafactory.dataset import SyntheticT2SDataset
+    monkeypatch.delenv("T2S_DEFAULT_MATH", raising=False)
+    monkeypatch.chdir(tmp_path)
+    seed, L_, n_ds, bs, steps, cfg = 21, 48, 11, 2, 6, 9.0
+    outs = {}
+    for tag, extra in (("default", []), ("f32", ["--math", "f32"])):
+        save = str(tmp_path / tag)
+        a = drv.main(["--dataset_name", f"ETTh1_{L_}", "--backbone", "ddpm", "--denoiser", "DiT", "--total_step", str(steps), "--cfg_scale",
+                      str(cfg), "--batch_size", str(bs), "--save_path", save, "--synthetic", str(n_ds), "--random_init", "--seed", str(seed),
+                      "--no_figs"] + extra)
+        assert a.math == ("bf16x3" if tag == "default" else "f32")
+        out = os.path.join(save, "generation", f"ddpm_DiT_ETTh1_{L_}_{cfg}_{steps}")
+        outs[tag] = {f: np.load(os.path.join(out, f + ".npy")) for f in ("x_1", "x_t", "x_t_latent_dec_array", "x_t_latent_enc_array")}
+    x1 = outs["default"]["x_1"][:, :, 0]
+    n = (n_ds // bs) * bs
+    ds = SyntheticT2SDataset(n_ds, L_)
+    rows = [int(np.argmin(np.abs(ds.samples - x1[i][None]).sum(axis=1))) for i in range(n)]
+    text = torch.from_numpy(ds.embedding[rows]).float()
+    sd, vsd = synth.make_dit_state_dict(seed), synth.make_vae_state_dict(seed)
+    with torch.no_grad():
+        x_T = torch.from_numpy(O.device_normal(seed, 0xFFFFFFFF, 0, n)).view(n, 64, 30)
+        noises = [torch.from_numpy(O.device_normal(seed, j, 0, n)).view(n, 64, 30) for j in range(steps)]
+        ref = O.sample_ddpm(sd, x_T, text, steps, cfg, noises)
+        series, _ = O.vae_decode(vsd, ref, L_)
+    scale = max(1.0, float(ref.abs().max()))
+    for tag in ("default", "f32"):
+        assert np.array_equal(outs[tag]["x_1"], outs["default"]["x_1"])                      # the same rows in the same order
+        assert float(np.abs(outs[tag]["x_t_latent_dec_array"] - ref.numpy()).max()) < 1e-4 * scale, tag
+        assert float(np.abs(outs[tag]["x_t"][:, :, 0] - series.reshape(n, L_).numpy()).max()) < 1e-4 * scale, tag
+    assert not np.array_equal(outs["default"]["x_t_latent_dec_array"], outs["f32"]["x_t_latent_dec_array"])   # two arithmetics...
+    assert float(np.abs(outs["default"]["x_t_latent_dec_array"] - outs["f32"]["x_t_latent_dec_array"]).max()) < 1e-4 * scale   # ...one accuracy
