@@ -1,7 +1,8 @@
 // The row-local chain of a DiT block (t2s_rows.h) in "bf16x3" arithmetic (t2s_x3.h): the same
 // register-resident chain, chunk order and LDS-DMA weight ring, with every fp32 product evaluated
 // as six bf16 MFMAs (fp32-accurate) -- 48 v_mfma_f32_32x32x16_bf16 per chunk instead of 64
-// v_mfma_f32_32x32x2_f32 at half the cycles each.  Opt-in (T2S_MATH_BF16X3), not the headline path.
+// v_mfma_f32_32x32x2_f32 at half the cycles each.  T2S_MATH_BF16X3: what infer.py / Sampler select by default since round 5
+// (the bench headline stays on the f32 kernels).
 //
 // Operand flow.  The 32x32 fp32 accumulator layout (lane = token, registers = features) is still the
 // next product's B operand: registers 8s..8s+7 of feature tile nt are k-step 2nt+s, split into three
@@ -24,6 +25,27 @@ namespace t2s {
 // waves of a SIMD are arbitrated by priority, then age, and a partner in an MFMA section needs the issue
 // port for only 8 of every 32 cycles (measured: 375 -> 364 us average per launch).
 #define X3_PRIO(p) __builtin_amdgcn_s_setprio(p);
+
+// -DT2S_X3_STAMP (tools/x3_stamp.sh; diagnosis only): every wave attributes the s_memtime cycles between consecutive stamps to a
+// category -- 0 prologue (first loads / operand split until chunk 0 has landed), 1 MFMA groups, 2 VALU sections (LayerNorm,
+// GELU, splits, gate / residual), 3 `s_waitcnt vmcnt(0)` in front of a chunk barrier, 4 the barrier itself, 5 issuing global
+// loads / stores and LDS-DMA, 6 epilogue -- and the first workgroups write their sums to RowArgsX3::stamp.
+#ifdef T2S_X3_STAMP
+__device__ __forceinline__ unsigned long long x3_clk() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define X3_STAMP_DECL unsigned long long st_last = x3_clk(), st_acc[7] = {0, 0, 0, 0, 0, 0, 0}; const unsigned long long st_t0 = st_last;
+#define X3_STAMP(k) { const unsigned long long n_ = x3_clk(); st_acc[k] += n_ - st_last; st_last = n_; }
+#define X3_SYNC() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); X3_STAMP(3) __builtin_amdgcn_s_barrier(); X3_STAMP(4) }
+#else
+#define X3_STAMP_DECL
+#define X3_STAMP(k)
+#define X3_SYNC() wg_sync();
+#endif
 constexpr int X3_CHUNK_UNITS = 24 * 64;                    // 16-byte units per chunk (24 KiB)
 constexpr int ROWS_X3_LDS_BYTES = 2 * X3_CHUNK_UNITS * 16 + (ROWS_CB_FLOATS + 4 * ROWS_CM_FLOATS) * 4;
 
@@ -47,6 +69,9 @@ struct RowArgsX3 {
     const float *bp, *b1, *b2, *bq;
     float* q;          // q fragment-major fp32 (the attention scales and splits it once per head)
     __bf16 *k3, *v3;   // k, V^T split planes (t2s_x3.h)
+#ifdef T2S_X3_STAMP
+    unsigned long long* stamp;   // [workgroup < 256][wave][8]: 7 category sums + total
+#endif
 };
 
 // fp32 packed weights (packed_index order, or the fc2 chunk order of pack_weight_kernel mode 1) ->
@@ -133,6 +158,20 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
                                              (__attribute__((address_space(3))) void*)(dst + (wave + 4 * p) * 64), 16, 0, 0);
     };
 
+    X3_STAMP_DECL
+    // The next chunk's six LDS-DMA pieces are issued BETWEEN the k-steps of the current chunk's MFMA group, one per k-step:
+    // an LDS-DMA instruction costs ~100 issue cycles in an MFMA gap against ~150 in front of the group, where nothing covers
+    // the wave's vector-memory issue (-DT2S_X3_STAMP put 14 % of a wave's cycles into the six-instruction burst; spread out
+    // they cost 10 %: rows -1.0 %, sampler +0.7 % in a same-box A/B, profiles/r05_x3_dma_mix_ab.txt).  Untracked inline asm
+    // (glds16_asm) so hipcc keeps its counted lgkmcnt waits for the fragment reads: every chunk therefore ends with an
+    // explicit vmcnt wait in front of its barrier.
+    auto fill_piece = [&](int ci, int p) T2S_X3_KERNEL {
+        const bf16x8* src = chunk_src(ci) + lane + (wave + 4 * p) * 64;
+        bf16x8* dst = wring3 + (ci & 1) * X3_CHUNK_UNITS + (wave + 4 * p) * 64;
+        glds16_asm(reinterpret_cast<const f32x4*>(src), reinterpret_cast<f32x4*>(dst));
+    };
+#define X3_FILL_MIX(ci, step) if ((step) >= 1 && (step) <= 6) fill_piece(ci, (step) - 1);
+#define X3_DMA_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     fill(0);
 
     // ---- per-feature constants in LDS (visible after the first barrier), as in t2s_rows.h ----
@@ -182,16 +221,21 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
                 const f32x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 aop[ks] = split3(v);
             }
-            wg_sync();  // chunk 0 landed (vmcnt(0) + barrier)
+            X3_STAMP(0)
+            X3_SYNC()  // chunk 0 landed (vmcnt(0) + barrier)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                fill(ci + 1);
+                X3_STAMP(5)
                 const bf16x8* wb = wring3 + (ci & 1) * X3_CHUNK_UNITS + lane;
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) acc = mfma_x3(ldw3(wb, ks), aop[ks], acc);
+                for (int ks = 0; ks < 8; ++ks) {
+                    acc = mfma_x3(ldw3(wb, ks), aop[ks], acc);
+                    X3_FILL_MIX(ci + 1, ks)
+                }
+                X3_STAMP(1)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 bias = ldc4(c_bp, nt, g, half);
@@ -199,7 +243,9 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[nt][4 * g + e] += gate[e] * (acc[4 * g + e] + bias[e]);
                 }
-                wg_sync();
+                X3_STAMP(2)
+                X3_DMA_LANDED()
+                X3_SYNC()
                 ++ci;
             }
         }
@@ -214,6 +260,7 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) xmp[ks] = split3_acc(xm[ks >> 1], ks & 1);
             }
+            X3_STAMP(2)
             // park the post-attention residual in HBM for the MLP loop (t2s_rows.h)
             if (active) {
 #pragma unroll
@@ -230,16 +277,21 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
             X3_PRIO(0)
+            X3_STAMP(5)
 #pragma unroll 1
             for (int c = 0; c < 8; ++c) {  // 32 hidden units per chunk; ci = 4 + 2c (even) here
-                fill(ci + 1);
+                X3_STAMP(5)
                 f32x16 hT;
                 {
                     const bf16x8* wb = wring3 + lane;  // ci even -> ring slot 0
 #pragma unroll
                     for (int r = 0; r < 16; ++r) hT[r] = 0.f;
 #pragma unroll
-                    for (int ks = 0; ks < 8; ++ks) hT = mfma_x3(ldw3(wb, ks), xmp[ks], hT);
+                    for (int ks = 0; ks < 8; ++ks) {
+                        hT = mfma_x3(ldw3(wb, ks), xmp[ks], hT);
+                        X3_FILL_MIX(ci + 1, ks)
+                    }
+                    X3_STAMP(1)
                     X3_PRIO(2)   // GELU + split: let this wave's VALU win the issue arbitration over the partner's MFMA stream
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -248,20 +300,27 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
                         for (int e = 0; e < 4; ++e) hT[4 * g + e] = gelu_tanh_f(hT[4 * g + e] + bias[e]);
                     }
                 }
-                wg_sync();
+                X3_STAMP(2)
+                X3_DMA_LANDED()
+                X3_SYNC()
                 ++ci;
-                if (ci + 1 < N_CHUNKS) fill(ci + 1);
+                X3_STAMP(5)
                 {   // fc2 partial over the 32 hidden units of this chunk: pieces (nt, s)
                     const bf16x8* wb = wring3 + X3_CHUNK_UNITS + lane;  // ci odd -> ring slot 1
                     const Split3 h0 = split3_acc(hT, 0), h1 = split3_acc(hT, 1);
                     X3_PRIO(0)
+                    X3_STAMP(2)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
                         acc[nt] = mfma_x3(ldw3(wb, nt * 2 + 0), h0, acc[nt]);
+                        if (ci + 1 < N_CHUNKS) { X3_FILL_MIX(ci + 1, 2 * nt) }
                         acc[nt] = mfma_x3(ldw3(wb, nt * 2 + 1), h1, acc[nt]);
+                        if (ci + 1 < N_CHUNKS) { X3_FILL_MIX(ci + 1, 2 * nt + 1) }
                     }
+                    X3_STAMP(1)
                 }
-                wg_sync();
+                X3_DMA_LANDED()
+                X3_SYNC()
                 ++ci;
             }
 #pragma unroll
@@ -279,9 +338,11 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
                     }
                     if (active && (DO_QKV || a.out0 == nullptr || a.keep_x)) xw[(nt * 4 + g) * 64] = t;   // final residual stream of this block
                 }
+            X3_STAMP(2)
         }
     } else {
-        wg_sync();  // chunk 0 landed
+        X3_STAMP(0)
+        X3_SYNC()  // chunk 0 landed
     }
 
     // ---- fused final layer of the LAST block (transformer.py:182-191): affine LayerNorm (eps 1e-5),
@@ -351,9 +412,10 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
         }
         const int tile_in_seq = tile - seq * (NTOK / 32);
         X3_PRIO(0)
+        X3_STAMP(2)
 #pragma unroll 1
         for (int t = 0; t < 12; ++t) {  // output tile t = which*4 + head
-            if (ci + 1 < N_CHUNKS) fill(ci + 1);
+            X3_STAMP(5)
             const bf16x8* wb = wring3 + (ci & 1) * X3_CHUNK_UNITS + lane;
             const int which = t >> 2, head = t & 3;
             const size_t head_tile = ((size_t)seq * NH + head) * (NTOK / 32) + tile_in_seq;
@@ -363,7 +425,11 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
             if (which < 2) {
                 // q / k tile, transposed product: lane = token, registers = features d
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) acc = mfma_x3(ldw3(wb, ks), xmp[ks], acc);
+                for (int ks = 0; ks < 8; ++ks) {
+                    acc = mfma_x3(ldw3(wb, ks), xmp[ks], acc);
+                    if (ci + 1 < N_CHUNKS) { X3_FILL_MIX(ci + 1, ks) }
+                }
+                X3_STAMP(1)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 bias = *reinterpret_cast<const f32x4*>(c_bq + 32 * t + 8 * g + 4 * half);
@@ -393,7 +459,11 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
                 // v tile with the MFMA operands swapped: lane = feature d, registers = keys
                 const float bias = c_bq[32 * t + (lane & 31)];
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) acc = mfma_x3(xmp[ks], ldw3(wb, ks), acc);
+                for (int ks = 0; ks < 8; ++ks) {
+                    acc = mfma_x3(xmp[ks], ldw3(wb, ks), acc);
+                    if (ci + 1 < N_CHUNKS) { X3_FILL_MIX(ci + 1, ks) }
+                }
+                X3_STAMP(1)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] += bias;
                 if (active) {
@@ -409,16 +479,27 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
             }
             // counted wait + raw barrier: the next chunk's 6 DMA pieces must have landed; the q (4) or
             // k / v plane (6) stores issued after them stay in flight.  Tail waves store nothing.
+            X3_STAMP(2)
             if (!active)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (which >= 1)
                 asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else
                 asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            X3_STAMP(3)
             __builtin_amdgcn_s_barrier();
+            X3_STAMP(4)
             ++ci;
         }
     }
+#ifdef T2S_X3_STAMP
+    X3_STAMP(6)
+    if (a.stamp != nullptr && blockIdx.x < 256 && lane == 0) {
+        unsigned long long* d = a.stamp + ((size_t)blockIdx.x * 4 + wave) * 8;
+        for (int k = 0; k < 7; ++k) d[k] = st_acc[k];
+        d[7] = st_last - st_t0;
+    }
+#endif
 }
 
 template <bool DO_MLP, bool DO_QKV>
@@ -435,9 +516,35 @@ inline int launch_dit_rows_x3(const RowArgsX3& a, hipStream_t st) {
         return T2S_E_INVALID;
     }
     const int tiles = a.M / 32;
+#ifdef T2S_X3_STAMP
+    static unsigned long long* buf = nullptr;
+    static int calls = 0;
+    if (!buf) {
+        T2S_HIP_CHECK(hipMalloc((void**)&buf, 256 * 4 * 8 * sizeof(unsigned long long)));
+        T2S_HIP_CHECK(hipMemset(buf, 0, 256 * 4 * 8 * sizeof(unsigned long long)));
+    }
+    RowArgsX3 a2 = a;
+    a2.stamp = buf;
+    dit_rows_x3_kernel<DO_MLP, DO_QKV><<<(tiles + 3) / 4, 256, ROWS_X3_LDS_BYTES, st>>>(a2);
+    T2S_LAUNCH_CHECK();
+    if (++calls == 40 && tiles >= 4096) {      // one dump per instance, well after warm-up, at a chip-filling launch
+        static unsigned long long host[256 * 4 * 8];
+        T2S_HIP_CHECK(hipStreamSynchronize(st));
+        T2S_HIP_CHECK(hipMemcpy(host, buf, sizeof(host), hipMemcpyDeviceToHost));
+        double sum[8] = {};
+        const int n = (tiles + 3) / 4 < 256 ? (tiles + 3) / 4 : 256;
+        for (int i = 0; i < n * 4; ++i)
+            for (int k = 0; k < 8; ++k) sum[k] += (double)host[i * 8 + k];
+        fprintf(stderr, "x3_stamp <%d,%d> tiles %d: cycles per wave (s_memtime, 100 MHz ticks x? see tools/x3_stamp.sh) total %.0f | prologue %.0f mfma %.0f valu %.0f "
+                        "vmcnt %.0f barrier %.0f issue %.0f epilogue %.0f\n", (int)DO_MLP, (int)DO_QKV, tiles, sum[7] / (n * 4), sum[0] / (n * 4),
+                sum[1] / (n * 4), sum[2] / (n * 4), sum[3] / (n * 4), sum[4] / (n * 4), sum[5] / (n * 4), sum[6] / (n * 4));
+    }
+    return T2S_OK;
+#else
     dit_rows_x3_kernel<DO_MLP, DO_QKV><<<(tiles + 3) / 4, 256, ROWS_X3_LDS_BYTES, st>>>(a);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
+#endif
 }
 
 }  // namespace t2s
