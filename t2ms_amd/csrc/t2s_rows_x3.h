@@ -24,7 +24,11 @@ namespace t2s {
 // Raise the wave's issue priority for its VALU-heavy sections (LayerNorm, GELU, operand splits): the two
 // waves of a SIMD are arbitrated by priority, then age, and a partner in an MFMA section needs the issue
 // port for only 8 of every 32 cycles (measured: 375 -> 364 us average per launch).
+#ifndef T2S_X3_NO_PRIO
 #define X3_PRIO(p) __builtin_amdgcn_s_setprio(p);
+#else
+#define X3_PRIO(p)
+#endif
 
 // -DT2S_X3_STAMP (tools/x3_stamp.sh; diagnosis only): every wave attributes the s_memtime cycles between consecutive stamps to a
 // category -- 0 prologue (first loads / operand split until chunk 0 has landed), 1 MFMA groups, 2 VALU sections (LayerNorm,
