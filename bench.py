@@ -749,7 +749,7 @@ def pmc_probe(dev):
         torch.cuda.synchronize(dev)
 
 
-def measure_pmc(passes, timeout_s=150):
+def measure_pmc(passes, timeout_s=90):
     """HBM bytes / matrix-busy cycles of the hot kernels measured BY THIS RUN: one `rocprofv3 --pmc <counters>` child per pass
     (separate passes for FETCH_SIZE and WRITE_SIZE, as MI355X_MICROARCH.md prescribes; counters only, no trace domains) around
     `bench.py --pmc-probe`.  The parent has initialised the GPU, so the profiler is STARTED AS A CHILD (never an exec), with the
