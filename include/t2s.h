@@ -109,13 +109,16 @@ void t2s_dit_destroy(t2s_dit* h);
 int t2s_dit_max_seqs(const t2s_dit* h);
 /* Matrix arithmetic of t2s_dit_forward[_cfg] / the sampler (attention and the row chain; the adaLN
  * linear and the small layers always run in f32).
- *   T2S_MATH_F32 (default)  v_mfma_f32_32x32x2_f32: exact fp32 multiply-add chains.
+ *   T2S_MATH_F32 (a new handle's mode)  v_mfma_f32_32x32x2_f32: exact fp32 multiply-add chains.
  *   T2S_MATH_BF16X3         every fp32 operand split into three bf16 terms, each product evaluated as
  *                           the six bf16 MFMAs of weight >= 2^-16 with fp32 accumulation: the same
  *                           accuracy as an fp32 product (dropped terms <= 3 * 2^-24 relative; measured
  *                           against fp64 the attention kernel is as close as the f32 one) at 2.67x
  *                           fewer matrix cycles.  Allocates 2 x max_seqs x 368,640 B + 3.1 MB of split
  *                           weights on first use; weights follow t2s_dit_update_weights.
+ *                           Since round 5 the host-side Sampler and infer.py SELECT this mode unless told otherwise
+ *                           (its error against fp64 is not larger than the reference's own CPU fp32 arithmetic at any of
+ *                           17 table entries, profiles/r05_accuracy.md); the class API and the bench headline stay on F32.
  * Not capturable; a hipGraph captured under one mode keeps replaying that mode's kernels. */
 #define T2S_MATH_F32 0
 #define T2S_MATH_BF16X3 1
