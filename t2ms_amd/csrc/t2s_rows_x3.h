@@ -51,15 +51,7 @@ __device__ __forceinline__ unsigned long long x3_clk() {
 #define X3_SYNC() wg_sync();
 #endif
 constexpr int X3_CHUNK_UNITS = 24 * 64;                    // 16-byte units per chunk (24 KiB)
-// NW waves per workgroup.  4 (two workgroups per CU): one barrier per chunk, 2-slot weight ring one chunk ahead.
-// 8 (one workgroup per CU; "ping-pong", T2S_X3_NW=8): waves 0-3 and 4-7 are the two waves of each SIMD and run HALF A CHUNK
-// APART -- two barriers per chunk split it into its MFMA group and its VALU epilogue, and while one half multiplies the other
-// does its epilogue (the stamps of -DT2S_X3_STAMP show the 4-wave kernel's SIMD partners, which come from two independent
-// workgroups, overlapping their matrix and vector phases hardly at all); 3-slot ring two chunks ahead, three DMA pieces per
-// wave and chunk, the weights cross L2 -> LDS once per 256 tokens.
-constexpr int x3_ring_slots(int nw) { return nw == 8 ? 3 : 2; }
-constexpr int rows_x3_lds_bytes(int nw) { return x3_ring_slots(nw) * X3_CHUNK_UNITS * 16 + (ROWS_CB_FLOATS + nw * ROWS_CM_FLOATS) * 4; }
-constexpr int ROWS_X3_LDS_BYTES = rows_x3_lds_bytes(4);
+constexpr int ROWS_X3_LDS_BYTES = 2 * X3_CHUNK_UNITS * 16 + (ROWS_CB_FLOATS + 4 * ROWS_CM_FLOATS) * 4;
 
 struct RowArgsX3 {
     float* x;          // (M,128) residual stream, fragment-major, in place
@@ -133,27 +125,12 @@ __device__ __forceinline__ Split3 ldw3(const bf16x8* wb, int pc) {
     return w;
 }
 
-// s_waitcnt vmcnt(n) for the counts the row kernel uses (the instruction takes an immediate): everything but the n youngest
-// vector-memory operations of this wave is done
-__device__ __forceinline__ void x3_wait_vm(int n) {
-    switch (n) {
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-
 // One chunk's eight k-steps with the NEXT k-step's three weight fragments requested before the current k-step's six MFMAs
-// (T2S_X3_PIPE; sched_barrier pins that order, the waitcnt pass then emits counted lgkmcnt waits): without it hipcc emits
-// `3 ds_read, s_waitcnt lgkmcnt(0), 6 MFMA` per k-step and every k-step exposes an LDS round trip to the matrix pipe.
-// `hook(ks)` runs between the k-steps (the LDS-DMA piece of the next chunk).
+// (sched_barrier pins that order; the waitcnt pass then emits counted lgkmcnt waits instead of `3 ds_read, lgkmcnt(0), 6 MFMA`
+// per k-step): rows -1.5 %, sampler +1.1 % in a same-box A/B (profiles/r05_x3_pingpong_ab.txt).  `hook(ks)` runs between the
+// k-steps (the LDS-DMA piece of the next chunk).
 template <bool SWAP, typename BOP, typename HOOK>
 __device__ __forceinline__ void ktile_x3(const bf16x8* wb, BOP&& bop, f32x16& acc, HOOK&& hook) {
-#ifdef T2S_X3_PIPE
     Split3 w = ldw3(wb, 0);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
@@ -165,27 +142,16 @@ __device__ __forceinline__ void ktile_x3(const bf16x8* wb, BOP&& bop, f32x16& ac
         __builtin_amdgcn_sched_barrier(0);
         w = wn;
     }
-#else
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        acc = SWAP ? mfma_x3(bop(ks), ldw3(wb, ks), acc) : mfma_x3(ldw3(wb, ks), bop(ks), acc);
-        hook(ks);
-    }
-#endif
 }
 
-template <bool DO_MLP, bool DO_QKV, int NW = 4>
-__global__ __launch_bounds__(NW * 64, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const RowArgsX3 a) {
-    constexpr int RS = x3_ring_slots(NW);         // ring slots
-    constexpr int DIST = RS - 1;                  // chunks the DMA runs ahead
-    constexpr int PPW = 24 / NW;                  // DMA pieces per wave and chunk
-    constexpr bool LATE = NW == 8;                // the barrier of a phase's last chunk follows the phase's closing VALU section
-    extern __shared__ __attribute__((aligned(16))) bf16x8 wring3[];  // [RS][X3_CHUNK_UNITS]
+template <bool DO_MLP, bool DO_QKV>
+__global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const RowArgsX3 a) {
+    extern __shared__ __attribute__((aligned(16))) bf16x8 wring3[];  // [2][X3_CHUNK_UNITS]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
     const int n_tiles = a.M >> 5;
-    int tile = blockIdx.x * NW + wave;            // 32-token tile of this wave
+    int tile = blockIdx.x * 4 + wave;             // 32-token tile of this wave
     const bool active = tile < n_tiles;           // tail waves compute on a clamped tile, store nothing
     if (!active) tile = n_tiles - 1;
     const int seq = (tile * 32) / NTOK;           // 480 = 15*32: a tile never straddles sequences
@@ -205,14 +171,14 @@ __global__ __launch_bounds__(NW * 64, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(c
         }
         return a.Wq + (size_t)ci * X3_CHUNK_UNITS;
     };
-    // each wave DMAs pieces {wave, wave + NW, ...} of the chunk
+    // each wave DMAs pieces {wave, wave+4, ..., wave+20} of the chunk
     auto fill = [&](int ci) T2S_X3_KERNEL {
         const bf16x8* src = chunk_src(ci) + lane;
-        bf16x8* dst = wring3 + (ci % RS) * X3_CHUNK_UNITS;
+        bf16x8* dst = wring3 + (ci & 1) * X3_CHUNK_UNITS;
 #pragma unroll
-        for (int p = 0; p < PPW; ++p)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (wave + NW * p) * 64),
-                                             (__attribute__((address_space(3))) void*)(dst + (wave + NW * p) * 64), 16, 0, 0);
+        for (int p = 0; p < 6; ++p)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (wave + 4 * p) * 64),
+                                             (__attribute__((address_space(3))) void*)(dst + (wave + 4 * p) * 64), 16, 0, 0);
     };
 
     X3_STAMP_DECL
@@ -223,34 +189,19 @@ __global__ __launch_bounds__(NW * 64, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(c
     // (glds16_asm) so hipcc keeps its counted lgkmcnt waits for the fragment reads: every chunk therefore ends with an
     // explicit vmcnt wait in front of its barrier.
     auto fill_piece = [&](int ci, int p) T2S_X3_KERNEL {
-        const bf16x8* src = chunk_src(ci) + lane + (wave + NW * p) * 64;
-        bf16x8* dst = wring3 + (ci % RS) * X3_CHUNK_UNITS + (wave + NW * p) * 64;
+        const bf16x8* src = chunk_src(ci) + lane + (wave + 4 * p) * 64;
+        bf16x8* dst = wring3 + (ci & 1) * X3_CHUNK_UNITS + (wave + 4 * p) * 64;
         glds16_asm(reinterpret_cast<const f32x4*>(src), reinterpret_cast<f32x4*>(dst));
     };
-    // during the MFMA group of chunk `cur`: the pieces of chunk cur + DIST, one per k-step
-#define X3_FILL_MIX(cur, step) if ((cur) + DIST < N_CHUNKS && (step) >= 1 && (step) <= PPW) fill_piece((cur) + DIST, (step) - 1);
-    // In front of the barrier that ends a chunk: the DMA pieces this wave issued for the chunks read next have landed.  NW = 4
-    // (one chunk ahead): everything.  NW = 8 (two ahead): everything but the PPW pieces issued during this chunk's MFMA group
-    // and the `stores` global stores of its epilogue (vmcnt counts in issue order: what is older than those is done).
-#define X3_DMA_LANDED(stores) x3_wait_vm(NW == 8 ? (stores) + ((ci + DIST < N_CHUNKS) ? PPW : 0) : ((stores) == 4 || (stores) == 6 ? (stores) : 0));
-    // NW = 8: the barrier between a chunk's MFMA group and its epilogue.  The other half reads the NEXT chunk right after it,
-    // so the pieces issued one MFMA group ago must have landed: all but the PPW just issued (none near the end of the kernel).
-#define X3_SYNC_MID()                                                                                \
-    if constexpr (NW == 8) {                                                                         \
-        x3_wait_vm((ci + DIST < N_CHUNKS) ? PPW : 0);                                                \
-        X3_STAMP(3)                                                                                  \
-        __builtin_amdgcn_s_barrier();                                                                \
-        X3_STAMP(4)                                                                                  \
-    }
-    static_assert(NW == 4 || PPW == 3, "the counted waits above are written for three pieces per wave");
+#define X3_FILL_MIX(ci, step) if ((step) >= 1 && (step) <= 6) fill_piece(ci, (step) - 1);
+#define X3_DMA_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     fill(0);
-    if constexpr (DIST == 2) fill(1);
 
     // ---- per-feature constants in LDS (visible after the first barrier), as in t2s_rows.h ----
-    float* cb = reinterpret_cast<float*>(wring3 + RS * X3_CHUNK_UNITS);
+    float* cb = reinterpret_cast<float*>(wring3 + 2 * X3_CHUNK_UNITS);
     float* cm = cb + ROWS_CB_FLOATS + wave * ROWS_CM_FLOATS;
     if constexpr (DO_MLP) {
-        for (int i = threadIdx.x; i < 512; i += NW * 64)
+        for (int i = threadIdx.x; i < 512; i += 256)
             cb[i] = i < 128 ? a.bp[i] : (i < 384 ? a.b1[i - 128] : a.b2[i - 384]);
         const float* src = modrow + a.blk * MODW;
 #pragma unroll
@@ -258,7 +209,7 @@ __global__ __launch_bounds__(NW * 64, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(c
             *reinterpret_cast<f32x4*>(cm + (i * 64 + lane) * 4) = *reinterpret_cast<const f32x4*>(src + (i * 64 + lane) * 4);
     }
     if constexpr (DO_QKV) {
-        for (int i = threadIdx.x; i < 384; i += NW * 64) cb[512 + i] = a.bq[i];
+        for (int i = threadIdx.x; i < 384; i += 256) cb[512 + i] = a.bq[i];
         const float* src = modrow + a.qkv_blk * MODW;   // shift_msa | scale_msa
         *reinterpret_cast<f32x4*>(cm + 768 + lane * 4) = *reinterpret_cast<const f32x4*>(src + lane * 4);
     }
@@ -294,22 +245,17 @@ __global__ __launch_bounds__(NW * 64, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(c
                 aop[ks] = split3(v);
             }
             X3_STAMP(0)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            X3_SYNC()  // chunks 0 .. DIST-1 landed (vmcnt(0) + barrier)
-            if constexpr (NW == 8) {
-                if (wave >= 4) { __builtin_amdgcn_s_barrier(); X3_STAMP(4) }      // the second half runs half a chunk behind
-            }
+            X3_SYNC()  // chunk 0 landed (vmcnt(0) + barrier)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 X3_STAMP(5)
-                const bf16x8* wb = wring3 + (ci % RS) * X3_CHUNK_UNITS + lane;
+                const bf16x8* wb = wring3 + (ci & 1) * X3_CHUNK_UNITS + lane;
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                 ktile_x3<false>(wb, [&](int ks) T2S_X3_KERNEL -> const Split3& { return aop[ks]; }, acc,
-                                [&](int ks) T2S_X3_KERNEL { X3_FILL_MIX(ci, ks) });
+                                [&](int ks) T2S_X3_KERNEL { X3_FILL_MIX(ci + 1, ks) });
                 X3_STAMP(1)
-                X3_SYNC_MID()
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 bias = ldc4(c_bp, nt, g, half);
@@ -318,10 +264,8 @@ __global__ __launch_bounds__(NW * 64, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(c
                     for (int e = 0; e < 4; ++e) x[nt][4 * g + e] += gate[e] * (acc[4 * g + e] + bias[e]);
                 }
                 X3_STAMP(2)
-                if (!(LATE && nt == 3)) {     // NW = 8: the last proj chunk's barrier comes after the LayerNorm + split below, so
-                    X3_DMA_LANDED(0)          // that the long VALU section is the other half's MFMA interval too
-                    X3_SYNC()
-                }
+                X3_DMA_LANDED()
+                X3_SYNC()
                 ++ci;
             }
         }
@@ -354,25 +298,17 @@ __global__ __launch_bounds__(NW * 64, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(c
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
             X3_PRIO(0)
             X3_STAMP(5)
-            if constexpr (LATE) {
-                x3_wait_vm(active ? 16 : 0);      // the 16 park stores stay in flight; everything older (the DMA pieces) is done
-                X3_STAMP(3)
-                __builtin_amdgcn_s_barrier();
-                X3_STAMP(4)
-            }
 #pragma unroll 1
             for (int c = 0; c < 8; ++c) {  // 32 hidden units per chunk; ci = 4 + 2c (even) here
                 X3_STAMP(5)
                 f32x16 hT;
-                Split3 h0, h1;      // gelu(fc1 chunk) as split operand fragments: the epilogue of the fc1 chunk
                 {
-                    const bf16x8* wb = wring3 + (ci % RS) * X3_CHUNK_UNITS + lane;
+                    const bf16x8* wb = wring3 + lane;  // ci even -> ring slot 0
 #pragma unroll
                     for (int r = 0; r < 16; ++r) hT[r] = 0.f;
                     ktile_x3<false>(wb, [&](int ks) T2S_X3_KERNEL -> const Split3& { return xmp[ks]; }, hT,
-                                    [&](int ks) T2S_X3_KERNEL { X3_FILL_MIX(ci, ks) });
+                                    [&](int ks) T2S_X3_KERNEL { X3_FILL_MIX(ci + 1, ks) });
                     X3_STAMP(1)
-                    X3_SYNC_MID()
                     X3_PRIO(2)   // GELU + split: let this wave's VALU win the issue arbitration over the partner's MFMA stream
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -380,31 +316,28 @@ __global__ __launch_bounds__(NW * 64, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(c
 #pragma unroll
                         for (int e = 0; e < 4; ++e) hT[4 * g + e] = gelu_tanh_f(hT[4 * g + e] + bias[e]);
                     }
-                    h0 = split3_acc(hT, 0);
-                    h1 = split3_acc(hT, 1);
-                    X3_PRIO(0)
                 }
                 X3_STAMP(2)
-                X3_DMA_LANDED(0)
+                X3_DMA_LANDED()
                 X3_SYNC()
                 ++ci;
                 X3_STAMP(5)
                 {   // fc2 partial over the 32 hidden units of this chunk: pieces (nt, s)
-                    const bf16x8* wb = wring3 + (ci % RS) * X3_CHUNK_UNITS + lane;
+                    const bf16x8* wb = wring3 + X3_CHUNK_UNITS + lane;  // ci odd -> ring slot 1
+                    const Split3 h0 = split3_acc(hT, 0), h1 = split3_acc(hT, 1);
+                    X3_PRIO(0)
+                    X3_STAMP(2)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
                         acc[nt] = mfma_x3(ldw3(wb, nt * 2 + 0), h0, acc[nt]);
-                        X3_FILL_MIX(ci, 2 * nt)
+                        if (ci + 1 < N_CHUNKS) { X3_FILL_MIX(ci + 1, 2 * nt) }
                         acc[nt] = mfma_x3(ldw3(wb, nt * 2 + 1), h1, acc[nt]);
-                        X3_FILL_MIX(ci, 2 * nt + 1)
+                        if (ci + 1 < N_CHUNKS) { X3_FILL_MIX(ci + 1, 2 * nt + 1) }
                     }
                     X3_STAMP(1)
-                    X3_SYNC_MID()
                 }
-                if (!(LATE && c == 7)) {      // NW = 8: the last fc2 chunk's barrier comes after the gate / residual (+ LayerNorm + split
-                    X3_DMA_LANDED(0)          // or the final layer) below
-                    X3_SYNC()
-                }
+                X3_DMA_LANDED()
+                X3_SYNC()
                 ++ci;
             }
 #pragma unroll
@@ -426,11 +359,7 @@ __global__ __launch_bounds__(NW * 64, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(c
         }
     } else {
         X3_STAMP(0)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        X3_SYNC()  // chunks 0 .. DIST-1 landed
-        if constexpr (NW == 8) {
-            if (wave >= 4) { __builtin_amdgcn_s_barrier(); X3_STAMP(4) }
-        }
+        X3_SYNC()  // chunk 0 landed
     }
 
     // ---- fused final layer of the LAST block (transformer.py:182-191): affine LayerNorm (eps 1e-5),
@@ -489,10 +418,6 @@ __global__ __launch_bounds__(NW * 64, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(c
             }
         }
     }
-    if constexpr (DO_MLP && !DO_QKV && LATE) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        X3_SYNC()
-    }
     if constexpr (DO_QKV) {
         Split3 xmp[8];      // LayerNorm + modulate output as resident planes
         X3_PRIO(2)
@@ -505,16 +430,10 @@ __global__ __launch_bounds__(NW * 64, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(c
         const int tile_in_seq = tile - seq * (NTOK / 32);
         X3_PRIO(0)
         X3_STAMP(2)
-        if constexpr (DO_MLP && LATE) {
-            x3_wait_vm(active ? 16 : 0);          // the 16 stores of the block's output stream stay in flight
-            X3_STAMP(3)
-            __builtin_amdgcn_s_barrier();
-            X3_STAMP(4)
-        }
 #pragma unroll 1
         for (int t = 0; t < 12; ++t) {  // output tile t = which*4 + head
             X3_STAMP(5)
-            const bf16x8* wb = wring3 + (ci % RS) * X3_CHUNK_UNITS + lane;
+            const bf16x8* wb = wring3 + (ci & 1) * X3_CHUNK_UNITS + lane;
             const int which = t >> 2, head = t & 3;
             const size_t head_tile = ((size_t)seq * NH + head) * (NTOK / 32) + tile_in_seq;
             f32x16 acc;
@@ -523,9 +442,8 @@ __global__ __launch_bounds__(NW * 64, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(c
             if (which < 2) {
                 // q / k tile, transposed product: lane = token, registers = features d
                 ktile_x3<false>(wb, [&](int ks) T2S_X3_KERNEL -> const Split3& { return xmp[ks]; }, acc,
-                                [&](int ks) T2S_X3_KERNEL { X3_FILL_MIX(ci, ks) });
+                                [&](int ks) T2S_X3_KERNEL { if (ci + 1 < N_CHUNKS) { X3_FILL_MIX(ci + 1, ks) } });
                 X3_STAMP(1)
-                X3_SYNC_MID()
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 bias = *reinterpret_cast<const f32x4*>(c_bq + 32 * t + 8 * g + 4 * half);
@@ -555,9 +473,8 @@ __global__ __launch_bounds__(NW * 64, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(c
                 // v tile with the MFMA operands swapped: lane = feature d, registers = keys
                 const float bias = c_bq[32 * t + (lane & 31)];
                 ktile_x3<true>(wb, [&](int ks) T2S_X3_KERNEL -> const Split3& { return xmp[ks]; }, acc,
-                               [&](int ks) T2S_X3_KERNEL { X3_FILL_MIX(ci, ks) });
+                               [&](int ks) T2S_X3_KERNEL { if (ci + 1 < N_CHUNKS) { X3_FILL_MIX(ci + 1, ks) } });
                 X3_STAMP(1)
-                X3_SYNC_MID()
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] += bias;
                 if (active) {
@@ -574,44 +491,32 @@ __global__ __launch_bounds__(NW * 64, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(c
             // counted wait + raw barrier: the next chunk's 6 DMA pieces must have landed; the q (4) or
             // k / v plane (6) stores issued after them stay in flight.  Tail waves store nothing.
             X3_STAMP(2)
-            if (!active) {
-                X3_DMA_LANDED(0)
-            } else if (which >= 1) {
-                X3_DMA_LANDED(6)
-            } else {
-                X3_DMA_LANDED(4)
-            }
+            if (!active)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (which >= 1)
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             X3_STAMP(3)
             __builtin_amdgcn_s_barrier();
             X3_STAMP(4)
             ++ci;
         }
     }
-    if constexpr (NW == 8) {
-        if (wave < 4) __builtin_amdgcn_s_barrier();       // the first half waits out the second half's last interval
-    }
 #ifdef T2S_X3_STAMP
     X3_STAMP(6)
     if (a.stamp != nullptr && blockIdx.x < 256 && lane == 0) {
-        unsigned long long* d = a.stamp + ((size_t)blockIdx.x * NW + wave) * 8;
+        unsigned long long* d = a.stamp + ((size_t)blockIdx.x * 4 + wave) * 8;
         for (int k = 0; k < 7; ++k) d[k] = st_acc[k];
         d[7] = st_last - st_t0;
     }
 #endif
 }
 
-// waves per workgroup of the bf16x3 row kernels: 8 = ping-pong halves (see above), 4 = two independent workgroups per CU
-inline int rows_x3_nw() {
-    static const int nw = getenv("T2S_X3_NW") ? atoi(getenv("T2S_X3_NW")) : 4;
-    return nw == 8 ? 8 : 4;
-}
-
 template <bool DO_MLP, bool DO_QKV>
 inline int dit_rows_x3_init() {
-    T2S_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dit_rows_x3_kernel<DO_MLP, DO_QKV, 4>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, rows_x3_lds_bytes(4)));
-    T2S_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dit_rows_x3_kernel<DO_MLP, DO_QKV, 8>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, rows_x3_lds_bytes(8)));
+    T2S_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dit_rows_x3_kernel<DO_MLP, DO_QKV>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_X3_LDS_BYTES));
     return T2S_OK;
 }
 
@@ -626,23 +531,20 @@ inline int launch_dit_rows_x3(const RowArgsX3& a, hipStream_t st) {
     static unsigned long long* buf = nullptr;
     static int calls = 0;
     if (!buf) {
-        T2S_HIP_CHECK(hipMalloc((void**)&buf, 256 * 8 * 8 * sizeof(unsigned long long)));
-        T2S_HIP_CHECK(hipMemset(buf, 0, 256 * 8 * 8 * sizeof(unsigned long long)));
+        T2S_HIP_CHECK(hipMalloc((void**)&buf, 256 * 4 * 8 * sizeof(unsigned long long)));
+        T2S_HIP_CHECK(hipMemset(buf, 0, 256 * 4 * 8 * sizeof(unsigned long long)));
     }
     RowArgsX3 a2 = a;
     a2.stamp = buf;
-    if (rows_x3_nw() == 8) dit_rows_x3_kernel<DO_MLP, DO_QKV, 8><<<(tiles + 7) / 8, 512, rows_x3_lds_bytes(8), st>>>(a2);
-    else dit_rows_x3_kernel<DO_MLP, DO_QKV, 4><<<(tiles + 3) / 4, 256, rows_x3_lds_bytes(4), st>>>(a2);
+    dit_rows_x3_kernel<DO_MLP, DO_QKV><<<(tiles + 3) / 4, 256, ROWS_X3_LDS_BYTES, st>>>(a2);
     T2S_LAUNCH_CHECK();
     if (++calls == 40 && tiles >= 4096) {      // one dump per instance, well after warm-up, at a chip-filling launch
-        static unsigned long long host[256 * 8 * 8];
-        const int nw = rows_x3_nw();
+        static unsigned long long host[256 * 4 * 8];
         T2S_HIP_CHECK(hipStreamSynchronize(st));
         T2S_HIP_CHECK(hipMemcpy(host, buf, sizeof(host), hipMemcpyDeviceToHost));
         double sum[8] = {};
-        const int n0 = (tiles + nw - 1) / nw < 256 ? (tiles + nw - 1) / nw : 256;
-        const int n = n0 * nw / 4;      // (the averages below divide by n * 4 waves)
-        for (int i = 0; i < n0 * nw; ++i)
+        const int n = (tiles + 3) / 4 < 256 ? (tiles + 3) / 4 : 256;
+        for (int i = 0; i < n * 4; ++i)
             for (int k = 0; k < 8; ++k) sum[k] += (double)host[i * 8 + k];
         fprintf(stderr, "x3_stamp <%d,%d> tiles %d: cycles per wave (s_memtime, 100 MHz ticks x? see tools/x3_stamp.sh) total %.0f | prologue %.0f mfma %.0f valu %.0f "
                         "vmcnt %.0f barrier %.0f issue %.0f epilogue %.0f\n", (int)DO_MLP, (int)DO_QKV, tiles, sum[7] / (n * 4), sum[0] / (n * 4),
@@ -650,8 +552,7 @@ inline int launch_dit_rows_x3(const RowArgsX3& a, hipStream_t st) {
     }
     return T2S_OK;
 #else
-    if (rows_x3_nw() == 8) dit_rows_x3_kernel<DO_MLP, DO_QKV, 8><<<(tiles + 7) / 8, 512, rows_x3_lds_bytes(8), st>>>(a);
-    else dit_rows_x3_kernel<DO_MLP, DO_QKV, 4><<<(tiles + 3) / 4, 256, rows_x3_lds_bytes(4), st>>>(a);
+    dit_rows_x3_kernel<DO_MLP, DO_QKV><<<(tiles + 3) / 4, 256, ROWS_X3_LDS_BYTES, st>>>(a);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 #endif
