@@ -769,10 +769,20 @@ def measure_pmc(passes, timeout_s=90):
         try:
             env = dict(os.environ, TMPDIR="/tmp")
             cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.abspath(__file__), "--pmc-probe"]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+            # its own process group: a pass that overruns is ended WITH the profiled grandchild (an exact group we started)
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                                    start_new_session=True)
+            try:
+                _, err = proc.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.communicate()
+                print(f"bench.py: rocprofv3 --pmc {' '.join(counters)} overran {timeout_s} s and was ended", file=sys.stderr)
+                return {}
             files = sorted(glob.glob(os.path.join(tmp, "*", "*counter_collection.csv")))
-            if r.returncode != 0 or not files:
-                print(f"bench.py: rocprofv3 --pmc {' '.join(counters)} failed (rc {r.returncode}): {r.stderr[-300:]}", file=sys.stderr)
+            if proc.returncode != 0 or not files:
+                print(f"bench.py: rocprofv3 --pmc {' '.join(counters)} failed (rc {proc.returncode}): {(err or '')[-300:]}", file=sys.stderr)
                 return {}
             agg = {}
             for row in csv.DictReader(open(files[-1])):
