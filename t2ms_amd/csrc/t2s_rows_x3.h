@@ -51,7 +51,11 @@ __device__ __forceinline__ unsigned long long x3_clk() {
 #define X3_SYNC() wg_sync();
 #endif
 constexpr int X3_CHUNK_UNITS = 24 * 64;                    // 16-byte units per chunk (24 KiB)
+#ifdef T2S_X3_LONE   // diagnosis (tools/x3_variant.sh x3_lone -DT2S_X3_LONE): pad the allocation so ONE workgroup fits a CU = one wave per SIMD
+constexpr int ROWS_X3_LDS_BYTES = 100 * 1024;
+#else
 constexpr int ROWS_X3_LDS_BYTES = 2 * X3_CHUNK_UNITS * 16 + (ROWS_CB_FLOATS + 4 * ROWS_CM_FLOATS) * 4;
+#endif
 
 struct RowArgsX3 {
     float* x;          // (M,128) residual stream, fragment-major, in place
