@@ -338,151 +338,6 @@ __global__ __launch_bounds__(512) T2S_X3_KERNEL void attn16_bwd_dkv_kernel(const
     }
 }
 
-// ------------------------------------------------------------------ backward in ONE pass: dQ, dK, dV from one evaluation of P
-// The two kernels above evaluate every 32 x 32 tile of P = exp2(S - lse) twice (once with the queries on the lanes for dQ,
-// once with the keys on the lanes for dK / dV) and both are bound by exactly that vector work (16 v_exp_f32 per tile against
-// 6 / 8 MFMAs at head_dim 32).  Here each tile is evaluated ONCE, by the wave that owns its 32 keys:
-//   waves 0..14  own key tile w: dK^T, dV^T stay in registers over the 15 query tiles (as in the dK / dV kernel); the dS tile
-//                of (query tile qb, key tile w) is also written, as bf16, into an exchange buffer in LDS as a 32-row image
-//                [key][query];
-//   wave 15      after the workgroup barrier that ends query tile qb, sums dQ^T[d][query] = sum_key K^T[d][key] dS^T[key][query]
-//                over the 15 exchanged tiles INSIDE one accumulator chain (30 MFMAs; both operands are column reads of images:
-//                K and the exchanged tile) -- no fp32 partials cross waves, the summation order is fixed, the result is
-//                deterministic -- and stores the dQ rows while the other waves are already on query tile qb + 1.
-// The exchange buffer is double-buffered by query-tile parity: wave 15 reads buffer qb & 1 between barriers qb and qb + 1, the
-// owners write it again only in iteration qb + 2, i.e. after barrier qb + 1.  LDS: Q, dO, K images 3 x 30,720 + lse / D
-// 3,840 + 2 x 15 x 2,048 = 157,440 B -> one 16-wave workgroup per CU (four waves per SIMD, as two of the 8-wave kernels).
-constexpr int XT = 32 * 64;                                          // one exchanged tile: 32 key rows x 32 queries, bf16
-constexpr int FUSED_LDS = 3 * IMG + 2 * NTOK * 4 + 2 * NKB * XT;     // 157,440 B
-
-__global__ __launch_bounds__(1024) T2S_X3_KERNEL void attn16_bwd_fused_kernel(
-    const __bf16* __restrict__ q, const __bf16* __restrict__ k, const __bf16* __restrict__ v, const __bf16* __restrict__ o_rows,
-    const __bf16* __restrict__ do_rows, const float* __restrict__ lse, __bf16* __restrict__ dqkv, int reverse) {
-    extern __shared__ __attribute__((aligned(16))) char fsm[];
-    char* Qs = fsm;                                               // Q image (pre-scaled q)
-    char* Os = fsm + IMG;                                         // dO image (this head)
-    char* Ks = fsm + 2 * IMG;                                     // K image (wave 15 only)
-    float* Ls = reinterpret_cast<float*>(fsm + 3 * IMG);          // -lse (log2 domain)
-    float* Ds = Ls + NTOK;                                        // -D_i
-    char* Xb = fsm + 3 * IMG + 2 * NTOK * 4;                      // [parity][key tile] exchanged dS tiles
-    const int bh = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x, tid = threadIdx.x;
-    const int lane = tid & 63, half = lane >> 5, j = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int seq = bh / NH, head = bh % NH;
-    const __bf16* dog = do_rows + (size_t)seq * NTOK * D + head * DH;
-    for (int p = wave; p < 90; p += 16) {
-        if (p < 30) dma_img_piece(Qs, q + (size_t)bh * NTOK * DH, DH, p, lane);
-        else if (p < 60) dma_img_piece(Os, dog, D, p - 30, lane);
-        else dma_img_piece(Ks, k + (size_t)bh * NTOK * DH, DH, p - 60, lane);
-    }
-    if (tid < 2 * NTOK) {   // D_i = sum_d dO[i][d] O[i][d]: two threads per query, 16 features each
-        const int tok = tid >> 1, hf = tid & 1;
-        const __bf16* orow = o_rows + ((size_t)seq * NTOK + tok) * D + head * DH + 16 * hf;
-        const __bf16* drow = dog + (size_t)tok * D + 16 * hf;
-        float d = 0.f;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const f32x8 ov = unpack8(*reinterpret_cast<const bf16x8*>(orow + 8 * c));
-            const f32x8 dv8 = unpack8(*reinterpret_cast<const bf16x8*>(drow + 8 * c));
-#pragma unroll
-            for (int e = 0; e < 8; ++e) d += ov[e] * dv8[e];
-        }
-        d += __shfl_xor(d, 1);
-        if (hf == 0) {
-            Ds[tok] = -d;
-            Ls[tok] = -lse[(size_t)bh * NTOK + tok];
-        }
-    }
-    bf16x8 kf[2], vf[2];   // owners: B operands K^T (of the pre-scaled scores' other factor) and V^T of this lane's key
-    if (wave < NKB) {
-        const size_t key = (size_t)bh * NTOK + wave * 32 + j;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            kf[s] = *reinterpret_cast<const bf16x8*>(k + key * DH + 16 * s + 8 * half);
-            vf[s] = *reinterpret_cast<const bf16x8*>(v + key * DH + 16 * s + 8 * half);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    wg_sync();
-    if (wave < NKB) {
-        f32x16 dk, dv;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dk[r] = dv[r] = 0.f;
-        char* xrow = Xb + wave * XT;
-        for (int qb = 0; qb < NKB; ++qb) {
-            f32x16 sc, dp;   // start at -lse / -D of the register's query: S - lse and dP - D come straight out of the MFMAs
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qb * 32 + 8 * g + 4 * half);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ds + qb * 32 + 8 * g + 4 * half);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    sc[4 * g + e] = l4[e];
-                    dp[4 * g + e] = d4[e];
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                sc = mfma16(row_frag(Qs, qb * 32, lane, s), kf[s], sc);    // S[query][key] - lse (registers = queries)
-                dp = mfma16(row_frag(Os, qb * 32, lane, s), vf[s], dp);    // dP[query][key] - D
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(sc[r]);
-                dp[r] = p * dp[r];             // dS[query][key]
-                sc[r] = p;                     // P[query][key]
-            }
-            char* xt = xrow + (qb & 1) * (NKB * XT);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 pf = acc_frag(sc, s), sf = acc_frag(dp, s);
-                dv = mfma16(col_frag(Os, qb * 32, lane, s), pf, dv);   // dV^T += dO^T P
-                dk = mfma16(col_frag(Qs, qb * 32, lane, s), sf, dk);   // dK^T += Q^T dS
-                // row j (this lane's key) of the exchanged image: queries 16 s + 4 half + {0..3, 8..11} = chunks 2s, 2s + 1
-                const uint4 w = __builtin_bit_cast(uint4, sf);
-                *reinterpret_cast<uint2*>(xt + img_off(j, 2 * s) + 8 * half) = make_uint2(w.x, w.y);
-                *reinterpret_cast<uint2*>(xt + img_off(j, 2 * s + 1) + 8 * half) = make_uint2(w.z, w.w);
-            }
-#ifndef T2S_FUSED_NO_BARRIER
-            wg_sync();   // barrier qb: the 15 tiles of query tile qb are in the exchange buffer
-#endif
-        }
-        __bf16* dst = dqkv + ((size_t)seq * NTOK + wave * 32 + j) * (3 * D) + head * DH;
-        store_row32(dst + D, dk, LN2, half);        // Qs holds q ATT_QS: dK = dS^T (q ATT_QS) ln 2
-        store_row32(dst + 2 * D, dv, 1.0f, half);
-    } else {
-        for (int qb = 0; qb < NKB; ++qb) {
-#ifndef T2S_FUSED_NO_BARRIER
-            wg_sync();   // barrier qb
-#endif
-            const char* xb = Xb + (qb & 1) * (NKB * XT);
-            // three independent accumulator chains (key tiles kt = c mod 3), summed in a fixed order at the end: a chain of 30
-            // dependent MFMAs would wait out the full MFMA latency 30 times per query tile
-            f32x16 dqc[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dqc[c][r] = 0.f;
-#ifndef T2S_FUSED_IDLE_DQ
-#pragma unroll 1
-            for (int kt = 0; kt < NKB; kt += 3) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)   // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
-                        dqc[c] = mfma16(col_frag(Ks, (kt + c) * 32, lane, s), col_frag(xb + (kt + c) * XT, 0, lane, s), dqc[c]);
-            }
-#else
-            (void)xb;
-#endif
-            f32x16 dq;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dq[r] = (dqc[0][r] + dqc[1][r]) + dqc[2][r];
-            store_row32(dqkv + ((size_t)seq * NTOK + qb * 32 + j) * (3 * D) + head * DH, dq, SCALE, half);
-        }
-    }
-}
-
 int attn16_train_fwd(const __bf16* q, const __bf16* k, const __bf16* v, __bf16* o_rows, float* lse, int BH, hipStream_t st) {
     attn16_fwd_kernel<<<BH, 512, 0, st>>>(q, k, v, o_rows, lse, next_tile_dir());
     T2S_LAUNCH_CHECK();
@@ -491,15 +346,6 @@ int attn16_train_fwd(const __bf16* q, const __bf16* k, const __bf16* v, __bf16* 
 
 int attn16_bwd(const __bf16* q, const __bf16* k, const __bf16* v, const __bf16* o_rows, const __bf16* do_rows,
                const float* lse, float* dsum, __bf16* dqkv_rows, int BH, hipStream_t st) {
-    static const bool split = getenv("T2S_ATTN_BWD_SPLIT") && atoi(getenv("T2S_ATTN_BWD_SPLIT"));   // the two-kernel form (A/B)
-    if (!split) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_fused_kernel),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);
-        T2S_HIP_CHECK(attr);
-        attn16_bwd_fused_kernel<<<BH, 1024, FUSED_LDS, st>>>(q, k, v, o_rows, do_rows, lse, dqkv_rows, next_tile_dir());
-        T2S_LAUNCH_CHECK();
-        return T2S_OK;
-    }
     attn16_bwd_dq_kernel<<<BH, 512, 0, st>>>(q, k, v, o_rows, do_rows, lse, dsum, dqkv_rows, next_tile_dir());   // also writes D_i -> dsum
     T2S_LAUNCH_CHECK();
     attn16_bwd_dkv_kernel<<<BH, 512, 0, st>>>(q, k, v, do_rows, lse, dsum, dqkv_rows, next_tile_dir());
