@@ -25,7 +25,7 @@
  *     of one process on one device (what the library serialises for them: "Threads"
  *     at t2s_sampler_run).  The handle-free entry points (t2s_ddpm_*, t2s_rf_*,
  *     t2s_philox_*, t2s_mse_ws, t2s_mse_backward, t2s_adamw_*, t2s_attn_fwd*,
- *     t2s_time_embedding_freqs, t2s_eval_*, t2s_ts2vec_encode) keep no state between
+ *     t2s_time_embedding_freqs, t2s_eval_*, t2s_ts2vec_encode, t2s_mlp_*) keep no state between
  *     calls and may be called from any thread on any stream; t2s_mse lends a scratch
  *     per (device, stream), see there.  The deployment model is one process per GPU.
  */
@@ -528,6 +528,42 @@ typedef struct t2s_ts2vec_weights {
  * their maximum over time.  Time steps of x holding a NaN are zeroed as the reference does.  3 * max(hidden,
  * output_dims) * T * 4 bytes must fit in 160 KB of LDS (T <= 128 at the evaluation's 64 / 100 channels). */
 int t2s_ts2vec_encode(const t2s_ts2vec_weights* w, const float* x, float* rep, float* full, int B, int T, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * MLP denoiser of BASELINE configs[0]: model/denoiser/mlp.py:49-94 (MLPlayer x 8 on a
+ * (64, 6) latent; inference forward -- training stays torch autograd in the mirror).
+ * ------------------------------------------------------------------------ */
+#define T2S_MLP_LAYERS 8
+#define T2S_MLP_WIDTH 64      /* channels, mlp.py:52-56 */
+#define T2S_MLP_POSITIONS 6   /* latent width the layer is built for, mlp.py:55,67 */
+#define T2S_MLP_TEXT_DIM 128
+#define T2S_MLP_HIDDEN 256
+#define T2S_MLP_PACKED_FLOATS 397888 /* 8 x 49,736: what t2s_mlp_pack writes */
+/* Device pointers to the state-dict tensors of layers.<i> that the forward reads (torch layouts).  cross_attn.query /
+ * cross_attn.key are not among them: the six keys are the same row (mlp.py:77 repeats the text over the positions), every
+ * softmax row is uniform and the attended value is value(text) whatever they hold.  norm1, norm3, pos_emb, self_attn,
+ * self_attn2 are constructed and never called (mlp.py:53-60). */
+typedef struct t2s_mlp_layer_weights {
+    const float *value_w, *value_b; /* cross_attn.value (64,128), (64) */
+    const float *proj_w, *proj_b;   /* cross_attn.proj  (64,64), (64)  */
+    const float *norm2_w, *norm2_b; /* (64) */
+    const float *mlp0_w, *mlp0_b;   /* mlp.0  (256,64), (256) */
+    const float *mlp2_w, *mlp2_b;   /* mlp.2  (64,256), (64)  */
+    const float *pos0_w, *pos0_b;   /* mlp2.0 (256,6), (256)  */
+    const float *pos2_w, *pos2_b;   /* mlp2.2 (6,256), (6)    */
+} t2s_mlp_layer_weights;
+typedef struct t2s_mlp_weights {
+    t2s_mlp_layer_weights layer[T2S_MLP_LAYERS];
+} t2s_mlp_weights;
+/* Transposes the weights into `packed` (T2S_MLP_PACKED_FLOATS floats, caller-owned device buffer).  Every pointer's
+ * allocation extent is checked against the shape above.  Stateless: pack again after the weights change. */
+int t2s_mlp_pack(const t2s_mlp_weights* w, float* packed, void* stream);
+/* MLP.forward (mlp.py:90-94): x (B,64,6); t (B) fp32 (int64 timesteps converted by the host mirror exactly as
+ * `t * 100.0` promotes them) and freqs (32) = 10000^linspace(0,1,32) as the caller evaluated it (mlp.py:12) for
+ * TimeEmbedding(64), mlp.py:5-18; text (B,128) or NULL (mlp.py:75 skips the cross attention) -> out (B,64,6); out may
+ * alias x.  One launch, one workgroup per series. */
+int t2s_mlp_forward(const float* packed, const float* x, const float* t, const float* freqs, const float* text, float* out,
+                    int B, void* stream);
 
 #ifdef __cplusplus
 }

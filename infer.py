@@ -58,7 +58,7 @@ def _load_models(args, device):
                          map_location=torch.device("cpu"), weights_only=False)     # infer.py:39
     vae = vae.float().to(device).eval()
     if args.denoiser == "MLP":
-        # BASELINE configs[0] (plumbing): torch mirror of the MLP denoiser on the (B,64,L/4) latent, L = 24
+        # BASELINE configs[0] (plumbing): the MLP denoiser on the (B,64,L/4) latent, L = 24 (t2s_mlp_forward under no_grad)
         from model.denoiser.mlp import MLP
         model = MLP()
         if args.random_init:
@@ -84,8 +84,9 @@ def sample_mlp_config1(model, vae, backbone, x_1, embedding, args, device, row0)
     """The loop of infer.py:76-95 for `--denoiser MLP`, in the runnable form SURVEY.md 8(d) config 1 prescribes: the
     reference's MLP needs a 6-wide latent (mlp.py:55,67) while its encoder emits 30 (vqvae.py:70), so the diffusion
     state is the PRE-interpolation latent `before` (B,64,L/4), L = 24, and the decoder's 6 -> 6 interpolation is the
-    identity.  The MLP is a torch module (plumbing); the encoder, the DDPM update and the decoder are
-    the HIP kernels; x_T and the per-step draws come from the library's Philox stream keyed by the global row."""
+    identity.  Every step is HIP kernels: the two `model(...)` calls are one launch of t2s_mlp_forward each (row a20), then
+    the DDPM update; encoder and decoder likewise; x_T and the per-step draws come from the library's Philox stream keyed
+    by the global row."""
     from t2ms_amd.sampler import XT_STREAM, philox_normal
     if backbone != "ddpm":
         raise ValueError("config 1 (MLP denoiser) is wired for --backbone ddpm")
@@ -157,7 +158,7 @@ def infer(args):
     L = int(x1_host.shape[1])
     x1_dev = x1_host.to(device)
     emb_dev = torch.as_tensor(emb_tab)[order].float().to(device)
-    # MLP (plumbing, a torch module): one launch per loader batch, as the reference; DiT: coalesced launches
+    # MLP (configs[0] plumbing): one sampling loop per loader batch, as the reference; DiT: coalesced launches
     plan = launch_plan(n_rows, B, 0 if is_mlp else int(getattr(args, "launch_batch", 256)), world)
     flush_rows = int(os.environ.get("T2S_INFER_FLUSH_ROWS", str(1 << 17)))     # outputs stay in HBM this long (16 KB / row)
 

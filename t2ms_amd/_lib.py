@@ -77,6 +77,22 @@ class Ts2vecWeights(C.Structure):
                 ("proj_w", C.c_void_p), ("proj_b", C.c_void_p)]
 
 
+MLP_LAYERS, MLP_PACKED_FLOATS = 8, 397888   # t2s.h: T2S_MLP_LAYERS, T2S_MLP_PACKED_FLOATS
+MLP_LAYER_FIELDS = (("value_w", "cross_attn.value.weight"), ("value_b", "cross_attn.value.bias"),
+                    ("proj_w", "cross_attn.proj.weight"), ("proj_b", "cross_attn.proj.bias"),
+                    ("norm2_w", "norm2.weight"), ("norm2_b", "norm2.bias"),
+                    ("mlp0_w", "mlp.0.weight"), ("mlp0_b", "mlp.0.bias"), ("mlp2_w", "mlp.2.weight"), ("mlp2_b", "mlp.2.bias"),
+                    ("pos0_w", "mlp2.0.weight"), ("pos0_b", "mlp2.0.bias"), ("pos2_w", "mlp2.2.weight"), ("pos2_b", "mlp2.2.bias"))
+
+
+class MlpLayerWeights(C.Structure):
+    _fields_ = [(f, C.c_void_p) for f, _ in MLP_LAYER_FIELDS]
+
+
+class MlpWeights(C.Structure):
+    _fields_ = [("layer", MlpLayerWeights * MLP_LAYERS)]
+
+
 class SampleConfig(C.Structure):
     _fields_ = [("mode", C.c_int), ("steps", C.c_int), ("cfg_scale", C.c_float), ("batch", C.c_int),
                 ("length", C.c_int), ("use_graph", C.c_int), ("seed", C.c_uint64), ("row0", C.c_uint32),
@@ -112,6 +128,8 @@ SYMBOLS = {
     "t2s_eval_crps": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "t2s_eval_dtw": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
     "t2s_ts2vec_encode": (_I, [C.POINTER(Ts2vecWeights), _VP, _VP, _VP, _I, _I, _VP]),
+    "t2s_mlp_pack": (_I, [C.POINTER(MlpWeights), _VP, _VP]),
+    "t2s_mlp_forward": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_attn_fwd_x3": (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_attn_fwd_bf16": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_dit_train_forward": (_I, [_VP, C.POINTER(DitWeights), _VP, _VP, _I, _VP, _VP, _I, _VP]),

@@ -1,0 +1,299 @@
+// The MLP denoiser of BASELINE configs[0] (reference model/denoiser/mlp.py:49-94) as ONE kernel per forward:
+// eight MLPlayers on a (64 channels x 6 positions) latent, one 256-thread workgroup per series, activations in LDS /
+// registers from the first layer to the last, fp32 FMA arithmetic (the layers are 0.8 MFLOP each: launch- and
+// latency-bound, not a matrix-core problem -- a torch-op evaluation is ~50 launches per layer).
+//
+// Per layer (mlp.py:71-85), for one series:
+//   h[p][c] = x[c][p] + temb[c]                                                  (mlp.py:73-74)
+//   text given:  h[p][:] += proj(value(text))                                   (mlp.py:76-79, 21-47)
+//       The cross attention's six keys / values are the SAME row (text repeated over the six positions, mlp.py:77), so
+//       every softmax row is uniform whatever the queries are and the attended value is value(text) itself: query and
+//       key cannot influence the result and are not evaluated (the reference's 6 x (1/6) v differs from v by one fp32
+//       rounding).
+//   h = LayerNorm_64(h) (norm2, eps 1e-5, affine)                                (mlp.py:80)
+//   h = h + W2 relu(W1 h + b1) + b2          (64 -> 256 -> 64, per position)     (mlp.py:81)
+//   x'[c][:] = W4 relu(W3 h[:][c] + b3) + b4 (6 -> 256 -> 6, per channel)        (mlp.py:83-84)
+//
+// Weights: t2s_mlp_pack transposes the torch Linear weights once into one buffer ([in][out], so that the thread that owns
+// an output reads its weights coalesced with its neighbours); t2s_mlp_forward takes only that buffer.  Both are
+// stateless: the caller owns the packed buffer and re-packs after changing the weights.
+#include "t2s_common.h"
+
+namespace t2s {
+namespace {
+
+constexpr int MC = T2S_MLP_WIDTH;       // 64 channels
+constexpr int MP = T2S_MLP_POSITIONS;   // 6 positions
+constexpr int MT = T2S_MLP_TEXT_DIM;    // 128
+constexpr int MH = T2S_MLP_HIDDEN;      // 256
+constexpr int ML = T2S_MLP_LAYERS;      // 8
+
+// packed layer (floats)
+constexpr int O_WV = 0;                    // [128][64]  value.weight^T
+constexpr int O_BV = O_WV + MT * MC;       // [64]
+constexpr int O_WP = O_BV + MC;            // [64][64]   proj.weight^T
+constexpr int O_BP = O_WP + MC * MC;       // [64]
+constexpr int O_LG = O_BP + MC;            // [64]       norm2.weight
+constexpr int O_LB = O_LG + MC;            // [64]       norm2.bias
+constexpr int O_W1 = O_LB + MC;            // [64][256]  mlp.0.weight^T
+constexpr int O_B1 = O_W1 + MC * MH;       // [256]
+constexpr int O_W2 = O_B1 + MH;            // [256][64]  mlp.2.weight^T
+constexpr int O_B2 = O_W2 + MH * MC;       // [64]
+constexpr int O_W3 = O_B2 + MC;            // [256][8]   mlp2.0.weight rows (6 used) | b3 | pad
+constexpr int O_W4 = O_W3 + MH * 8;        // [256][8]   mlp2.2.weight^T rows (6 used), pad
+constexpr int O_B4 = O_W4 + MH * 8;        // [8]        (6 used)
+constexpr int LAYER_FLOATS = O_B4 + 8;
+static_assert(LAYER_FLOATS * ML == T2S_MLP_PACKED_FLOATS, "include/t2s.h: T2S_MLP_PACKED_FLOATS");
+static_assert(LAYER_FLOATS % 4 == 0, "layers stay 16-byte aligned");
+
+struct PackArgs {
+    t2s_mlp_weights w;
+    float* dst;
+};
+
+// one workgroup per (layer, tensor group); plain gathers -- this runs once per set of weights
+__global__ __launch_bounds__(256) void mlp_pack_kernel(PackArgs a) {
+    const int layer = blockIdx.x;
+    const t2s_mlp_layer_weights& w = a.w.layer[layer];
+    float* d = a.dst + (size_t)layer * LAYER_FLOATS;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < MT * MC; i += 256) d[O_WV + i] = w.value_w[(i % MC) * MT + i / MC];      // [k][c] <- [c][k]
+    for (int i = tid; i < MC * MC; i += 256) d[O_WP + i] = w.proj_w[(i % MC) * MC + i / MC];
+    for (int i = tid; i < MC * MH; i += 256) d[O_W1 + i] = w.mlp0_w[(i % MH) * MC + i / MH];       // [c][j] <- [j][c]
+    for (int i = tid; i < MH * MC; i += 256) d[O_W2 + i] = w.mlp2_w[(i % MC) * MH + i / MC];       // [j][c] <- [c][j]
+    for (int i = tid; i < MH * 8; i += 256) {
+        const int j = i >> 3, p = i & 7;
+        d[O_W3 + i] = p < MP ? w.pos0_w[j * MP + p] : (p == 6 ? w.pos0_b[j] : 0.f);               // row j: W3[j][0..5], b3[j]
+        d[O_W4 + i] = p < MP ? w.pos2_w[p * MH + j] : 0.f;                                          // row j: W4[0..5][j]
+    }
+    if (tid < MC) {
+        d[O_BV + tid] = w.value_b[tid];
+        d[O_BP + tid] = w.proj_b[tid];
+        d[O_LG + tid] = w.norm2_w[tid];
+        d[O_LB + tid] = w.norm2_b[tid];
+        d[O_B2 + tid] = w.mlp2_b[tid];
+    }
+    d[O_B1 + tid] = w.mlp0_b[tid];
+    if (tid < 8) d[O_B4 + tid] = tid < MP ? w.pos2_b[tid] : 0.f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void mlp_forward_kernel(const float* __restrict__ packed, const float* __restrict__ x,
+                                                          const float* __restrict__ t, const float* __restrict__ freqs,
+                                                          const float* __restrict__ text, float* __restrict__ out) {
+    __shared__ float xs[MC * MP];          // current latent [c][p]
+    __shared__ float hs[MP][MC];           // normalised rows
+    __shared__ float hid[MP][MH];          // relu(W1 h + b1)
+    __shared__ float red[4][MP][MC];       // partial sums of the four input quarters, added in a fixed order
+    __shared__ float txt[MT];
+    __shared__ float vs[MC], as[MC];
+    __shared__ f32x4 w3s[2 * MH], w4s[2 * MH];   // this layer's position-MLP rows
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < MC * MP; i += 256) xs[i] = x[(size_t)b * MC * MP + i];
+    if (text != nullptr && tid < MT) txt[tid] = text[(size_t)b * MT + tid];
+    // TimeEmbedding(64), mlp.py:5-18: [sin(100 t / f) | cos(100 t / f)] -- this lane's channel; the same in every layer
+    const float targ = (t[b] * 100.0f) / freqs[lane & 31];
+    const float te = lane < 32 ? sinf(targ) : cosf(targ);
+    __syncthreads();
+
+    for (int layer = 0; layer < ML; ++layer) {
+        const float* w = packed + (size_t)layer * LAYER_FLOATS;
+        // Every weight this thread needs in the layer is requested HERE, before the first dependent instruction: the layer
+        // is a chain of short phases and a phase that starts by fetching its weights pays an L2 round trip per unrolled
+        // group (measured: 24 us per layer that way, 190 us per forward whatever the batch).
+        float wv1[MC], wv2[MC], wvv[32], wvp[16];
+#pragma unroll
+        for (int c = 0; c < MC; ++c) wv1[c] = w[O_W1 + c * MH + tid];                       // fc1 column of hidden unit tid
+#pragma unroll
+        for (int jj = 0; jj < MC; ++jj) wv2[jj] = w[O_W2 + (64 * wave + jj) * MC + lane];   // fc2: this wave's quarter, channel lane
+        if (text != nullptr) {
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) wvv[kk] = w[O_WV + (32 * wave + kk) * MC + lane];
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) wvp[kk] = w[O_WP + (16 * wave + kk) * MC + lane];
+        }
+        const float b1 = w[O_B1 + tid], b2 = w[O_B2 + lane], g = w[O_LG + lane], be = w[O_LB + lane];
+        const float bv = w[O_BV + lane], bp = w[O_BP + lane];
+        {   // the position MLP's rows (uniform per wave later): through LDS, one coalesced copy
+            const f32x4* src3 = reinterpret_cast<const f32x4*>(w + O_W3) + 2 * tid;
+            const f32x4* src4 = reinterpret_cast<const f32x4*>(w + O_W4) + 2 * tid;
+            w3s[2 * tid] = src3[0];
+            w3s[2 * tid + 1] = src3[1];
+            w4s[2 * tid] = src4[0];
+            w4s[2 * tid + 1] = src4[1];
+        }
+        float add = te;                                   // temb[c] (+ the cross-attention row)
+        if (text != nullptr) {
+            // v = value(text): channel = lane, the 128 inputs in four quarters (one per wave)
+            float acc = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) acc = fmaf(wvv[kk], txt[32 * wave + kk], acc);
+            red[wave][0][lane] = acc;
+            __syncthreads();
+            if (wave == 0) vs[lane] = bv + ((red[0][0][lane] + red[1][0][lane]) + (red[2][0][lane] + red[3][0][lane]));
+            __syncthreads();
+            acc = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) acc = fmaf(wvp[kk], vs[16 * wave + kk], acc);
+            red[wave][1][lane] = acc;
+            __syncthreads();
+            if (wave == 0) as[lane] = bp + ((red[0][1][lane] + red[1][1][lane]) + (red[2][1][lane] + red[3][1][lane]));
+            __syncthreads();
+            add += as[lane];
+        }
+        // LayerNorm over the 64 channels of a position: wave w takes positions w and w + 4
+        for (int p = wave; p < MP; p += 4) {
+            const float v = xs[lane * MP + p] + add;
+            const float mean = wave_sum(v) * (1.0f / MC);
+            const float dlt = v - mean;
+            const float var = wave_sum(dlt * dlt) * (1.0f / MC);
+            hs[p][lane] = dlt * (1.0f / sqrtf(var + 1e-5f)) * g + be;
+        }
+        __syncthreads();
+        // fc1: thread j owns hidden unit j for the six positions
+        {
+            float acc[MP];
+#pragma unroll
+            for (int p = 0; p < MP; ++p) acc[p] = b1;
+#pragma unroll
+            for (int c = 0; c < MC; c += 4) {
+#pragma unroll
+                for (int p = 0; p < MP; ++p) {
+                    const f32x4 h4 = *reinterpret_cast<const f32x4*>(&hs[p][c]);
+                    acc[p] = fmaf(wv1[c], h4.x, acc[p]);
+                    acc[p] = fmaf(wv1[c + 1], h4.y, acc[p]);
+                    acc[p] = fmaf(wv1[c + 2], h4.z, acc[p]);
+                    acc[p] = fmaf(wv1[c + 3], h4.w, acc[p]);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < MP; ++p) hid[p][tid] = fmaxf(acc[p], 0.f);
+        }
+        __syncthreads();
+        // fc2: channel = lane, hidden units in four quarters (one per wave)
+        {
+            float acc[MP];
+#pragma unroll
+            for (int p = 0; p < MP; ++p) acc[p] = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < MC; jj += 4) {
+#pragma unroll
+                for (int p = 0; p < MP; ++p) {
+                    const f32x4 h4 = *reinterpret_cast<const f32x4*>(&hid[p][64 * wave + jj]);
+                    acc[p] = fmaf(wv2[jj], h4.x, acc[p]);
+                    acc[p] = fmaf(wv2[jj + 1], h4.y, acc[p]);
+                    acc[p] = fmaf(wv2[jj + 2], h4.z, acc[p]);
+                    acc[p] = fmaf(wv2[jj + 3], h4.w, acc[p]);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < MP; ++p) red[wave][p][lane] = acc[p];
+        }
+        __syncthreads();
+        // g[c][p] = h[p][c] + b2[c] + sum of the four quarters; every wave needs all six of its channel
+        float gv[MP];
+#pragma unroll
+        for (int p = 0; p < MP; ++p)
+            gv[p] = hs[p][lane] + (b2 + ((red[0][p][lane] + red[1][p][lane]) + (red[2][p][lane] + red[3][p][lane])));
+        __syncthreads();   // red is rewritten below
+        // position MLP of channel `lane`: hidden units in four quarters (one per wave); the rows are wave-uniform LDS reads
+        {
+            float acc[MP];
+#pragma unroll
+            for (int p = 0; p < MP; ++p) acc[p] = 0.f;
+            const f32x4* w3 = w3s + 2 * 64 * wave;
+            const f32x4* w4 = w4s + 2 * 64 * wave;
+#pragma unroll 8
+            for (int j = 0; j < 64; ++j) {
+                const f32x4 a0 = w3[2 * j], a1 = w3[2 * j + 1];     // W3[j][0..3] | W3[j][4..5], b3[j], 0
+                float hdn = a1.z;
+                hdn = fmaf(a0.x, gv[0], hdn);
+                hdn = fmaf(a0.y, gv[1], hdn);
+                hdn = fmaf(a0.z, gv[2], hdn);
+                hdn = fmaf(a0.w, gv[3], hdn);
+                hdn = fmaf(a1.x, gv[4], hdn);
+                hdn = fmaf(a1.y, gv[5], hdn);
+                hdn = fmaxf(hdn, 0.f);
+                const f32x4 c0 = w4[2 * j], c1 = w4[2 * j + 1];     // W4[0..3][j] | W4[4..5][j], 0, 0
+                acc[0] = fmaf(c0.x, hdn, acc[0]);
+                acc[1] = fmaf(c0.y, hdn, acc[1]);
+                acc[2] = fmaf(c0.z, hdn, acc[2]);
+                acc[3] = fmaf(c0.w, hdn, acc[3]);
+                acc[4] = fmaf(c1.x, hdn, acc[4]);
+                acc[5] = fmaf(c1.y, hdn, acc[5]);
+            }
+#pragma unroll
+            for (int p = 0; p < MP; ++p) red[wave][p][lane] = acc[p];
+        }
+        __syncthreads();
+        for (int i = tid; i < MC * MP; i += 256) {
+            const int c = i / MP, p = i - c * MP;
+            xs[i] = w[O_B4 + p] + ((red[0][p][c] + red[1][p][c]) + (red[2][p][c] + red[3][p][c]));
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < MC * MP; i += 256) out[(size_t)b * MC * MP + i] = xs[i];
+}
+
+}  // namespace
+}  // namespace t2s
+
+extern "C" int t2s_mlp_pack(const t2s_mlp_weights* w, float* packed, void* stream) {
+    using namespace t2s;
+    T2S_REQUIRE(w && packed, "t2s_mlp_pack: null argument");
+    static const struct { size_t off; size_t floats; const char* name; } items[] = {
+        {offsetof(t2s_mlp_layer_weights, value_w), (size_t)MC * MT, "cross_attn.value.weight"},
+        {offsetof(t2s_mlp_layer_weights, value_b), MC, "cross_attn.value.bias"},
+        {offsetof(t2s_mlp_layer_weights, proj_w), (size_t)MC * MC, "cross_attn.proj.weight"},
+        {offsetof(t2s_mlp_layer_weights, proj_b), MC, "cross_attn.proj.bias"},
+        {offsetof(t2s_mlp_layer_weights, norm2_w), MC, "norm2.weight"},
+        {offsetof(t2s_mlp_layer_weights, norm2_b), MC, "norm2.bias"},
+        {offsetof(t2s_mlp_layer_weights, mlp0_w), (size_t)MH * MC, "mlp.0.weight"},
+        {offsetof(t2s_mlp_layer_weights, mlp0_b), MH, "mlp.0.bias"},
+        {offsetof(t2s_mlp_layer_weights, mlp2_w), (size_t)MC * MH, "mlp.2.weight"},
+        {offsetof(t2s_mlp_layer_weights, mlp2_b), MC, "mlp.2.bias"},
+        {offsetof(t2s_mlp_layer_weights, pos0_w), (size_t)MH * MP, "mlp2.0.weight"},
+        {offsetof(t2s_mlp_layer_weights, pos0_b), MH, "mlp2.0.bias"},
+        {offsetof(t2s_mlp_layer_weights, pos2_w), (size_t)MP * MH, "mlp2.2.weight"},
+        {offsetof(t2s_mlp_layer_weights, pos2_b), MP, "mlp2.2.bias"},
+    };
+    for (int l = 0; l < ML; ++l)
+        for (const auto& it : items) {
+            const float* p = *reinterpret_cast<const float* const*>(reinterpret_cast<const char*>(&w->layer[l]) + it.off);
+            T2S_REQUIRE(p != nullptr, "t2s_mlp_pack: layers.%d.%s is null", l, it.name);
+            char what[96];
+            snprintf(what, sizeof what, "t2s_mlp_pack: layers.%d.%s", l, it.name);
+            if (int rc = check_device_extent(p, it.floats * sizeof(float), what)) return rc;
+        }
+    if (int rc = check_device_extent(packed, (size_t)T2S_MLP_PACKED_FLOATS * sizeof(float), "t2s_mlp_pack: packed")) return rc;
+    PackArgs a;
+    a.w = *w;
+    a.dst = packed;
+    mlp_pack_kernel<<<ML, 256, 0, (hipStream_t)stream>>>(a);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+extern "C" int t2s_mlp_forward(const float* packed, const float* x, const float* t, const float* freqs, const float* text,
+                               float* out, int B, void* stream) {
+    using namespace t2s;
+    T2S_REQUIRE(packed && x && t && freqs && out, "t2s_mlp_forward: null argument");
+    T2S_REQUIRE(B >= 0, "t2s_mlp_forward: B = %d", B);
+    if (B == 0) return T2S_OK;
+    if (int rc = check_device_extent(packed, (size_t)T2S_MLP_PACKED_FLOATS * sizeof(float), "t2s_mlp_forward: packed")) return rc;
+    if (int rc = check_device_extent(x, (size_t)B * MC * MP * sizeof(float), "t2s_mlp_forward: x")) return rc;
+    if (int rc = check_device_extent(t, (size_t)B * sizeof(float), "t2s_mlp_forward: t")) return rc;
+    if (int rc = check_device_extent(freqs, (size_t)(MC / 2) * sizeof(float), "t2s_mlp_forward: freqs")) return rc;
+    if (text)
+        if (int rc = check_device_extent(text, (size_t)B * MT * sizeof(float), "t2s_mlp_forward: text")) return rc;
+    if (int rc = check_device_extent(out, (size_t)B * MC * MP * sizeof(float), "t2s_mlp_forward: out")) return rc;
+    mlp_forward_kernel<<<B, 256, 0, (hipStream_t)stream>>>(packed, x, t, freqs, text, out);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}

@@ -1,11 +1,13 @@
-"""Mirror of the reference MLP denoiser (model/denoiser/mlp.py:49-94) -- BASELINE config 1 plumbing.
+"""Mirror of the reference MLP denoiser (model/denoiser/mlp.py:49-94) -- BASELINE configs[0].
 
-SURVEY.md 8(a) row a20 scopes this denoiser as plumbing only ("PyTorch is sufficient"): it is a
-632 K-parameter model on a (B,64,6) latent that the reference itself can no longer run end to end
-(its encoder emits 30 positions, vqvae.py:70).  So, unlike the DiT, this class evaluates with torch
-ops on whatever device its tensors live on; it is NOT part of the accelerated path and no
-throughput claim is made for it.  State-dict keys equal the reference's, including the modules it
-constructs but never uses (norm1, norm3, pos_emb, self_attn, self_attn2).
+A 632 K-parameter model on a (B,64,6) latent that the reference itself can no longer run end to end (its encoder emits 30
+positions, vqvae.py:70; SURVEY.md 8(d) prescribes the runnable form).  SURVEY 8(a) row a20 scopes it as plumbing.
+  * Inference on a GPU (no autograd): `MLP.forward` is ONE launch of the HIP kernel `t2s_mlp_forward` (csrc/t2s_mlp.hip:
+    all eight layers, one workgroup per series) on weights packed by `t2s_mlp_pack`; there is no other GPU inference path
+    (a missing library raises).
+  * Under autograd (train.py --denoiser MLP) and on CPU tensors the layers below evaluate with torch ops, as the reference.
+State-dict keys equal the reference's, including the modules it constructs but never uses (norm1, norm3, pos_emb,
+self_attn, self_attn2) and the cross attention's query / key, which cannot influence the result (see t2s.h).
 """
 from __future__ import annotations
 
@@ -15,6 +17,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import _lib as L
+
 WIDTH, POSITIONS, TEXT_DIM, HEADS = 64, 6, 128, 4
 
 
@@ -23,6 +27,17 @@ def _time_features(t: torch.Tensor, dim: int) -> torch.Tensor:
     f = torch.pow(10000, torch.linspace(0, 1, dim // 2)).to(t.device)
     arg = (t * 100.0).reshape(-1, 1) / f
     return torch.cat([torch.sin(arg), torch.cos(arg)], dim=-1)
+
+
+_FREQS = {}
+
+
+def _freqs_on(device):
+    """10000**linspace(0,1,32) evaluated by the reference's own fp32 torch ops on the host (mlp.py:12), once per device."""
+    f = _FREQS.get(device)
+    if f is None:
+        f = _FREQS[device] = torch.pow(10000, torch.linspace(0, 1, WIDTH // 2)).to(device)
+    return f
 
 
 class TimeEmbedding(nn.Module):
@@ -88,9 +103,74 @@ class MLP(nn.Module):
         self.layers = nn.ModuleList([MLPlayer() for _ in range(8)])
 
     def forward(self, input, t, text_input):
+        needs_grad = torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if input.is_cuda and not needs_grad:
+            return self._forward_hip(input, t, text_input)
         for layer in self.layers:
             input = layer(input, t, text_input)
         return input
+
+    # -- the HIP path -------------------------------------------------------------------------------------------------
+    def _hip_tensors(self):
+        """The 14 tensors per layer t2s_mlp_pack reads, in t2s_mlp_layer_weights order.  Walks the modules' own dicts
+        (dict(named_parameters()) costs 0.3 ms per call, more than the kernel); nothing is cached, so a re-assigned
+        Parameter is still seen."""
+        ts = []
+        for layer in self._modules["layers"]._modules.values():
+            m = layer._modules
+            ca, n2, mlp, mlp2 = m["cross_attn"]._modules, m["norm2"]._parameters, m["mlp"]._modules, m["mlp2"]._modules
+            for holder in (ca["value"]._parameters, ca["proj"]._parameters, n2, mlp["0"]._parameters, mlp["2"]._parameters,
+                           mlp2["0"]._parameters, mlp2["2"]._parameters):
+                ts.append(holder["weight"])
+                ts.append(holder["bias"])
+        return ts
+
+    def _packed(self, device):
+        """The transposed weights `t2s_mlp_forward` reads, re-packed whenever a parameter's storage or in-place version
+        changed (optimizer steps, load_state_dict, .to()); never cached for parameters torch keeps no version for."""
+        from .transformer import _stamp_of
+        ts = self._hip_tensors()
+        stamp = _stamp_of(ts)
+        cached = self.__dict__.get("_t2s_packed")
+        if cached is not None and stamp is not None and cached[0] == device and cached[1] == stamp:
+            return cached[2]
+        if len(self.layers) != L.MLP_LAYERS:
+            raise L.T2SError(f"t2s_mlp_forward is built for {L.MLP_LAYERS} layers, this model has {len(self.layers)}")
+        keep = []
+        w = L.MlpWeights()
+        it = iter(ts)
+        for i in range(L.MLP_LAYERS):
+            for field, key in L.MLP_LAYER_FIELDS:
+                t = next(it)
+                if t.device != device:
+                    raise L.T2SError(f"MLP parameters live on {t.device} but the input is on {device}; call model.to(device) first")
+                t = L.as_f32(t.detach())
+                keep.append(t)
+                setattr(w.layer[i], field, L.dev_ptr(t, f"layers.{i}.{key}"))
+        packed = torch.empty(L.MLP_PACKED_FLOATS, dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            L.check(L.lib().t2s_mlp_pack(w, packed.data_ptr(), L.stream_ptr(device)), "t2s_mlp_pack")
+        self.__dict__["_t2s_packed"] = (device, stamp, packed)
+        return packed
+
+    def _forward_hip(self, input, t, text_input):
+        if input.dim() != 3 or input.shape[1] != WIDTH or input.shape[2] != POSITIONS:
+            raise L.T2SError(f"MLP.forward: input must be (B,{WIDTH},{POSITIONS}), got {tuple(input.shape)}")
+        B, device = input.shape[0], input.device
+        if text_input is not None and tuple(text_input.shape) != (B, TEXT_DIM):
+            raise L.T2SError(f"MLP.forward: text_input must be ({B},{TEXT_DIM}), got {tuple(text_input.shape)}")
+        if t.numel() != B:
+            raise L.T2SError(f"MLP.forward: t must hold {B} values, got {tuple(t.shape)}")
+        packed = self._packed(device)
+        x = L.as_f32(input)
+        tf = L.as_f32(t.to(device).reshape(-1))                                   # `t * 100.0` promotes an int64 t the same way
+        text = None if text_input is None else L.as_f32(text_input.to(device))
+        out = torch.empty_like(x)
+        with torch.cuda.device(device):
+            L.check(L.lib().t2s_mlp_forward(packed.data_ptr(), L.dev_ptr(x, "input"), L.dev_ptr(tf, "t"),
+                                            L.dev_ptr(_freqs_on(device)), L.dev_ptr(text, "text_input"), out.data_ptr(), B,
+                                            L.stream_ptr(device)), "t2s_mlp_forward")
+        return out
 
 
 for _cls in (MLP, MLPlayer, TextToSeriesCrossAttention, TimeEmbedding):

@@ -159,3 +159,101 @@ def test_train_driver_mlp_denoiser_then_infer(tmp_path, monkeypatch):
     out = os.path.join(save, "generation", "ddpm_MLP_ETTh1_24_7.0_5")
     xt = np.load(os.path.join(out, "x_t.npy"))
     assert xt.shape == (16, 24, 1) and np.isfinite(xt).all()
+
+
+# ------------------------------------------------------------------ the HIP forward (csrc/t2s_mlp.hip) through the C ABI
+def _gpu_mlp(seed=2025):
+    from model.denoiser.mlp import MLP
+    m = MLP().eval()
+    m.load_state_dict(synth.make_mlp_state_dict(seed), strict=True)
+    return m.cuda()
+
+
+@pytest.mark.gpu
+def test_hip_mlp_forward_matches_reference_golden(golden_dir):
+    """a20: `MLP.forward` on a GPU without autograd = ONE launch of t2s_mlp_forward; against the vectors the reference's own
+    mlp.py produced (cond and uncond), fp32 tolerance."""
+    g = np.load(os.path.join(golden_dir, "mlp_denoiser.npz"))
+    m = _gpu_mlp()
+    x = torch.from_numpy(g["x"]).cuda()
+    t = torch.tensor([49, 20, 1, 0]).cuda()
+    text = synth.make_text_embeddings(5, 4).cuda()
+    with torch.no_grad():
+        yc, yu = m(x, t, text), m(x, t, None)
+    assert "_t2s_packed" in m.__dict__                       # the HIP path ran (its packed weights exist)
+    np.testing.assert_allclose(yc.cpu().numpy(), g["cond"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(yu.cpu().numpy(), g["uncond"], atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 32, 257])
+def test_hip_mlp_forward_vs_oracle_and_its_own_torch_path(B):
+    """Against the CPU oracle on random inputs (long and float t, with and without text), and against the mirror's torch-op
+    evaluation on the same GPU (what training runs): one arithmetic, two evaluations; rows are independent of the batch."""
+    msd = synth.make_mlp_state_dict(7)
+    m = _gpu_mlp(7)
+    rs = np.random.RandomState(B)
+    x = torch.from_numpy(rs.randn(B, 64, 6).astype(np.float32))
+    text = synth.make_text_embeddings(11, B)
+    for t in (torch.from_numpy(rs.randint(0, 50, size=B)), torch.from_numpy(rs.rand(B).astype(np.float32))):
+        for tx in (None, text):
+            with torch.no_grad():
+                y = m(x.cuda(), t.cuda(), None if tx is None else tx.cuda())
+                ref = O.mlp_denoiser_forward(msd, x, t, tx)
+            scale = max(1.0, float(ref.abs().max()))
+            assert float((y.cpu() - ref).abs().max()) < 2e-5 * scale
+            xg = x.cuda().requires_grad_(True)                  # autograd wanted -> the torch-op layers
+            y_t = m(xg, t.cuda(), None if tx is None else tx.cuda())
+            assert y_t.requires_grad and float((y - y_t.detach()).abs().max()) < 2e-5 * scale
+            if B > 1:                                           # a row's result does not depend on its batch
+                with torch.no_grad():
+                    y1 = m(x[:1].cuda(), t[:1].cuda(), None if tx is None else tx[:1].cuda())
+                assert torch.equal(y1, y[:1])
+
+
+@pytest.mark.gpu
+def test_hip_mlp_repacks_after_weight_changes_and_checks_extents():
+    from t2ms_amd import _lib as L
+    m = _gpu_mlp(3)
+    x, t = torch.randn(4, 64, 6, device="cuda"), torch.tensor([5, 6, 7, 8], device="cuda")
+    text = synth.make_text_embeddings(1, 4).cuda()
+    with torch.no_grad():
+        y0 = m(x, t, text)
+        m.layers[3].mlp[0].weight.mul_(1.5)                     # in place: the version counter moves, the mirror re-packs
+        y1 = m(x, t, text)
+    xg = x.clone().requires_grad_(True)
+    assert not torch.allclose(y0, y1) and float((y1 - m(xg, t, text).detach()).abs().max()) < 2e-5 * max(1.0, float(y1.abs().max()))
+    # query / key cannot influence the result (the six keys are one row): scrambling them changes nothing
+    with torch.no_grad():
+        m.layers[0].cross_attn.query.weight.normal_()
+        m.layers[0].cross_attn.key.weight.normal_()
+        assert float((m(x, t, text) - m(xg, t, text).detach()).abs().max()) < 2e-5 * max(1.0, float(y1.abs().max()))
+    # the C entry points: a short packed buffer, a short input and out == x
+    lib = L.lib()
+    packed = m.__dict__["_t2s_packed"][2]
+    tz = torch.zeros(4, device="cuda")
+    fr = torch.pow(10000, torch.linspace(0, 1, 32)).cuda()
+    out = torch.empty_like(x)
+    # (private hipMallocs: torch's caching allocator hides the end of a small tensor inside a 2 MB segment)
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes, hip.hipFree.argtypes = [C.POINTER(C.c_void_p), C.c_size_t], [C.c_void_p]
+    short_packed, short_x = C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(short_packed), (L.MLP_PACKED_FLOATS - 8) * 4) == 0
+    assert hip.hipMalloc(C.byref(short_x), 3 * 384 * 4) == 0
+    try:
+        assert lib.t2s_mlp_forward(short_packed.value, x.data_ptr(), tz.data_ptr(), fr.data_ptr(), None, out.data_ptr(), 4, None) == -1
+        assert b"packed" in lib.t2s_last_error() and b"allocation ends" in lib.t2s_last_error()
+        assert lib.t2s_mlp_forward(packed.data_ptr(), short_x.value, tz.data_ptr(), fr.data_ptr(), None, out.data_ptr(), 4, None) == -1
+        assert b": x" in lib.t2s_last_error()
+    finally:
+        hip.hipFree(short_packed)
+        hip.hipFree(short_x)
+    w = L.MlpWeights()
+    assert lib.t2s_mlp_pack(w, packed.data_ptr(), None) == -1 and b"null" in lib.t2s_last_error()
+    assert lib.t2s_mlp_forward(packed.data_ptr(), x.data_ptr(), tz.data_ptr(), fr.data_ptr(), None, out.data_ptr(), 0, None) == 0
+    L.check(lib.t2s_mlp_forward(packed.data_ptr(), x.data_ptr(), tz.data_ptr(), fr.data_ptr(), None, out.data_ptr(), 4, None))
+    xa = x.clone()
+    L.check(lib.t2s_mlp_forward(packed.data_ptr(), xa.data_ptr(), tz.data_ptr(), fr.data_ptr(), None, xa.data_ptr(), 4, None))
+    torch.cuda.synchronize()
+    assert torch.equal(xa, out)
