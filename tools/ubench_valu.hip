@@ -8,9 +8,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-enum { OP_FMA, OP_SUB, OP_EXP, OP_CVTPK, OP_PKADD, OP_PKMUL, OP_AND, OP_LSHL, OP_MAX3, OP_MOV, OP_RCP, N_OPS };
+enum { OP_FMA, OP_SUB, OP_EXP, OP_CVTPK, OP_PKADD, OP_PKMUL, OP_AND, OP_LSHL, OP_MAX3, OP_MOV, OP_RCP, OP_DOT2C, N_OPS };
 static const char* op_name[N_OPS] = {"v_fma_f32", "v_sub_f32", "v_exp_f32", "v_cvt_pk_bf16_f32", "v_pk_add_f32", "v_pk_mul_f32",
-                                     "v_and_b32", "v_lshlrev_b32", "v_max3_f32", "v_mov_b32", "v_rcp_f32"};
+                                     "v_and_b32", "v_lshlrev_b32", "v_max3_f32", "v_mov_b32", "v_rcp_f32", "v_dot2c_f32_bf16"};
 
 template <int OP>
 __device__ __forceinline__ void one(float& a, float& b, f32x2& p, float c) {
@@ -25,6 +25,7 @@ __device__ __forceinline__ void one(float& a, float& b, f32x2& p, float c) {
     if (OP == OP_MAX3) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
     if (OP == OP_MOV) asm volatile("v_mov_b32 %0, %0" : "+v"(a));
     if (OP == OP_RCP) asm volatile("v_rcp_f32 %0, %0" : "+v"(a));
+    if (OP == OP_DOT2C) asm volatile("v_dot2c_f32_bf16 %0, -1.0, %1" : "+v"(a) : "v"(b));   // a += (-1, 0) . (b.lo, b.hi): the x3 split's residual
 }
 
 template <int OP, int MF, int NM, int NV>
@@ -246,8 +247,8 @@ int main() {
     }
     op_rows<OP_FMA>(d, c); op_rows<OP_SUB>(d, c); op_rows<OP_EXP>(d, c); op_rows<OP_CVTPK>(d, c); op_rows<OP_PKADD>(d, c);
     op_rows<OP_PKMUL>(d, c); op_rows<OP_AND>(d, c); op_rows<OP_LSHL>(d, c); op_rows<OP_MAX3>(d, c); op_rows<OP_MOV>(d, c);
-    op_rows<OP_RCP>(d, c);
-    het_row<OP_SUB>(d); het_row<OP_FMA>(d); het_row<OP_EXP>(d); het_row<OP_CVTPK>(d); het_row<OP_PKADD>(d); het_row<OP_LSHL>(d);
+    op_rows<OP_RCP>(d, c); op_rows<OP_DOT2C>(d, c);
+    het_row<OP_SUB>(d); het_row<OP_FMA>(d); het_row<OP_EXP>(d); het_row<OP_CVTPK>(d); het_row<OP_PKADD>(d); het_row<OP_LSHL>(d); het_row<OP_DOT2C>(d);
     phase_rows<48, 240>(d);
     phase_rows<48, 120>(d);
     // true dependencies (VALU phase reads the matrix results, matrix phase reads the VALU results), same work per SIMD
