@@ -732,10 +732,12 @@ extern "C" int t2s_vae_encode_backward(t2s_vae* h, const float* x, const float* 
     // row blocks: floats per row, in the order the pointers are handed out below
     const size_t per_row = 256 + 384 + 128 + 128 + 128 + 128 + (size_t)NR * (384 + R + 128 + R);
     if (rows > h->bwd_rows || B > h->bwd_series) {
-        if (h->bwd) T2S_HIP_CHECK(hipFree(h->bwd));
-        h->bwd = nullptr;
         const size_t r2 = rows > h->bwd_rows ? rows : h->bwd_rows;
         const int b2 = B > h->bwd_series ? B : h->bwd_series;
+        if (h->bwd) T2S_HIP_CHECK(hipFree(h->bwd));
+        h->bwd = nullptr;
+        h->bwd_rows = 0;          // (a failed hipMalloc below must not leave sizes that vouch for a NULL buffer)
+        h->bwd_series = 0;
         T2S_HIP_CHECK(hipMalloc((void**)&h->bwd, (r2 * per_row + (size_t)b2 * VAE_P1 + 128 * 128 + 128) * sizeof(float)));
         h->bwd_rows = r2;
         h->bwd_series = b2;
@@ -753,6 +755,7 @@ extern "C" int t2s_vae_encode_backward(t2s_vae* h, const float* x, const float* 
         if (need > h->wg_floats) {
             if (h->wg) T2S_HIP_CHECK(hipFree(h->wg));
             h->wg = nullptr;
+            h->wg_floats = 0;
             T2S_HIP_CHECK(hipMalloc((void**)&h->wg, need * sizeof(float)));
             h->wg_floats = need;
         }

@@ -177,7 +177,10 @@ class Encoder(_Codec):
         if not inputs.is_cuda:
             raise L.T2SError("Encoder.forward: input must live on a GPU; the HIP path has no CPU fallback")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if self._hip_backward_ok(inputs.shape[-1]) and os.environ.get("T2S_ENCODER_TORCH_AUTOGRAD", "0") in ("", "0"):
+            # (a series that itself requires a gradient -- never the case in train.py:104-106, where it is data -- takes the
+            # torch-op forward: t2s_vae_encode_backward produces parameter gradients only)
+            if (self._hip_backward_ok(inputs.shape[-1]) and not inputs.requires_grad
+                    and os.environ.get("T2S_ENCODER_TORCH_AUTOGRAD", "0") in ("", "0")):
                 return _EncodeFn.apply(self, inputs, *self._grad_params())
             return self._forward_autograd(inputs)
         return self._forward_hip(inputs)

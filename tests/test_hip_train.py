@@ -678,6 +678,16 @@ def test_encoder_backward_refuses_what_it_does_not_cover(dev):
     g = L.VaeEncGrads()
     rc = L.lib().t2s_vae_encode_backward(h, x.data_ptr(), z.detach().data_ptr(), None, C.byref(g), 2, 24, None)
     assert rc == -1 and "unsupported" in L.lib().t2s_last_error().decode()
+    # a series that itself asks for a gradient (never in train.py, where it is data) is not silently given none: the default
+    # shape then takes the torch-op forward too
+    vd = vqvae(types.SimpleNamespace(block_hidden_size=128, num_residual_layers=2, res_hidden_size=256, embedding_dim=64)).to(dev)
+    xg = synth.make_series(2, 2, 24).to(dev).requires_grad_(True)
+    zg, _ = vd.encoder(xg)
+    assert type(zg.grad_fn).__name__ != "_EncodeFnBackward"
+    zg.sum().backward()
+    assert xg.grad is not None and float(xg.grad.abs().max()) > 0
+    zd, _ = vd.encoder(xg.detach())
+    assert type(zd.grad_fn).__name__ == "_EncodeFnBackward" and float((zd - zg).abs().max()) < 1e-5
 
 
 def test_train_driver_with_unfrozen_encoder(dev, tmp_path, monkeypatch):
