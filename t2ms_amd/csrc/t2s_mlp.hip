@@ -83,6 +83,10 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// EAGER: every weight of a layer is requested at the layer's start and held in registers (450 of them: one workgroup per CU) --
+// the latency form, for launches that do not fill the chip anyway; otherwise each phase fetches its own weights with a short
+// unroll (84 registers, several workgroups per CU cover each other's round trips) -- the throughput form.
+template <bool EAGER>
 __global__ __launch_bounds__(256) void mlp_forward_kernel(const float* __restrict__ packed, const float* __restrict__ x,
                                                           const float* __restrict__ t, const float* __restrict__ freqs,
                                                           const float* __restrict__ text, float* __restrict__ out) {
@@ -107,16 +111,23 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(const float* __restric
         // Every weight this thread needs in the layer is requested HERE, before the first dependent instruction: the layer
         // is a chain of short phases and a phase that starts by fetching its weights pays an L2 round trip per unrolled
         // group (measured: 24 us per layer that way, 190 us per forward whatever the batch).
-        float wv1[MC], wv2[MC], wvv[32], wvp[16];
+        constexpr int UNR = EAGER ? MC / 4 : 4;
+        float wv1[EAGER ? MC : 1], wv2[EAGER ? MC : 1], wvv[EAGER ? 32 : 1], wvp[EAGER ? 16 : 1];
+        const float* w1p = w + O_W1 + tid;                       // fc1 column of hidden unit tid (stride MH)
+        const float* w2p = w + O_W2 + 64 * wave * MC + lane;     // fc2: this wave's quarter, channel lane (stride MC)
+        const float* wvq = w + O_WV + 32 * wave * MC + lane;
+        const float* wpq = w + O_WP + 16 * wave * MC + lane;
+        if constexpr (EAGER) {
 #pragma unroll
-        for (int c = 0; c < MC; ++c) wv1[c] = w[O_W1 + c * MH + tid];                       // fc1 column of hidden unit tid
+            for (int c = 0; c < MC; ++c) wv1[c] = w1p[c * MH];
 #pragma unroll
-        for (int jj = 0; jj < MC; ++jj) wv2[jj] = w[O_W2 + (64 * wave + jj) * MC + lane];   // fc2: this wave's quarter, channel lane
-        if (text != nullptr) {
+            for (int jj = 0; jj < MC; ++jj) wv2[jj] = w2p[jj * MC];
+            if (text != nullptr) {
 #pragma unroll
-            for (int kk = 0; kk < 32; ++kk) wvv[kk] = w[O_WV + (32 * wave + kk) * MC + lane];
+                for (int kk = 0; kk < 32; ++kk) wvv[kk] = wvq[kk * MC];
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) wvp[kk] = w[O_WP + (16 * wave + kk) * MC + lane];
+                for (int kk = 0; kk < 16; ++kk) wvp[kk] = wpq[kk * MC];
+            }
         }
         const float b1 = w[O_B1 + tid], b2 = w[O_B2 + lane], g = w[O_LG + lane], be = w[O_LB + lane];
         const float bv = w[O_BV + lane], bp = w[O_BP + lane];
@@ -132,15 +143,25 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(const float* __restric
         if (text != nullptr) {
             // v = value(text): channel = lane, the 128 inputs in four quarters (one per wave)
             float acc = 0.f;
+            if constexpr (EAGER) {
 #pragma unroll
-            for (int kk = 0; kk < 32; ++kk) acc = fmaf(wvv[kk], txt[32 * wave + kk], acc);
+                for (int kk = 0; kk < 32; ++kk) acc = fmaf(wvv[kk], txt[32 * wave + kk], acc);
+            } else {
+#pragma unroll 8
+                for (int kk = 0; kk < 32; ++kk) acc = fmaf(wvq[kk * MC], txt[32 * wave + kk], acc);
+            }
             red[wave][0][lane] = acc;
             __syncthreads();
             if (wave == 0) vs[lane] = bv + ((red[0][0][lane] + red[1][0][lane]) + (red[2][0][lane] + red[3][0][lane]));
             __syncthreads();
             acc = 0.f;
+            if constexpr (EAGER) {
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) acc = fmaf(wvp[kk], vs[16 * wave + kk], acc);
+                for (int kk = 0; kk < 16; ++kk) acc = fmaf(wvp[kk], vs[16 * wave + kk], acc);
+            } else {
+#pragma unroll 8
+                for (int kk = 0; kk < 16; ++kk) acc = fmaf(wpq[kk * MC], vs[16 * wave + kk], acc);
+            }
             red[wave][1][lane] = acc;
             __syncthreads();
             if (wave == 0) as[lane] = bp + ((red[0][1][lane] + red[1][1][lane]) + (red[2][1][lane] + red[3][1][lane]));
@@ -161,15 +182,18 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(const float* __restric
             float acc[MP];
 #pragma unroll
             for (int p = 0; p < MP; ++p) acc[p] = b1;
-#pragma unroll
+#pragma unroll UNR
             for (int c = 0; c < MC; c += 4) {
+                float wq[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wq[e] = EAGER ? wv1[EAGER ? c + e : 0] : w1p[(c + e) * MH];
 #pragma unroll
                 for (int p = 0; p < MP; ++p) {
                     const f32x4 h4 = *reinterpret_cast<const f32x4*>(&hs[p][c]);
-                    acc[p] = fmaf(wv1[c], h4.x, acc[p]);
-                    acc[p] = fmaf(wv1[c + 1], h4.y, acc[p]);
-                    acc[p] = fmaf(wv1[c + 2], h4.z, acc[p]);
-                    acc[p] = fmaf(wv1[c + 3], h4.w, acc[p]);
+                    acc[p] = fmaf(wq[0], h4.x, acc[p]);
+                    acc[p] = fmaf(wq[1], h4.y, acc[p]);
+                    acc[p] = fmaf(wq[2], h4.z, acc[p]);
+                    acc[p] = fmaf(wq[3], h4.w, acc[p]);
                 }
             }
 #pragma unroll
@@ -181,15 +205,18 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(const float* __restric
             float acc[MP];
 #pragma unroll
             for (int p = 0; p < MP; ++p) acc[p] = 0.f;
-#pragma unroll
+#pragma unroll UNR
             for (int jj = 0; jj < MC; jj += 4) {
+                float wq[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wq[e] = EAGER ? wv2[EAGER ? jj + e : 0] : w2p[(jj + e) * MC];
 #pragma unroll
                 for (int p = 0; p < MP; ++p) {
                     const f32x4 h4 = *reinterpret_cast<const f32x4*>(&hid[p][64 * wave + jj]);
-                    acc[p] = fmaf(wv2[jj], h4.x, acc[p]);
-                    acc[p] = fmaf(wv2[jj + 1], h4.y, acc[p]);
-                    acc[p] = fmaf(wv2[jj + 2], h4.z, acc[p]);
-                    acc[p] = fmaf(wv2[jj + 3], h4.w, acc[p]);
+                    acc[p] = fmaf(wq[0], h4.x, acc[p]);
+                    acc[p] = fmaf(wq[1], h4.y, acc[p]);
+                    acc[p] = fmaf(wq[2], h4.z, acc[p]);
+                    acc[p] = fmaf(wq[3], h4.w, acc[p]);
                 }
             }
 #pragma unroll
@@ -293,7 +320,16 @@ extern "C" int t2s_mlp_forward(const float* packed, const float* x, const float*
     if (text)
         if (int rc = check_device_extent(text, (size_t)B * MT * sizeof(float), "t2s_mlp_forward: text")) return rc;
     if (int rc = check_device_extent(out, (size_t)B * MC * MP * sizeof(float), "t2s_mlp_forward: out")) return rc;
-    mlp_forward_kernel<<<B, 256, 0, (hipStream_t)stream>>>(packed, x, t, freqs, text, out);
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    if (B <= n_cu)      // one round of workgroups either way: the latency form (same arithmetic, same bits)
+        mlp_forward_kernel<true><<<B, 256, 0, (hipStream_t)stream>>>(packed, x, t, freqs, text, out);
+    else
+        mlp_forward_kernel<false><<<B, 256, 0, (hipStream_t)stream>>>(packed, x, t, freqs, text, out);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }

@@ -29,7 +29,7 @@ def main():
     m.load_state_dict(synth.make_mlp_state_dict(2025), strict=True)
     m = m.to(dev)
     out = {}
-    for B in (32, 64, 1024):
+    for B in (32, 64, 256, 1024):
         x = torch.randn(B, 64, 6, device=dev)
         t = torch.full((B,), 25, device=dev)
         text = synth.make_text_embeddings(1, B).to(dev)
