@@ -437,11 +437,17 @@ void t2s_sampler_destroy(t2s_sampler* s);
  *          handles of one device concurrently.  Every run that opens a stream capture (use_graph) or uses the library's
  *          stream pool (several lanes, or stream NULL with use_graph) holds a per-device lock for the length of its
  *          ENQUEUE (host work of a few ms; the GPU work stays asynchronous), and t2s_sampler_create / _destroy take the
- *          same lock: they allocate, copy synchronously and synchronise, and the library does not rely on such calls
- *          being harmless to another thread's open capture (DESIGN.md 4.5 says what is known about that and what is
- *          inferred).  What the lock cannot cover is the CALLER's own allocations / synchronous copies / device
- *          synchronisations on other threads while a run is being enqueued, and a `stream` handed to a single-lane run,
- *          which -- like any HIP stream under capture -- must not be used by another thread meanwhile.
+ *          same lock.  Why (measured): while ANY thread has a stream capture open on the device, HIP
+ *          answers a synchronous hipMemcpy and a hipDeviceSynchronize from any other thread with an error
+ *          (hipErrorStreamCaptureImplicit / hipErrorStreamCaptureUnsupported) and INVALIDATES the open capture, thread-
+ *          local capture mode notwithstanding.  The library itself issues neither outside that lock (t2s_sampler_create
+ *          uploads on a non-blocking stream of its own; no entry point copies synchronously), and the Python mirrors
+ *          build / grow / destroy their handles under the same per-device lock (t2ms_amd._lib.device_lock).  What no lock
+ *          of the library can cover is the CALLER's own device-wide calls on other threads while a run is being enqueued
+ *          -- hipDeviceSynchronize (torch.cuda.synchronize()), synchronous hipMemcpy -- and a `stream` handed to a
+ *          single-lane run, which -- like any HIP stream under capture -- must not be used by another thread meanwhile.
+ *          (Stream-ordered work of other threads, including torch's default-stream kernels, asynchronous copies and
+ *          stream synchronisations, is fine: tools/stress_threads.py runs it against open captures by the thousand.)
  *          The pool is created and calibrated by the first t2s_sampler_create on a device (not by a run), so a run
  *          never allocates or synchronises for it.
  * Memory:  t2s_sampler_create also allocates a whole-run adaLN table (steps x (batch + 1) x 3072 floats: 3.2 GB at

@@ -217,5 +217,26 @@ def as_f32(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
+_DEVICE_LOCKS = {}
+
+
+def device_lock(device) -> "threading.RLock":
+    """Per device, re-entrant: held by everything in this package that allocates, frees, copies synchronously or synchronises
+    the DEVICE -- building / growing / destroying a handle, a Sampler's create / stage / run / destroy -- so that none of it
+    runs while another thread's sampler run has a stream capture open.  HIP answers a device-wide synchronous call from ANY
+    thread (hipDeviceSynchronize = torch.cuda.synchronize(), a synchronous hipMemcpy) with an error while a capture is open
+    on the device, thread-local capture mode notwithstanding, and that error invalidates the capture (reproduced in round 5:
+    tools/stress_threads.py --unserialised).  The caller's OWN device-wide calls in other threads are not
+    covered: see include/t2s.h "Threads"."""
+    import threading
+    return _DEVICE_LOCKS.setdefault(str(torch.device(device)), threading.RLock())
+
+
+def destroy_locked(fn_name: str, device_key: str, ptr) -> None:
+    """Finalizer body of the handle owners: t2s_*_destroy frees device memory -- under the device's lock (device_lock)."""
+    with device_lock(device_key):
+        getattr(lib(), fn_name)(ptr)
+
+
 def stream_ptr(device=None) -> int:
     return torch.cuda.current_stream(device).cuda_stream

@@ -451,7 +451,8 @@ bool streams_overlap(hipStream_t a, hipStream_t b, unsigned long long* stamps_de
         spin_kernel<<<1, 64, 0, a>>>(40000ull, stamps_dev);          // 400 us at the 100 MHz wall clock
         spin_kernel<<<1, 64, 0, b>>>(40000ull, stamps_dev + 2);
         if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
-        if (hipMemcpy(h, stamps_dev, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return false;
+        // (read back on stream a, not with a legacy-stream hipMemcpy: see t2s_sampler_create)
+        if (hipMemcpyAsync(h, stamps_dev, sizeof(h), hipMemcpyDeviceToHost, a) != hipSuccess || hipStreamSynchronize(a) != hipSuccess) return false;
         if (h[2] < h[1] && h[0] < h[3]) return true;
     }
     return false;
@@ -464,6 +465,19 @@ int g_lane_pool_concurrent[16] = {};      // per device: mutually concurrent str
 // capture, or hipErrorStreamCaptureIsolation).  A run that uses pool streams holds this lock from its first event to its
 // join: the enqueue of a run is host work of a few ms, the GPU side stays asynchronous.
 std::recursive_mutex g_pool_use[16];     // recursive: a failing t2s_sampler_create destroys its half-built sampler under the lock
+
+// one non-blocking stream per device for the library's own set-up work (t2s_sampler_create); see there
+hipStream_t setup_stream(int dev) {
+    static hipStream_t st[16] = {};
+    static std::mutex guard;
+    std::lock_guard<std::mutex> lock(guard);
+    if (dev < 0 || dev >= 16) return nullptr;
+    if (!st[dev] && hipStreamCreateWithFlags(&st[dev], hipStreamNonBlocking) != hipSuccess) {
+        st[dev] = nullptr;
+        (void)hipGetLastError();
+    }
+    return st[dev];
+}
 
 hipStream_t* lane_streams() {
     constexpr int ML = t2s_sampler::MAX_LANES;
@@ -592,7 +606,9 @@ extern "C" int t2s_sampler_create(t2s_dit* dit, t2s_vae* vae, const t2s_sample_c
     int cur_dev = 0;
     T2S_HIP_CHECK(hipGetDevice(&cur_dev));
     T2S_REQUIRE(cur_dev >= 0 && cur_dev < 16, "t2s_sampler_create: device %d", cur_dev);
+#ifndef T2S_DIAG_UNSERIALISED   // (diagnosis build of tools/stress_threads.py --unserialised: round 4's locking)
     std::lock_guard<std::recursive_mutex> pool_lock(g_pool_use[cur_dev]);
+#endif
     t2s_sampler* s = new t2s_sampler();
     s->dit = dit; s->vae = vae; s->cfg = *cfg;
     s->cfg.ddpm_coef = nullptr; s->cfg.t_values = nullptr;  // host pointers are not retained
@@ -618,17 +634,25 @@ extern "C" int t2s_sampler_create(t2s_dit* dit, t2s_vae* vae, const t2s_sample_c
         s->mod_table = nullptr;       // an optimisation only: a device too full for it keeps the per-step kernel
         (void)hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpy(s->tvals, cfg->t_values, T * sizeof(float), hipMemcpyHostToDevice);
+    // Uploads and the table kernel run on a NON-BLOCKING stream of the library's own, never on the legacy default stream: an
+    // operation on the legacy stream implicitly joins every blocking stream of the device, and HIP refuses it
+    // (hipErrorStreamCaptureImplicit, "operation would make the legacy stream depend on a capturing blocking stream") while
+    // ANY thread has a capture open -- invalidating that capture.  That was the round-4 two-thread failure (reproduced in
+    // round 5 with the serialisation taken away, tools/stress_threads.py --unserialised).
+    hipStream_t setup = setup_stream(cur_dev);
+    if (e == hipSuccess && !setup) e = hipErrorUnknown;
+    if (e == hipSuccess) e = hipMemcpyAsync(s->tvals, cfg->t_values, T * sizeof(float), hipMemcpyHostToDevice, setup);
     if (e == hipSuccess && cfg->mode == T2S_MODE_DDPM)
-        e = hipMemcpy(s->coef, cfg->ddpm_coef, T * 3 * sizeof(float), hipMemcpyHostToDevice);
+        e = hipMemcpyAsync(s->coef, cfg->ddpm_coef, T * 3 * sizeof(float), hipMemcpyHostToDevice, setup);
+    if (e == hipSuccess) e = hipStreamSynchronize(setup);      // the host tables may go away when the call returns
     if (e != hipSuccess) {
         set_error("t2s_sampler_create: allocation/upload failed: %s", hipGetErrorString(e));
         t2s_sampler_destroy(s);
         return T2S_E_HIP;
     }
     // time-embedding table for every loop index (transformer.py:30-40 applied to t_values)
-    int rc = t2s_time_embedding(dit, s->tvals, s->temb_table, cfg->steps, nullptr);
-    if (rc == T2S_OK && hipStreamSynchronize(nullptr) != hipSuccess) {
+    int rc = t2s_time_embedding(dit, s->tvals, s->temb_table, cfg->steps, setup);
+    if (rc == T2S_OK && hipStreamSynchronize(setup) != hipSuccess) {
         set_error("t2s_sampler_create: time-embedding table failed");
         rc = T2S_E_HIP;
     }
@@ -674,7 +698,9 @@ extern "C" void t2s_sampler_destroy(t2s_sampler* s) {
     if (!s) return;
     int cur_dev = 0;
     std::unique_lock<std::recursive_mutex> pool_lock;  // hipFree synchronises the device: not inside another thread's capture
+#ifndef T2S_DIAG_UNSERIALISED
     if (hipGetDevice(&cur_dev) == hipSuccess && cur_dev >= 0 && cur_dev < 16) pool_lock = std::unique_lock<std::recursive_mutex>(g_pool_use[cur_dev]);
+#endif
     drop_graph(s);
     for (int l = 0; l < t2s_sampler::MAX_LANES; ++l)
         if (s->ev_join[l]) (void)hipEventDestroy(s->ev_join[l]);

@@ -610,7 +610,10 @@ extern "C" int t2s_vae_create(const t2s_vae_weights* w, t2s_vae** out) {
     }
     size_t off = 0;
     for (auto& it : items) {
-        e = hipMemcpy(h->arena + off, it.src, it.n * sizeof(float), hipMemcpyDeviceToDevice);
+        // (asynchronous on the default stream -- ordered behind whatever the caller's framework enqueued there to produce the
+        // tensors -- and ONE synchronisation below; a synchronous hipMemcpy is what HIP refuses while another thread has a
+        // stream capture open)
+        e = hipMemcpyAsync(h->arena + off, it.src, it.n * sizeof(float), hipMemcpyDeviceToDevice, nullptr);
         if (e != hipSuccess) {
             set_error("t2s_vae_create: weight copy failed: %s", hipGetErrorString(e));
             t2s_vae_destroy(h);
@@ -618,6 +621,12 @@ extern "C" int t2s_vae_create(const t2s_vae_weights* w, t2s_vae** out) {
         }
         *it.dst = h->arena + off;
         off += r64(it.n);
+    }
+    e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) {
+        set_error("t2s_vae_create: weight copy failed: %s", hipGetErrorString(e));
+        t2s_vae_destroy(h);
+        return T2S_E_HIP;
     }
     h->has_encoder = enc;
     h->has_decoder = dec;

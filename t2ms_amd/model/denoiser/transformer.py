@@ -153,7 +153,8 @@ class _DitHandle:
         self.keep = keep
         self.max_seqs = max_seqs
         L.check(L.lib().t2s_dit_create(C.byref(weights), max_seqs, C.byref(self.ptr)), "t2s_dit_create")
-        self._fin = weakref.finalize(self, L.lib().t2s_dit_destroy, self.ptr)
+        dev = f"cuda:{torch.cuda.current_device()}"          # created under torch.cuda.device(device)
+        self._fin = weakref.finalize(self, L.destroy_locked, "t2s_dit_destroy", dev, self.ptr)
 
     def close(self):
         self._fin()
@@ -253,14 +254,17 @@ class Transformer(nn.Module):
         w, keep, stamp = self._weights_struct(device)
         h = self.__dict__.get("_t2s_h")
         if h is None or self.__dict__.get("_t2s_dev") != device or h.max_seqs < n_seqs:
-            if h is not None:
-                h.close()
-            cap = max(n_seqs, h.max_seqs if h is not None else 0)
-            if headroom:
-                cap = max(cap, (n_seqs + n_seqs // 8 + 63) // 64 * 64)
-            torch.cuda.synchronize(device)
-            with torch.cuda.device(device):
-                h = _DitHandle(w, keep, cap)
+            # a device synchronisation, frees and allocations: under the package's per-device lock, i.e. never while another
+            # thread's sampler run has a capture open (HIP would fail this call AND invalidate that capture, _lib.device_lock)
+            with L.device_lock(device):
+                if h is not None:
+                    h.close()
+                cap = max(n_seqs, h.max_seqs if h is not None else 0)
+                if headroom:
+                    cap = max(cap, (n_seqs + n_seqs // 8 + 63) // 64 * 64)
+                torch.cuda.synchronize(device)
+                with torch.cuda.device(device):
+                    h = _DitHandle(w, keep, cap)
             self.__dict__["_t2s_h"], self.__dict__["_t2s_dev"], self.__dict__["_t2s_stamp"] = h, device, stamp
             self.__dict__.pop("_t2s_math_applied", None)
         elif stamp is None or self.__dict__.get("_t2s_stamp") != stamp:
@@ -270,7 +274,7 @@ class Transformer(nn.Module):
             self.__dict__["_t2s_stamp"] = stamp
         math = self.__dict__.get("_t2s_math", "f32")
         if self.__dict__.get("_t2s_math_applied") != math:
-            with torch.cuda.device(device):
+            with L.device_lock(device), torch.cuda.device(device):       # (first bf16x3 use allocates and synchronises)
                 L.check(L.lib().t2s_dit_set_math(h.ptr, L.MATH_BF16X3 if math == "bf16x3" else L.MATH_F32),
                         "t2s_dit_set_math")
             self.__dict__["_t2s_math_applied"] = math

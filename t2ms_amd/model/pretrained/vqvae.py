@@ -55,7 +55,7 @@ class _VaeHandle:
         torch.cuda.synchronize(device)
         with torch.cuda.device(device):
             L.check(L.lib().t2s_vae_create(C.byref(w), C.byref(self.ptr)), "t2s_vae_create")
-        self._fin = weakref.finalize(self, L.lib().t2s_vae_destroy, self.ptr)
+        self._fin = weakref.finalize(self, L.destroy_locked, "t2s_vae_destroy", str(torch.device(device)), self.ptr)
 
     def close(self):
         self._fin()
@@ -90,11 +90,12 @@ class _Codec(nn.Module):
         shape = (str(device),) + tuple(tuple(t.shape) for t in ts)
         h = self.__dict__.get("_t2s_h")
         if h is None or self.__dict__.get("_t2s_shape") != shape:
-            if h is not None:
-                h.close()
-            w, keep = self._weights_struct()
-            h = _VaeHandle(w, device)
-            del keep  # the library made its own copies
+            with L.device_lock(device):       # frees, allocations, a stream synchronisation: not inside another thread's capture
+                if h is not None:
+                    h.close()
+                w, keep = self._weights_struct()
+                h = _VaeHandle(w, device)
+                del keep  # the library made its own copies
             self.__dict__["_t2s_h"], self.__dict__["_t2s_stamp"], self.__dict__["_t2s_shape"] = h, stamp, shape
         elif stamp is None or self.__dict__.get("_t2s_stamp") != stamp:
             # same tensors' shapes, new contents (an optimizer step on a trainable encoder, load_state_dict): re-copy into the

@@ -49,17 +49,13 @@ def loop_t_values(backbone: str, steps: int) -> torch.Tensor:
 
 
 _STREAMS = {}
-_RUN_LOCKS = {}          # per device: the Samplers of a process share one capture stream (below), so one run enqueues at a time
 
 
 def _run_lock(device) -> "threading.RLock":
-    """Per device, re-entrant.  Held for EVERYTHING a Sampler does on the GPU -- building its handle and C sampler
-    (allocations, synchronous copies, a device synchronize), staging inputs, the run itself: while one thread's run has a
-    stream capture open, another thread's allocation / synchronous copy / device synchronize is exactly the kind of call HIP
-    may answer by invalidating that capture (thread-local capture mode allows it on paper; a two-thread test failed once in
-    a few runs until the whole sequence was serialised).  Foreign GPU work of other threads is not covered."""
-    import threading
-    return _RUN_LOCKS.setdefault(str(torch.device(device)), threading.RLock())
+    """The package's per-device lock (_lib.device_lock): held for EVERYTHING a Sampler does on the GPU -- building its handle
+    and C sampler (allocations, copies, a device synchronize), staging inputs, the run itself.  Foreign GPU work of other
+    threads is not covered."""
+    return L.device_lock(device)
 
 
 def _sampler_stream(device) -> "torch.cuda.Stream":
@@ -75,7 +71,7 @@ def _sampler_stream(device) -> "torch.cuda.Stream":
 
 def _destroy_locked(device_key, ptr):
     """t2s_sampler_destroy frees device memory (a device-wide synchronisation): not while another thread's run is capturing."""
-    with _RUN_LOCKS.setdefault(device_key, __import__("threading").RLock()):
+    with L.device_lock(device_key):
         L.lib().t2s_sampler_destroy(ptr)
 
 

@@ -20,7 +20,25 @@ from model.denoiser.transformer import Transformer  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=150)
+    ap.add_argument("--unserialised", action="store_true",
+                    help="DIAGNOSIS: round 4's locking -- only Sampler.run takes the per-device lock, creating / staging / destroying "
+                         "samplers run concurrently with the other thread's open capture (use with T2S_LIB = a library built with "
+                         "-DT2S_DIAG_UNSERIALISED: tools/variant.sh t2s_sampler diag_unser -DT2S_DIAG_UNSERIALISED).  Records WHICH "
+                         "call fails with WHICH HIP error when the serialisation of DESIGN 4.5 is taken away.")
+    ap.add_argument("--fresh-handles", type=int, default=0, metavar="N",
+                    help="every N-th round builds a new Transformer and a new LA-VAE (their HIP handles are created inside the loop)")
     a = ap.parse_args()
+    if a.unserialised:
+        import contextlib
+        from t2ms_amd import sampler as S
+        real_lock = S._run_lock
+        S._run_lock = lambda device: contextlib.nullcontext()
+
+        def run_with_lock(self, text, x_T=None, noise=None, decode=True, trace=False):
+            with real_lock(self.device):
+                return self._run_locked(text, x_T, noise, decode, trace)
+        S.Sampler.run = run_with_lock
+        S._destroy_locked = lambda device_key, ptr: S.L.lib().t2s_sampler_destroy(ptr)
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     _, vae = bench.build_models(dev)
@@ -41,15 +59,25 @@ def main():
     def work(i):
         try:
             torch.cuda.set_device(dev)
+            model, dec = models[i], vae.decoder
             for rep in range(a.reps):
-                s = Sampler(models[i], vae.decoder, "ddpm", 5, 9.0, 64, 48, dev, seed=100 + i, lanes=2 if rep % 3 else 1)
+                if a.fresh_handles and rep % a.fresh_handles == a.fresh_handles - 1:
+                    # a new model and a new LA-VAE: torch uploads on the default stream, t2s_dit_create, the bf16x3 weight
+                    # packing and t2s_vae_create, all while the other thread may have a capture open
+                    model = Transformer()
+                    model.load_state_dict(synth.make_dit_state_dict((31337, 4242)[i], gain=0.7), strict=True)
+                    model = model.to(dev).eval()
+                    _, v2 = bench.build_models(dev)
+                    dec = v2.decoder
+                s = Sampler(model, dec, "ddpm", 5, 9.0, 64, 48, dev, seed=100 + i, lanes=2 if rep % 3 else 1)
                 for _ in range(2):
                     lat, ser, _ = s.run(texts[i])
                     if not (torch.equal(lat, want[i][0]) and torch.equal(ser, want[i][1])):
                         bad[i] += 1
             torch.cuda.synchronize(dev)
         except Exception as e:                       # noqa: BLE001
-            errors.append((i, repr(e)))
+            import traceback
+            errors.append((i, repr(e)[:300], traceback.format_exc()[-1500:]))
 
     th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
     [t.start() for t in th]
