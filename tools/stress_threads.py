@@ -25,6 +25,10 @@ def main():
                          "samplers run concurrently with the other thread's open capture (use with T2S_LIB = a library built with "
                          "-DT2S_DIAG_UNSERIALISED: tools/variant.sh t2s_sampler diag_unser -DT2S_DIAG_UNSERIALISED).  Records WHICH "
                          "call fails with WHICH HIP error when the serialisation of DESIGN 4.5 is taken away.")
+    ap.add_argument("--foreign-sync", choices=["global", "relaxed"], default=None,
+                    help="a third thread calls torch.cuda.synchronize() in a loop (a caller's own device-wide call, outside every "
+                         "lock): in HIP's default capture mode ('global': refused while a capture is open, and the capture dies) or "
+                         "after hipThreadExchangeStreamCaptureMode(relaxed) in that thread")
     ap.add_argument("--fresh-handles", type=int, default=0, metavar="N",
                     help="every N-th round builds a new Transformer and a new LA-VAE (their HIP handles are created inside the loop)")
     a = ap.parse_args()
@@ -79,9 +83,37 @@ def main():
             import traceback
             errors.append((i, repr(e)[:300], traceback.format_exc()[-1500:]))
 
+    stop, refused = threading.Event(), [0, 0]
+
+    def foreign():
+        """A thread of the CALLER's that keeps synchronising the device: HIP fails the call while a sampler run has a capture
+        open and invalidates that capture; the runs must survive it (t2s_sampler_run re-captures)."""
+        torch.cuda.set_device(dev)
+        if a.foreign_sync == "relaxed":
+            # what such a thread can do about it: take ITSELF out of HIP's capture bookkeeping.  In the default (global) mode
+            # a thread's device-wide calls are checked against every open capture of the process; in relaxed mode they are not.
+            import ctypes as C
+            hip = C.CDLL("libamdhip64.so")
+            mode = C.c_int(2)                        # hipStreamCaptureModeRelaxed
+            assert hip.hipThreadExchangeStreamCaptureMode(C.byref(mode)) == 0
+        while not stop.is_set():
+            try:
+                torch.cuda.synchronize(dev)
+                refused[1] += 1
+            except Exception:                        # noqa: BLE001
+                refused[0] += 1
+            stop.wait(0.0005)
+
     th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    fth = threading.Thread(target=foreign) if a.foreign_sync else None
+    if fth:
+        fth.start()
     [t.start() for t in th]
     [t.join() for t in th]
+    stop.set()
+    if fth:
+        fth.join()
+        print("foreign torch.cuda.synchronize() [%s]: refused" % a.foreign_sync, refused[0], "of", sum(refused))
     print("mismatches", bad, "errors", errors)
     sys.exit(1 if (sum(bad) or errors) else 0)
 
