@@ -365,10 +365,11 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
     const bool shared_in = S == 2 * B;
     float* tokens = shared_in ? w_h0 : w_h;
     const int in_seqs = shared_in ? B : S;
-    // f32 path: the <qkv only> row kernel of block 0 patchifies in its prologue (t2s_rows.h) and writes the tokens for
-    // block 0's <proj + MLP> kernel; the stand-alone launch remains for the bf16x3 kernels.  T2S_PATCHIFY_KERNEL=1: A/B.
+    // The <qkv only> row kernel of block 0 patchifies in its prologue (t2s_rows.h, t2s_rows16.h, t2s_rows_x3.h: the same
+    // helpers, the same bits as patchify_kernel) and writes the tokens for block 0's <proj + MLP> kernel.
+    // T2S_PATCHIFY_KERNEL=1 restores the stand-alone launch (A/B).
     static const bool patch_launch = getenv("T2S_PATCHIFY_KERNEL") && atoi(getenv("T2S_PATCHIFY_KERNEL")) != 0;
-    const bool patch_fused = h->math != T2S_MATH_BF16X3 && !patch_launch;
+    const bool patch_fused = !patch_launch;
     if (!patch_fused) {
         const int threads = in_seqs * NTOK * 32;
         TimeScope ts(h, TC_OTHER, st);
@@ -406,6 +407,9 @@ int run_forward(t2s_dit* h, const float* x, int B, int S, int uncond_rows, const
         RowArgsX3 a{};
         a.x = w_h; a.ao = w_ao; a.mod = w_mod; a.M = M; a.blk = blk; a.qkv_blk = qkv_blk;
         if (use_table) { a.mod = mt.base; a.mod_step = step_ptr; a.mod_rows = mt.rows; a.mod_uncond = uncond_rows; a.mod_row0 = mt.row0; }
+        if (blk < 0 && patch_fused) {
+            a.p_lat = x; a.p_B = B; a.p_cw = h->conv_w; a.p_cb = h->conv_b; a.p_pw = h->patch_w; a.p_pb = h->patch_b; a.p_pos = h->pos;
+        }
         const bool first = blk <= 0 && qkv_blk <= 1;
         a.x_in = first ? tokens : w_h; a.in_seqs = first ? in_seqs : S;
         if (blk == NBLK - 1) {

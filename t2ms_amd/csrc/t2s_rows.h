@@ -91,7 +91,8 @@ struct RowArgs {
 };
 
 // patchify of one token (shared by the 32- and the 16-token kernel: the same expression, hence the same bits)
-__device__ __forceinline__ void patch_conv(const RowArgs& a, int seq, int n, float (&cv)[4]) {
+template <class Args>   // RowArgs or RowArgsX3 (t2s_rows_x3.h): the same p_* fields
+__device__ __forceinline__ void patch_conv(const Args& a, int seq, int n, float (&cv)[4]) {
     const int hh = n >> 5, ww = n & 31;
     const float* xin = a.p_lat + (size_t)(seq % a.p_B) * LAT;
     float px[4];

@@ -61,6 +61,11 @@ struct RowArgsX3 {
     float* x;          // (M,128) residual stream, fragment-major, in place
     const float* x_in; // where the stream is READ at kernel entry: x itself, or (block 0 of a CFG pass) the patchified
     int in_seqs;       //   tokens of the in_seqs distinct sequences, sequence s reading slot s % in_seqs
+    // <qkv only> kernel of block 0 with p_lat != NULL: the tokens are GENERATED in the prologue from the latent (patchify,
+    // exactly as in t2s_rows.h: same helpers, same bits as patchify_kernel) and written to x_in for block 0's <proj + MLP> kernel
+    const float* p_lat;
+    int p_B;
+    const float *p_cw, *p_cb, *p_pw, *p_pb, *p_pos;
     // last block only (DO_MLP && !DO_QKV): fused final layer when out0 != NULL; sequences [0,split) -> out0, rest -> out1;
     // keep_x = 0 skips the store of the final residual stream (only the t2s_dit_read_stream tap reads it)
     const float *f_lnw, *f_lnb, *f_ow, *f_ob;
@@ -224,8 +229,42 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
 
     // residual stream of this lane's token, accumulator layout: x[nt][4g+e] = X[row][32nt+8g+4half+e]
     f32x16 x[4];
-    {
-        const int tile_src = tile - (seq - seq % a.in_seqs) * (NTOK / 32);   // same tile of sequence seq % in_seqs
+    const int tile_src = tile - (seq - seq % a.in_seqs) * (NTOK / 32);   // same tile of sequence seq % in_seqs
+    bool generated = false;
+    if constexpr (!DO_MLP) {
+        if (a.p_lat != nullptr) {
+            // patchify in the prologue (as t2s_rows.h): patch_emb weight in the (unused) proj / MLP bias slots of LDS, bias in the
+            // wave's (unused) MLP adaLN slots; visible after this barrier
+            for (int i = threadIdx.x; i < 512; i += 256) cb[i] = a.p_pw[i];
+            *reinterpret_cast<f32x4*>(cm + 256 + (lane & 31) * 4) = *reinterpret_cast<const f32x4*>(a.p_pb + (lane & 31) * 4);
+            wg_sync();
+            const int n = (tile - seq * (NTOK / 32)) * 32 + (lane & 31);
+            float cv[4];
+            patch_conv(a, seq, n, cv);
+            const float* posrow = a.p_pos + (size_t)n * D;
+#pragma unroll
+            for (int G = 0; G < 16; ++G) {
+                const int d0 = 8 * G + 4 * half;
+                const f32x4 pos4 = *reinterpret_cast<const f32x4*>(posrow + d0);
+                const f32x4 pb4 = *reinterpret_cast<const f32x4*>(cm + 256 + d0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    x[G >> 2][4 * (G & 3) + e] = patch_feature(cv, *reinterpret_cast<const f32x4*>(cb + (d0 + e) * 4), pb4[e], pos4[e]);
+            }
+            if (active && seq < a.in_seqs) {   // block 0's <proj + MLP> kernel reads the tokens of sequence s % in_seqs
+                f32x4* xo = const_cast<f32x4*>(reinterpret_cast<const f32x4*>(a.x_in)) + (size_t)tile_src * 16 * 64 + lane;
+#pragma unroll
+                for (int G = 0; G < 16; ++G) {
+                    f32x4 t;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = x[G >> 2][4 * (G & 3) + e];
+                    xo[G * 64] = t;
+                }
+            }
+            generated = true;
+        }
+    }
+    if (!generated) {
         const f32x4* xr = reinterpret_cast<const f32x4*>(a.x_in) + (size_t)tile_src * 16 * 64 + lane;
 #pragma unroll
         for (int G = 0; G < 16; ++G) {
