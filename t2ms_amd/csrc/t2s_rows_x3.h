@@ -45,10 +45,14 @@ __device__ __forceinline__ unsigned long long x3_clk() {
 #define X3_STAMP_DECL unsigned long long st_last = x3_clk(), st_acc[7] = {0, 0, 0, 0, 0, 0, 0}; const unsigned long long st_t0 = st_last;
 #define X3_STAMP(k) { const unsigned long long n_ = x3_clk(); st_acc[k] += n_ - st_last; st_last = n_; }
 #define X3_SYNC() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); X3_STAMP(3) __builtin_amdgcn_s_barrier(); X3_STAMP(4) }
+#define X3_SYNC_BUT16() { asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); X3_STAMP(3) __builtin_amdgcn_s_barrier(); X3_STAMP(4) }
 #else
 #define X3_STAMP_DECL
 #define X3_STAMP(k)
 #define X3_SYNC() wg_sync();
+// the same, but the 16 YOUNGEST vector-memory operations of the wave may still be in flight (the tile's residual stream, issued
+// last on purpose: it is first needed after the proj chunks).  Not wg_sync(): its release fence waits for vmcnt(0).
+#define X3_SYNC_BUT16() { asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
 #endif
 constexpr int X3_CHUNK_UNITS = 24 * 64;                    // 16-byte units per chunk (24 KiB)
 #ifdef T2S_X3_LONE   // diagnosis (tools/x3_variant.sh x3_lone -DT2S_X3_LONE): pad the allocation so ONE workgroup fits a CU = one wave per SIMD
@@ -185,9 +189,9 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
         const bf16x8* src = chunk_src(ci) + lane;
         bf16x8* dst = wring3 + (ci & 1) * X3_CHUNK_UNITS;
 #pragma unroll
-        for (int p = 0; p < 6; ++p)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (wave + 4 * p) * 64),
-                                             (__attribute__((address_space(3))) void*)(dst + (wave + 4 * p) * 64), 16, 0, 0);
+        for (int p = 0; p < 6; ++p)      // untracked (glds16_asm), like the pieces below: with a TRACKED LDS-DMA pending hipcc turns
+            glds16_asm(reinterpret_cast<const f32x4*>(src + (wave + 4 * p) * 64),      // every wait of the prologue into vmcnt(0) --
+                       reinterpret_cast<f32x4*>(dst + (wave + 4 * p) * 64));           // one full round trip per constant load
     };
 
     X3_STAMP_DECL
@@ -205,22 +209,56 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
 #define X3_FILL_MIX(ci, step) if ((step) >= 1 && (step) <= 6) fill_piece(ci, (step) - 1);
 #define X3_DMA_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     fill(0);
+    // The attention output of the tile is requested FIRST, in front of the constants below (whose loads the compiler waits for
+    // one by one before their ds_writes): its round trip then runs under theirs instead of after them.
+    f32x4 araw[DO_MLP ? 16 : 1];
+    if constexpr (DO_MLP) {
+        const f32x4* ar = reinterpret_cast<const f32x4*>(a.ao) + (size_t)tile * 16 * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+#ifdef T2S_X3_NOPROLOGUE   // TIMING ONLY (results invalid): the bound of a perfect prefetch of the tile's inputs
+            araw[g] = f32x4{0.01f * lane, 0.3f, 0.1f * g, -0.7f};
+            (void)ar;
+#else
+            araw[g] = ar[g * 64];
+#endif
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
     // ---- per-feature constants in LDS (visible after the first barrier), as in t2s_rows.h ----
     float* cb = reinterpret_cast<float*>(wring3 + 2 * X3_CHUNK_UNITS);
     float* cm = cb + ROWS_CB_FLOATS + wave * ROWS_CM_FLOATS;
-    if constexpr (DO_MLP) {
-        for (int i = threadIdx.x; i < 512; i += 256)
-            cb[i] = i < 128 ? a.bp[i] : (i < 384 ? a.b1[i - 128] : a.b2[i - 384]);
-        const float* src = modrow + a.blk * MODW;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            *reinterpret_cast<f32x4*>(cm + (i * 64 + lane) * 4) = *reinterpret_cast<const f32x4*>(src + (i * 64 + lane) * 4);
-    }
-    if constexpr (DO_QKV) {
-        for (int i = threadIdx.x; i < 384; i += 256) cb[512 + i] = a.bq[i];
-        const float* src = modrow + a.qkv_blk * MODW;   // shift_msa | scale_msa
-        *reinterpret_cast<f32x4*>(cm + 768 + lane * 4) = *reinterpret_cast<const f32x4*>(src + lane * 4);
+    {   // every load first, then every ds_write: written as load -> store pairs each pair cost its own L2 round trip
+        const int t0 = threadIdx.x, t1 = t0 + 256;
+        float c0 = 0.f, c1 = 0.f, q0 = 0.f, q1 = 0.f;
+        f32x4 m0 = {}, m1 = {}, m2 = {}, mq = {};
+        if constexpr (DO_MLP) {
+            c0 = t0 < 128 ? a.bp[t0] : a.b1[t0 - 128];                  // i = t0 < 256
+            c1 = t1 < 384 ? a.b1[t1 - 128] : a.b2[t1 - 384];            // i = t1 in [256, 512)
+            const float* src = modrow + a.blk * MODW;
+            m0 = *reinterpret_cast<const f32x4*>(src + lane * 4);
+            m1 = *reinterpret_cast<const f32x4*>(src + (64 + lane) * 4);
+            m2 = *reinterpret_cast<const f32x4*>(src + (128 + lane) * 4);
+        }
+        if constexpr (DO_QKV) {
+            q0 = a.bq[t0];
+            if (t1 < 384) q1 = a.bq[t1];
+            mq = *reinterpret_cast<const f32x4*>(modrow + a.qkv_blk * MODW + lane * 4);   // shift_msa | scale_msa
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DO_MLP) {
+            cb[t0] = c0;
+            cb[t1] = c1;
+            *reinterpret_cast<f32x4*>(cm + lane * 4) = m0;
+            *reinterpret_cast<f32x4*>(cm + (64 + lane) * 4) = m1;
+            *reinterpret_cast<f32x4*>(cm + (128 + lane) * 4) = m2;
+        }
+        if constexpr (DO_QKV) {
+            cb[512 + t0] = q0;
+            if (t1 < 384) cb[512 + t1] = q1;
+            *reinterpret_cast<f32x4*>(cm + 768 + lane * 4) = mq;
+        }
     }
     const float* c_bp = cb;
     const float* c_b1 = cb + 128;
@@ -264,15 +302,21 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
             generated = true;
         }
     }
-    if (!generated) {
+    auto load_x = [&]() T2S_X3_KERNEL {
         const f32x4* xr = reinterpret_cast<const f32x4*>(a.x_in) + (size_t)tile_src * 16 * 64 + lane;
 #pragma unroll
         for (int G = 0; G < 16; ++G) {
+#ifdef T2S_X3_NOPROLOGUE   // TIMING ONLY (results invalid): the bound of a perfect prefetch of the tile's inputs
+            const f32x4 t = {0.25f * lane, 0.5f, -0.125f * G, 1.0f};
+            (void)xr;
+#else
             const f32x4 t = xr[G * 64];
+#endif
 #pragma unroll
             for (int e = 0; e < 4; ++e) x[G >> 2][4 * (G & 3) + e] = t[e];
         }
-    }
+    };
+    if (!DO_MLP && !generated) load_x();
     int ci = 0;
 
     if constexpr (DO_MLP) {
@@ -280,15 +324,25 @@ __global__ __launch_bounds__(256, 2) T2S_X3_KERNEL void dit_rows_x3_kernel(const
         // ---------------- x += gate_msa * (proj(ao) + b): ao planes resident ----------------
         {
             Split3 aop[8];      // k-step ks = features 16 ks .. 16 ks + 15 in the permuted order
-            const f32x4* ar = reinterpret_cast<const f32x4*>(a.ao) + (size_t)tile * 16 * 64 + lane;
+            // Order of the prologue's vector-memory operations: chunk 0's DMA, the attention output (top of the kernel), the
+            // constants, and LAST the 16 loads of the residual stream -- it is first needed after the four proj chunks, so the
+            // first barrier does not wait for it (X3_SYNC_BUT16) and the split of ao runs while it is in flight.  A timing-only
+            // build without any prologue load bounded this at +5.3 % of the sampler (profiles/EXPERIMENTS.md 0.11).
+            __builtin_amdgcn_sched_barrier(0);
+            load_x();
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                const f32x4 lo = ar[(2 * ks) * 64], hi = ar[(2 * ks + 1) * 64];
+                const f32x4 lo = araw[2 * ks], hi = araw[2 * ks + 1];
                 const f32x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 aop[ks] = split3(v);
             }
             X3_STAMP(0)
-            X3_SYNC()  // chunk 0 landed (vmcnt(0) + barrier)
+#ifdef T2S_X3_NOPROLOGUE
+            X3_SYNC()
+#else
+            X3_SYNC_BUT16()  // chunk 0 landed, ao consumed; the residual stream may still be on its way
+#endif
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 X3_STAMP(5)
