@@ -264,6 +264,14 @@ constexpr int ROWS_NW = T2S_ROWS_NW;
         __syncthreads();                                     \
     } while (0)
 
+// the same, but the 16 YOUNGEST vector-memory operations of the wave may stay in flight (the tile's residual stream, issued last
+// on purpose).  A raw barrier: __syncthreads()' release fence would make hipcc wait for vmcnt(0) again.
+#define ROWS_SYNC_BUT16()                                                \
+    do {                                                                 \
+        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");     \
+        __builtin_amdgcn_s_barrier();                                    \
+    } while (0)
+
 template <bool DO_MLP, bool DO_QKV>
 __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(const RowArgs a) {
     extern __shared__ __attribute__((aligned(16))) f32x4 wring[];  // [ROWS_SLOTS][1024]
@@ -325,18 +333,51 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
     // per wave: [0,256) shift_msa | scale_msa of the QKV block, [256,768) gate_msa | shift_mlp | scale_mlp | gate_mlp
     // of the MLP block (whose own shift_msa / scale_msa were consumed by the previous kernel)
     float* cm = cb + ROWS_CB_FLOATS + wave * ROWS_CMF;
+    // Order of the prologue's vector-memory operations (round 5, as in t2s_rows_x3.h): the weight DMAs, the attention output
+    // (requested FIRST: its round trip runs under the constants'), the constants as ONE batch of loads then one batch of
+    // ds_writes (written as load -> store pairs hipcc waits vmcnt(0) in front of every store: three serial L2 round trips
+    // before the tile's own loads were even issued), and LAST the residual stream, which the first barrier leaves in flight
+    // (ROWS_SYNC_BUT16: it is first used after the four proj chunks).
+    static_assert(ROWS_NW == 4, "the constants below are staged by 256 threads");
+    f32x16 bop[DO_MLP ? 4 : 1];  // B operand of proj: ao[row][8G+4half+e] at bop[G>>2][4(G&3)+e]
     if constexpr (DO_MLP) {
-        for (int i = threadIdx.x; i < 512; i += 64 * ROWS_NW)
-            cb[i] = i < 128 ? a.bp[i] : (i < 384 ? a.b1[i - 128] : a.b2[i - 384]);
-        const float* src = modrow + a.blk * MODW;
+        const f32x4* ar = reinterpret_cast<const f32x4*>(a.ao) + (size_t)tile * 16 * 64 + lane;
 #pragma unroll
-        for (int i = 1; i < 3; ++i)
-            *reinterpret_cast<f32x4*>(cm + (i * 64 + lane) * 4) = *reinterpret_cast<const f32x4*>(src + (i * 64 + lane) * 4);
+        for (int G = 0; G < 16; ++G) {
+            const f32x4 t = ar[G * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bop[G >> 2][4 * (G & 3) + e] = t[e];
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (DO_QKV) {
-        for (int i = threadIdx.x; i < 384; i += 64 * ROWS_NW) cb[512 + i] = a.bq[i];
-        const float* src = modrow + a.qkv_blk * MODW;   // shift_msa | scale_msa
-        *reinterpret_cast<f32x4*>(cm + lane * 4) = *reinterpret_cast<const f32x4*>(src + lane * 4);
+    {
+        const int t0 = threadIdx.x, t1 = t0 + 256;
+        float c0 = 0.f, c1 = 0.f, q0 = 0.f, q1 = 0.f;
+        f32x4 m1 = {}, m2 = {}, mq = {};
+        if constexpr (DO_MLP) {
+            c0 = t0 < 128 ? a.bp[t0] : a.b1[t0 - 128];
+            c1 = t1 < 384 ? a.b1[t1 - 128] : a.b2[t1 - 384];
+            const float* src = modrow + a.blk * MODW;
+            m1 = *reinterpret_cast<const f32x4*>(src + (64 + lane) * 4);
+            m2 = *reinterpret_cast<const f32x4*>(src + (128 + lane) * 4);
+        }
+        if constexpr (DO_QKV) {
+            q0 = a.bq[t0];
+            if (t1 < 384) q1 = a.bq[t1];
+            mq = *reinterpret_cast<const f32x4*>(modrow + a.qkv_blk * MODW + lane * 4);   // shift_msa | scale_msa
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DO_MLP) {
+            cb[t0] = c0;
+            cb[t1] = c1;
+            *reinterpret_cast<f32x4*>(cm + (64 + lane) * 4) = m1;
+            *reinterpret_cast<f32x4*>(cm + (128 + lane) * 4) = m2;
+        }
+        if constexpr (DO_QKV) {
+            cb[512 + t0] = q0;
+            if (t1 < 384) cb[512 + t1] = q1;
+            *reinterpret_cast<f32x4*>(cm + lane * 4) = mq;
+        }
     }
     const float* c_bp = cb;
     const float* c_b1 = cb + 128;
@@ -380,7 +421,7 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
             generated = true;
         }
     }
-    if (!generated) {
+    auto load_x = [&]() {
         const f32x4* xr = reinterpret_cast<const f32x4*>(a.x_in) + (size_t)tile_src * 16 * 64 + lane;
 #pragma unroll
         for (int G = 0; G < 16; ++G) {
@@ -388,22 +429,18 @@ __global__ __launch_bounds__(64 * ROWS_NW, 8 / ROWS_NW) void dit_rows_kernel(con
 #pragma unroll
             for (int e = 0; e < 4; ++e) x[G >> 2][4 * (G & 3) + e] = t[e];
         }
-    }
+    };
+    if (!DO_MLP && !generated) load_x();
     int ci = 0;
 
     if constexpr (DO_MLP) {
         const float* mb = cm;   // [shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp] of a.blk
         // ---------------- x += gate_msa * (proj(ao) + b) ----------------
         {
-            f32x16 bop[4];  // B operand: ao[row][8G+4half+e] at bop[G>>2][4(G&3)+e]
-            const f32x4* ar = reinterpret_cast<const f32x4*>(a.ao) + (size_t)tile * 16 * 64 + lane;
-#pragma unroll
-            for (int G = 0; G < 16; ++G) {
-                const f32x4 t = ar[G * 64];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bop[G >> 2][4 * (G & 3) + e] = t[e];
-            }
-            ROWS_SYNC();  // chunk 0 landed (vmcnt(0) + barrier)
+            __builtin_amdgcn_sched_barrier(0);
+            load_x();
+            __builtin_amdgcn_sched_barrier(0);
+            ROWS_SYNC_BUT16();  // chunk 0 landed, ao and the constants here; the residual stream (16 loads) may still be on its way
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 prefetch(ci);
