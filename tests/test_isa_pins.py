@@ -98,3 +98,31 @@ def test_f32_path_uses_the_f32_matrix_instruction(reports):
 def test_x3_row_kernels_scratch_is_bounded(reports, kernel):
     m = reports[kernel]["meta"]
     assert m["private_segment_fixed_size"] <= X3_SCRATCH_MAX[kernel] and m["vgpr_count"] <= 256, m
+
+
+# the <proj + MLP ...> row kernels (f32 and bf16x3) leave their residual stream in flight across the FIRST barrier
+BUT16 = [NS + "15dit_rows_kernelILb1ELb1EEEvNS_7RowArgsE", NS + "15dit_rows_kernelILb1ELb0EEEvNS_7RowArgsE",
+         NS + "18dit_rows_x3_kernelILb1ELb1EEEvNS_9RowArgsX3E", NS + "18dit_rows_x3_kernelILb1ELb0EEEvNS_9RowArgsX3E"]
+
+
+@pytest.mark.parametrize("kernel", BUT16)
+def test_first_barrier_keeps_only_the_residual_stream_in_flight(kernel):
+    """ROWS_SYNC_BUT16 / X3_SYNC_BUT16 (round 5): `s_waitcnt vmcnt(16) lgkmcnt(0)` + `s_barrier` instead of vmcnt(0).  It is
+    right only while (a) at least 16 vector-memory operations follow the weight DMAs of the prologue (else a DMA piece could be
+    among the 16 youngest and chunk 0 be read before it has landed), (b) the 16 youngest are plain 16-byte loads (the tile's
+    residual stream, whose registers the compiler guards itself) -- no store, no scratch, no LDS-DMA -- and (c) the wait
+    directly precedes the barrier.  A compiler that moves a load or spills here fails this test, not a GPU run."""
+    wd = tempfile.mkdtemp(prefix="t2s_isa_")
+    try:
+        co = isa.extract_code_object(os.path.join(REPO, "t2ms_amd", "csrc", "t2s_dit.o"), wd)
+        insts = isa.disassemble(co)[kernel]
+    finally:
+        shutil.rmtree(wd, ignore_errors=True)
+    idx = next(i for i, (_, mn, ops) in enumerate(insts) if mn == "s_waitcnt" and "vmcnt(16)" in ops and "lgkmcnt(0)" in ops)
+    assert insts[idx + 1][1] == "s_barrier", insts[idx:idx + 3]
+    assert not any(mn == "s_barrier" for _, mn, _ in insts[:idx]), "the counted wait must belong to the FIRST barrier"
+    vm = [(mn, ops) for _, mn, ops in insts[:idx] if isa.VMEM.match(mn)]
+    last_dma = max(i for i, (mn, _) in enumerate(vm) if mn.startswith("global_load_lds"))
+    assert len(vm) - 1 - last_dma >= 16, f"only {len(vm) - 1 - last_dma} vector-memory operations follow the prologue's weight DMAs"
+    youngest = vm[-16:]
+    assert all(mn == "global_load_dwordx4" for mn, _ in youngest), youngest
