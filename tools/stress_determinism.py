@@ -3,7 +3,7 @@
 DiT forward is repeated many times on the same inputs and must reproduce its first result BIT FOR BIT; interleaved with
 other-shape launches and a second stream's traffic so that timing varies.  A DMA / barrier race shows up as a differing
 tile sooner or later; a clean run is no proof, a differing run is a bug.
-    python tools/stress_determinism.py [--rounds 40]
+    python tools/stress_determinism.py [--rounds 40] [--math bf16x3]
 """
 import argparse
 import os
@@ -20,10 +20,12 @@ from t2ms_amd.sampler import Sampler  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=40)
+    ap.add_argument("--math", choices=["f32", "bf16x3"], default="f32", help="matrix arithmetic of the forward / the samplers")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     model, vae = bench.build_models(dev)
+    model.set_math(args.math)
     shapes = [1, 3, 7, 16, 25, 32, 50, 64, 100, 128, 256]
     inputs, first = {}, {}
     side = torch.cuda.Stream(dev)
