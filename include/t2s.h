@@ -537,7 +537,7 @@ int t2s_ts2vec_encode(const t2s_ts2vec_weights* w, const float* x, float* rep, f
 
 /* ------------------------------------------------------------------------ *
  * MLP denoiser of BASELINE configs[0]: model/denoiser/mlp.py:49-94 (MLPlayer x 8 on a
- * (64, 6) latent; inference forward -- training stays torch autograd in the mirror).
+ * (64, 6) latent; forward, and the backward for train.py --denoiser MLP).
  * ------------------------------------------------------------------------ */
 #define T2S_MLP_LAYERS 8
 #define T2S_MLP_WIDTH 64      /* channels, mlp.py:52-56 */
@@ -570,6 +570,22 @@ int t2s_mlp_pack(const t2s_mlp_weights* w, float* packed, void* stream);
  * alias x.  One launch, one workgroup per series. */
 int t2s_mlp_forward(const float* packed, const float* x, const float* t, const float* freqs, const float* text, float* out,
                     int B, void* stream);
+/* Gradients of the same forward (train.py:123-125 with --denoiser MLP): every tensor of t2s_mlp_layer_weights, in its own layout. */
+typedef struct t2s_mlp_layer_grads {
+    float *value_w, *value_b, *proj_w, *proj_b, *norm2_w, *norm2_b, *mlp0_w, *mlp0_b, *mlp2_w, *mlp2_b, *pos0_w, *pos0_b, *pos2_w,
+        *pos2_b;
+} t2s_mlp_layer_grads;
+typedef struct t2s_mlp_grads {
+    t2s_mlp_layer_grads layer[T2S_MLP_LAYERS];
+} t2s_mlp_grads;
+#define T2S_MLP_GRAD_PART_FLOATS 391744 /* 8 x 48,968: one series' contributions, what `scratch` holds per series */
+/* Backward of t2s_mlp_forward for dout (B,64,6): the forward is recomputed from x (nothing else is saved); every series writes
+ * its contribution to `scratch` (B x T2S_MLP_GRAD_PART_FLOATS floats, caller-owned) and the contributions are added in series
+ * order -- bit-reproducible.  grads receives d loss / d parameter (overwritten, not accumulated); dx (B,64,6) the gradient of
+ * x, or NULL.  `w` are the tensors `packed` was made from.  cross_attn.query / key get no gradient here: exact zeros are theirs. */
+int t2s_mlp_backward(const t2s_mlp_weights* w, const float* packed, const float* x, const float* t, const float* freqs,
+                     const float* text, const float* dout, float* dx, const t2s_mlp_grads* grads, float* scratch,
+                     uint64_t scratch_floats, int B, void* stream);
 
 #ifdef __cplusplus
 }

@@ -93,6 +93,13 @@ class MlpWeights(C.Structure):
     _fields_ = [("layer", MlpLayerWeights * MLP_LAYERS)]
 
 
+MLP_GRAD_PART_FLOATS = 391744           # t2s.h: T2S_MLP_GRAD_PART_FLOATS
+
+
+class MlpGrads(C.Structure):            # t2s_mlp_grads: the same fields, writable
+    _fields_ = [("layer", MlpLayerWeights * MLP_LAYERS)]
+
+
 class SampleConfig(C.Structure):
     _fields_ = [("mode", C.c_int), ("steps", C.c_int), ("cfg_scale", C.c_float), ("batch", C.c_int),
                 ("length", C.c_int), ("use_graph", C.c_int), ("seed", C.c_uint64), ("row0", C.c_uint32),
@@ -130,6 +137,7 @@ SYMBOLS = {
     "t2s_ts2vec_encode": (_I, [C.POINTER(Ts2vecWeights), _VP, _VP, _VP, _I, _I, _VP]),
     "t2s_mlp_pack": (_I, [C.POINTER(MlpWeights), _VP, _VP]),
     "t2s_mlp_forward": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
+    "t2s_mlp_backward": (_I, [C.POINTER(MlpWeights), _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(MlpGrads), _VP, _U64, _I, _VP]),
     "t2s_attn_fwd_x3": (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_attn_fwd_bf16": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "t2s_dit_train_forward": (_I, [_VP, C.POINTER(DitWeights), _VP, _VP, _I, _VP, _VP, _I, _VP]),

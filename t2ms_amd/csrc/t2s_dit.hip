@@ -501,7 +501,7 @@ extern "C" {
 const char* t2s_last_error(void) { return t2s::g_err; }
 // 0.3: + t2s_philox_uniform, t2s_dit_forward_cfg_rows, t2s_sampler_set_loop_graph (additions only)
 // 0.4: + t2s_time_embedding_freqs, t2s_dit_weights_check, t2s_mse_ws, t2s_vae_update_weights, t2s_vae_encode_backward (additions only)
-// 0.5: + t2s_mlp_pack, t2s_mlp_forward (additions only)
+// 0.5: + t2s_mlp_pack, t2s_mlp_forward, t2s_mlp_backward (additions only)
 const char* t2s_version(void) { return "t2s 0.5 gfx950 fp32-mfma"; }
 
 int t2s_dit_create(const t2s_dit_weights* w, int max_seqs, t2s_dit** out) {

@@ -268,6 +268,366 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(const float* __restric
     for (int i = tid; i < MC * MP; i += 256) out[(size_t)b * MC * MP + i] = xs[i];
 }
 
+
+// ------------------------------------------------------------------------------------------------ backward (training)
+// One workgroup per series again: the forward is re-run keeping every layer's INPUT in LDS (8 x 384 floats), then the layers are
+// walked backwards, each recomputing its own activations from its input (cheap: the layer is 0.8 MFLOP) and producing
+//   * the gradient of its input (handed to the layer below),
+//   * this series' contribution to the layer's 14 parameter gradients, written to part[b][layer][N_*] in the parameters' own
+//     (torch) layouts.
+// mlp_grad_reduce_kernel then adds the B contributions of every element in series order (deterministic) into the gradient
+// tensors.  cross_attn.query / .key receive exact zeros (they cannot influence the forward, see the top of the file).
+constexpr int N_WV = 0;                     // value.weight (64,128)
+constexpr int N_BV = N_WV + MC * MT;
+constexpr int N_WP = N_BV + MC;             // proj.weight (64,64)
+constexpr int N_BP = N_WP + MC * MC;
+constexpr int N_LG = N_BP + MC;
+constexpr int N_LB = N_LG + MC;
+constexpr int N_W1 = N_LB + MC;             // mlp.0.weight (256,64)
+constexpr int N_B1 = N_W1 + MH * MC;
+constexpr int N_W2 = N_B1 + MH;             // mlp.2.weight (64,256)
+constexpr int N_B2 = N_W2 + MC * MH;
+constexpr int N_W3 = N_B2 + MC;             // mlp2.0.weight (256,6)
+constexpr int N_B3 = N_W3 + MH * MP;
+constexpr int N_W4 = N_B3 + MH;             // mlp2.2.weight (6,256)
+constexpr int N_B4 = N_W4 + MP * MH;        // (6) + 2 pad
+constexpr int N_LAYER = N_B4 + 8;
+static_assert(N_LAYER * ML == T2S_MLP_GRAD_PART_FLOATS, "include/t2s.h: T2S_MLP_GRAD_PART_FLOATS");
+
+struct BwdArgs {
+    t2s_mlp_weights w;        // native layouts: mlp.0.weight [j][c] and mlp.2.weight [c][j] are read as they are
+    const float* packed;
+    const float *x, *t, *freqs, *text, *dout;
+    float *dx, *part;
+};
+
+__global__ __launch_bounds__(256) void mlp_backward_kernel(const BwdArgs a) {
+    __shared__ float xin[ML][MC * MP];     // input of every layer, [c][p]
+    __shared__ float hs[MP][MC];           // LayerNorm output
+    __shared__ float xh[MP][MC];           // normalised (before the affine)
+    __shared__ float rs[MP];               // 1 / sqrt(var + eps)
+    __shared__ float hid[MP][MH];          // relu(W1 h + b1)
+    __shared__ float ys[MC][MP + 2];       // y = h + W2 hid + b2, [c][p] (row padded to 8)
+    __shared__ float dys[MP][MC];          // gradient of y / of hs
+    __shared__ float dp1[MP][MH];          // gradient of the fc1 pre-activation
+    __shared__ float red[4][MP][MC];
+    __shared__ float dcur[MC][MP + 2];     // gradient of the layer's output, [c][p]
+    __shared__ float txt[MT];
+    __shared__ float vs[MC], dadd[MC], dvs[MC];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool has_text = a.text != nullptr;
+    for (int i = tid; i < MC * MP; i += 256) xin[0][i] = a.x[(size_t)b * MC * MP + i];
+    if (has_text && tid < MT) txt[tid] = a.text[(size_t)b * MT + tid];
+    const float targ = (a.t[b] * 100.0f) / a.freqs[lane & 31];
+    const float te = lane < 32 ? sinf(targ) : cosf(targ);
+    __syncthreads();
+
+    // forward of one layer from xin[layer]: leaves hs, xh, rs, hid, ys (and vs) in LDS; returns the layer's output in ys' place?
+    // no: the output goes to `outp` ([c][p], 384 floats) when outp != nullptr
+    auto forward_layer = [&](int layer, float* outp) {
+        const float* w = a.packed + (size_t)layer * LAYER_FLOATS;
+        float add = te;
+        if (has_text) {
+            float acc = 0.f;
+            for (int kk = 0; kk < 32; ++kk) acc = fmaf(w[O_WV + (32 * wave + kk) * MC + lane], txt[32 * wave + kk], acc);
+            red[wave][0][lane] = acc;
+            __syncthreads();
+            if (wave == 0) vs[lane] = w[O_BV + lane] + ((red[0][0][lane] + red[1][0][lane]) + (red[2][0][lane] + red[3][0][lane]));
+            __syncthreads();
+            acc = 0.f;
+            for (int kk = 0; kk < 16; ++kk) acc = fmaf(w[O_WP + (16 * wave + kk) * MC + lane], vs[16 * wave + kk], acc);
+            red[wave][1][lane] = acc;
+            __syncthreads();
+            add += w[O_BP + lane] + ((red[0][1][lane] + red[1][1][lane]) + (red[2][1][lane] + red[3][1][lane]));
+            __syncthreads();
+        }
+        const float g = w[O_LG + lane], be = w[O_LB + lane];
+        for (int p = wave; p < MP; p += 4) {
+            const float v = xin[layer][lane * MP + p] + add;
+            const float mean = wave_sum(v) * (1.0f / MC);
+            const float dlt = v - mean;
+            const float var = wave_sum(dlt * dlt) * (1.0f / MC);
+            const float r = 1.0f / sqrtf(var + 1e-5f);
+            xh[p][lane] = dlt * r;
+            hs[p][lane] = dlt * r * g + be;
+            if (lane == 0) rs[p] = r;
+        }
+        __syncthreads();
+        {
+            float acc[MP];
+            const float b1 = w[O_B1 + tid];
+#pragma unroll
+            for (int p = 0; p < MP; ++p) acc[p] = b1;
+            for (int c = 0; c < MC; ++c) {
+                const float wv = w[O_W1 + c * MH + tid];
+#pragma unroll
+                for (int p = 0; p < MP; ++p) acc[p] = fmaf(wv, hs[p][c], acc[p]);
+            }
+#pragma unroll
+            for (int p = 0; p < MP; ++p) hid[p][tid] = fmaxf(acc[p], 0.f);
+        }
+        __syncthreads();
+        {
+            float acc[MP];
+#pragma unroll
+            for (int p = 0; p < MP; ++p) acc[p] = 0.f;
+            for (int jj = 0; jj < MC; ++jj) {
+                const int j = 64 * wave + jj;
+                const float wv = w[O_W2 + j * MC + lane];
+#pragma unroll
+                for (int p = 0; p < MP; ++p) acc[p] = fmaf(wv, hid[p][j], acc[p]);
+            }
+#pragma unroll
+            for (int p = 0; p < MP; ++p) red[wave][p][lane] = acc[p];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const float b2 = w[O_B2 + lane];
+#pragma unroll
+            for (int p = 0; p < MP; ++p)
+                ys[lane][p] = hs[p][lane] + (b2 + ((red[0][p][lane] + red[1][p][lane]) + (red[2][p][lane] + red[3][p][lane])));
+        }
+        __syncthreads();
+        if (outp != nullptr) {
+            float gv[MP], acc[MP];
+#pragma unroll
+            for (int p = 0; p < MP; ++p) { gv[p] = ys[lane][p]; acc[p] = 0.f; }
+            const f32x4* w3 = reinterpret_cast<const f32x4*>(w + O_W3) + 2 * 64 * wave;
+            const f32x4* w4 = reinterpret_cast<const f32x4*>(w + O_W4) + 2 * 64 * wave;
+            for (int j = 0; j < 64; ++j) {
+                const f32x4 a0 = w3[2 * j], a1 = w3[2 * j + 1];
+                float hdn = a1.z;
+                hdn = fmaf(a0.x, gv[0], hdn); hdn = fmaf(a0.y, gv[1], hdn); hdn = fmaf(a0.z, gv[2], hdn);
+                hdn = fmaf(a0.w, gv[3], hdn); hdn = fmaf(a1.x, gv[4], hdn); hdn = fmaf(a1.y, gv[5], hdn);
+                hdn = fmaxf(hdn, 0.f);
+                const f32x4 c0 = w4[2 * j], c1 = w4[2 * j + 1];
+                acc[0] = fmaf(c0.x, hdn, acc[0]); acc[1] = fmaf(c0.y, hdn, acc[1]); acc[2] = fmaf(c0.z, hdn, acc[2]);
+                acc[3] = fmaf(c0.w, hdn, acc[3]); acc[4] = fmaf(c1.x, hdn, acc[4]); acc[5] = fmaf(c1.y, hdn, acc[5]);
+            }
+            __syncthreads();   // every wave has read red / ys
+#pragma unroll
+            for (int p = 0; p < MP; ++p) red[wave][p][lane] = acc[p];
+            __syncthreads();
+            for (int i = tid; i < MC * MP; i += 256) {
+                const int c = i / MP, p = i - c * MP;
+                outp[i] = w[O_B4 + p] + ((red[0][p][c] + red[1][p][c]) + (red[2][p][c] + red[3][p][c]));
+            }
+            __syncthreads();
+        }
+    };
+
+    for (int layer = 0; layer + 1 < ML; ++layer) forward_layer(layer, xin[layer + 1]);
+    for (int i = tid; i < MC * MP; i += 256) dcur[i / MP][i % MP] = a.dout[(size_t)b * MC * MP + i];
+    __syncthreads();
+
+    for (int layer = ML - 1; layer >= 0; --layer) {
+        forward_layer(layer, nullptr);      // hs, xh, rs, hid, ys, vs of this layer
+        const float* w = a.packed + (size_t)layer * LAYER_FLOATS;
+        const t2s_mlp_layer_weights& wn = a.w.layer[layer];
+        float* gp = a.part + ((size_t)b * ML + layer) * N_LAYER;
+        // ---- position MLP, pass A: hidden unit j = tid over the 64 channels -> dW4[:, j], dW3[j, :], db3[j]
+        {
+            const f32x4 a0 = reinterpret_cast<const f32x4*>(w + O_W3)[2 * tid], a1 = reinterpret_cast<const f32x4*>(w + O_W3)[2 * tid + 1];
+            const f32x4 c0 = reinterpret_cast<const f32x4*>(w + O_W4)[2 * tid], c1 = reinterpret_cast<const f32x4*>(w + O_W4)[2 * tid + 1];
+            const float w3r[MP] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y}, w4c[MP] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
+            float g4[MP], g3[MP], gb3 = 0.f;
+#pragma unroll
+            for (int p = 0; p < MP; ++p) g4[p] = g3[p] = 0.f;
+            for (int c = 0; c < MC; ++c) {
+                float hdn = a1.z, dh = 0.f;
+#pragma unroll
+                for (int p = 0; p < MP; ++p) hdn = fmaf(w3r[p], ys[c][p], hdn);
+                hdn = fmaxf(hdn, 0.f);
+#pragma unroll
+                for (int p = 0; p < MP; ++p) {
+                    const float d = dcur[c][p];
+                    g4[p] = fmaf(d, hdn, g4[p]);
+                    dh = fmaf(w4c[p], d, dh);
+                }
+                const float dpre = hdn > 0.f ? dh : 0.f;
+#pragma unroll
+                for (int p = 0; p < MP; ++p) g3[p] = fmaf(dpre, ys[c][p], g3[p]);
+                gb3 += dpre;
+            }
+#pragma unroll
+            for (int p = 0; p < MP; ++p) {
+                gp[N_W3 + tid * MP + p] = g3[p];
+                gp[N_W4 + p * MH + tid] = g4[p];
+            }
+            gp[N_B3 + tid] = gb3;
+        }
+        if (wave == 0) {    // db4[p] = sum_c dout[c][p]
+#pragma unroll
+            for (int p = 0; p < MP; ++p) {
+                const float s = wave_sum(dcur[lane][p]);
+                if (lane == 0) gp[N_B4 + p] = s;
+            }
+        }
+        // ---- pass B: channel = lane, hidden units in quarters -> dy[p][c]
+        {
+            float gv[MP], dq[MP], acc[MP];
+#pragma unroll
+            for (int p = 0; p < MP; ++p) { gv[p] = ys[lane][p]; dq[p] = dcur[lane][p]; acc[p] = 0.f; }
+            const f32x4* w3 = reinterpret_cast<const f32x4*>(w + O_W3) + 2 * 64 * wave;
+            const f32x4* w4 = reinterpret_cast<const f32x4*>(w + O_W4) + 2 * 64 * wave;
+            for (int j = 0; j < 64; ++j) {
+                const f32x4 a0 = w3[2 * j], a1 = w3[2 * j + 1], c0 = w4[2 * j], c1 = w4[2 * j + 1];
+                float hdn = a1.z;
+                hdn = fmaf(a0.x, gv[0], hdn); hdn = fmaf(a0.y, gv[1], hdn); hdn = fmaf(a0.z, gv[2], hdn);
+                hdn = fmaf(a0.w, gv[3], hdn); hdn = fmaf(a1.x, gv[4], hdn); hdn = fmaf(a1.y, gv[5], hdn);
+                float dh = c0.x * dq[0];
+                dh = fmaf(c0.y, dq[1], dh); dh = fmaf(c0.z, dq[2], dh); dh = fmaf(c0.w, dq[3], dh);
+                dh = fmaf(c1.x, dq[4], dh); dh = fmaf(c1.y, dq[5], dh);
+                const float dpre = hdn > 0.f ? dh : 0.f;
+                acc[0] = fmaf(a0.x, dpre, acc[0]); acc[1] = fmaf(a0.y, dpre, acc[1]); acc[2] = fmaf(a0.z, dpre, acc[2]);
+                acc[3] = fmaf(a0.w, dpre, acc[3]); acc[4] = fmaf(a1.x, dpre, acc[4]); acc[5] = fmaf(a1.y, dpre, acc[5]);
+            }
+#pragma unroll
+            for (int p = 0; p < MP; ++p) red[wave][p][lane] = acc[p];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float sb2 = 0.f;
+#pragma unroll
+            for (int p = 0; p < MP; ++p) {
+                const float d = (red[0][p][lane] + red[1][p][lane]) + (red[2][p][lane] + red[3][p][lane]);
+                dys[p][lane] = d;
+                sb2 += d;
+            }
+            gp[N_B2 + lane] = sb2;      // y = hs + W2 hid + b2
+        }
+        __syncthreads();
+        // ---- channel MLP: dW2[c][j], dhid -> dp1, dW1[j][c], db1, d(hs) += W1^T dp1
+        {
+            float dyc[MP];
+#pragma unroll
+            for (int p = 0; p < MP; ++p) dyc[p] = dys[p][lane];
+            for (int jj = 0; jj < MC; ++jj) {
+                const int j = 64 * wave + jj;
+                float s = 0.f;
+#pragma unroll
+                for (int p = 0; p < MP; ++p) s = fmaf(dyc[p], hid[p][j], s);
+                gp[N_W2 + lane * MH + j] = s;
+            }
+        }
+        {
+            float acc[MP];
+#pragma unroll
+            for (int p = 0; p < MP; ++p) acc[p] = 0.f;
+            for (int c = 0; c < MC; ++c) {
+                const float wv = wn.mlp2_w[c * MH + tid];           // native (64,256): coalesced over j = tid
+#pragma unroll
+                for (int p = 0; p < MP; ++p) acc[p] = fmaf(wv, dys[p][c], acc[p]);
+            }
+            float sb1 = 0.f;
+#pragma unroll
+            for (int p = 0; p < MP; ++p) {
+                const float d = hid[p][tid] > 0.f ? acc[p] : 0.f;
+                dp1[p][tid] = d;
+                sb1 += d;
+            }
+            gp[N_B1 + tid] = sb1;
+            for (int c = 0; c < MC; ++c) {
+                float s = 0.f;
+#pragma unroll
+                for (int p = 0; p < MP; ++p) s = fmaf(acc[p] * (hid[p][tid] > 0.f ? 1.f : 0.f), hs[p][c], s);
+                gp[N_W1 + tid * MC + c] = s;
+            }
+        }
+        __syncthreads();
+        {
+            float acc[MP];
+#pragma unroll
+            for (int p = 0; p < MP; ++p) acc[p] = 0.f;
+            for (int jj = 0; jj < MC; ++jj) {
+                const int j = 64 * wave + jj;
+                const float wv = wn.mlp0_w[j * MC + lane];          // native (256,64): coalesced over c = lane
+#pragma unroll
+                for (int p = 0; p < MP; ++p) acc[p] = fmaf(wv, dp1[p][j], acc[p]);
+            }
+            __syncthreads();   // red's previous readers (wave 0 above) are done
+#pragma unroll
+            for (int p = 0; p < MP; ++p) red[wave][p][lane] = acc[p];
+        }
+        __syncthreads();
+        // ---- LayerNorm backward per position (wave w: positions w, w + 4); dgamma / dbeta summed over the positions afterwards
+        {
+            const float g = w[O_LG + lane];
+            for (int p = wave; p < MP; p += 4) {
+                const float dh = dys[p][lane] + ((red[0][p][lane] + red[1][p][lane]) + (red[2][p][lane] + red[3][p][lane]));
+                const float xhat = xh[p][lane];
+                const float dxh = dh * g;
+                const float m1 = wave_sum(dxh) * (1.0f / MC);
+                const float m2 = wave_sum(dxh * xhat) * (1.0f / MC);
+                const float du = rs[p] * (dxh - m1 - xhat * m2);
+                hs[p][lane] = dh;                 // (hs is dead now: keep dh for dgamma / dbeta)
+                dp1[p][lane] = du;                // (dp1 rows are free again: du[p][c] in their first 64 columns)
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float sg = 0.f, sb = 0.f, sa = 0.f;
+#pragma unroll
+            for (int p = 0; p < MP; ++p) {
+                sg = fmaf(hs[p][lane], xh[p][lane], sg);
+                sb += hs[p][lane];
+                sa += dp1[p][lane];
+            }
+            gp[N_LG + lane] = sg;
+            gp[N_LB + lane] = sb;
+            dadd[lane] = sa;                      // gradient of the broadcast row te + a
+        }
+        __syncthreads();
+        // ---- cross attention: a = proj(value(text)) broadcast over the positions
+        if (has_text) {
+            const float da = dadd[lane];
+            if (wave == 0) gp[N_BP + lane] = da;
+            for (int kk = 0; kk < 16; ++kk) gp[N_WP + lane * MC + 16 * wave + kk] = da * vs[16 * wave + kk];
+            for (int kk = 0; kk < 16; ++kk) {      // dvs[k] = sum_c proj.weight[c][k] da[c]: packed [k][c], lane = c
+                const int k = 16 * wave + kk;
+                const float s = wave_sum(w[O_WP + k * MC + lane] * da);
+                if (lane == 0) dvs[k] = s;
+            }
+            __syncthreads();
+            const float dv = dvs[lane];
+            if (wave == 0) gp[N_BV + lane] = dv;
+            for (int tt = 0; tt < 32; ++tt) gp[N_WV + lane * MT + 32 * wave + tt] = dv * txt[32 * wave + tt];
+        } else {
+            for (int i = tid; i < N_LG; i += 256) gp[i] = 0.f;     // value / proj parameters: untouched by this forward
+        }
+        if (tid < 2) gp[N_B4 + MP + tid] = 0.f;
+        // ---- the gradient of the layer's input is du, as [c][p]
+        __syncthreads();
+        for (int i = tid; i < MC * MP; i += 256) dcur[i / MP][i % MP] = dp1[i % MP][i / MP];
+        __syncthreads();
+    }
+    if (a.dx != nullptr)
+        for (int i = tid; i < MC * MP; i += 256) a.dx[(size_t)b * MC * MP + i] = dcur[i / MP][i % MP];
+}
+
+struct ReduceArgs {
+    t2s_mlp_grads g;
+    const float* part;
+    int B;
+};
+
+// grad element = sum over the series, in series order; one thread per element of one layer's N_LAYER block
+__global__ __launch_bounds__(256) void mlp_grad_reduce_kernel(const ReduceArgs a) {
+    const int layer = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N_LAYER) return;
+    constexpr int starts[15] = {N_WV, N_BV, N_WP, N_BP, N_LG, N_LB, N_W1, N_B1, N_W2, N_B2, N_W3, N_B3, N_W4, N_B4, N_LAYER};
+    float* const* dst = reinterpret_cast<float* const*>(&a.g.layer[layer]);
+    int seg = 0;
+#pragma unroll
+    for (int k = 1; k < 14; ++k) seg += i >= starts[k];
+    if (seg == 13 && i - N_B4 >= MP) return;     // padding behind mlp2.2.bias
+    const float* p = a.part + (size_t)layer * N_LAYER + i;
+    float s = 0.f;
+    for (int b = 0; b < a.B; ++b) s += p[(size_t)b * ML * N_LAYER];
+    dst[seg][i - starts[seg]] = s;
+}
+
 }  // namespace
 }  // namespace t2s
 
@@ -330,6 +690,44 @@ extern "C" int t2s_mlp_forward(const float* packed, const float* x, const float*
         mlp_forward_kernel<true><<<B, 256, 0, (hipStream_t)stream>>>(packed, x, t, freqs, text, out);
     else
         mlp_forward_kernel<false><<<B, 256, 0, (hipStream_t)stream>>>(packed, x, t, freqs, text, out);
+    T2S_LAUNCH_CHECK();
+    return T2S_OK;
+}
+
+extern "C" int t2s_mlp_backward(const t2s_mlp_weights* w, const float* packed, const float* x, const float* t, const float* freqs,
+                                const float* text, const float* dout, float* dx, const t2s_mlp_grads* grads, float* scratch,
+                                uint64_t scratch_floats, int B, void* stream) {
+    using namespace t2s;
+    T2S_REQUIRE(w && packed && x && t && freqs && dout && grads && scratch, "t2s_mlp_backward: null argument");
+    T2S_REQUIRE(B > 0, "t2s_mlp_backward: B = %d", B);
+    T2S_REQUIRE(scratch_floats >= (uint64_t)B * T2S_MLP_GRAD_PART_FLOATS, "t2s_mlp_backward: scratch holds %llu floats, B x %d needed",
+                (unsigned long long)scratch_floats, T2S_MLP_GRAD_PART_FLOATS);
+    if (int rc = check_device_extent(scratch, (size_t)B * T2S_MLP_GRAD_PART_FLOATS * sizeof(float), "t2s_mlp_backward: scratch")) return rc;
+    if (int rc = check_device_extent(packed, (size_t)T2S_MLP_PACKED_FLOATS * sizeof(float), "t2s_mlp_backward: packed")) return rc;
+    if (int rc = check_device_extent(x, (size_t)B * MC * MP * sizeof(float), "t2s_mlp_backward: x")) return rc;
+    if (int rc = check_device_extent(dout, (size_t)B * MC * MP * sizeof(float), "t2s_mlp_backward: dout")) return rc;
+    if (dx)
+        if (int rc = check_device_extent(dx, (size_t)B * MC * MP * sizeof(float), "t2s_mlp_backward: dx")) return rc;
+    static const size_t gsz[14] = {(size_t)MC * MT, MC, (size_t)MC * MC, MC, MC, MC, (size_t)MH * MC, MH, (size_t)MC * MH, MC, (size_t)MH * MP, MH,
+                                   (size_t)MP * MH, MP};
+    for (int l = 0; l < ML; ++l) {
+        float* const* gp = reinterpret_cast<float* const*>(&grads->layer[l]);
+        const float* const* wp = reinterpret_cast<const float* const*>(&w->layer[l]);
+        for (int k = 0; k < 14; ++k) {
+            T2S_REQUIRE(gp[k] && wp[k], "t2s_mlp_backward: layers.%d tensor %d is null", l, k);
+            if (int rc = check_device_extent(gp[k], gsz[k] * sizeof(float), "t2s_mlp_backward: a gradient tensor")) return rc;
+        }
+        if (int rc = check_device_extent(wp[6], gsz[6] * sizeof(float), "t2s_mlp_backward: mlp.0.weight")) return rc;
+        if (int rc = check_device_extent(wp[8], gsz[8] * sizeof(float), "t2s_mlp_backward: mlp.2.weight")) return rc;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    BwdArgs a;
+    a.w = *w; a.packed = packed; a.x = x; a.t = t; a.freqs = freqs; a.text = text; a.dout = dout; a.dx = dx; a.part = scratch;
+    mlp_backward_kernel<<<B, 256, 0, st>>>(a);
+    T2S_LAUNCH_CHECK();
+    ReduceArgs r;
+    r.g = *grads; r.part = scratch; r.B = B;
+    mlp_grad_reduce_kernel<<<dim3((N_LAYER + 255) / 256, ML), 256, 0, st>>>(r);
     T2S_LAUNCH_CHECK();
     return T2S_OK;
 }

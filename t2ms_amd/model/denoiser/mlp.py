@@ -5,13 +5,17 @@ positions, vqvae.py:70; SURVEY.md 8(d) prescribes the runnable form).  SURVEY 8(
   * Inference on a GPU (no autograd): `MLP.forward` is ONE launch of the HIP kernel `t2s_mlp_forward` (csrc/t2s_mlp.hip:
     all eight layers, one workgroup per series) on weights packed by `t2s_mlp_pack`; there is no other GPU inference path
     (a missing library raises).
-  * Under autograd (train.py --denoiser MLP) and on CPU tensors the layers below evaluate with torch ops, as the reference.
+  * Under autograd on a GPU (train.py --denoiser MLP) the same forward runs and the backward is `t2s_mlp_backward` (one
+    autograd node, `_MlpFn`; T2S_MLP_TORCH_AUTOGRAD=1 keeps torch-op autograd for A/B).
+  * On CPU tensors the layers below evaluate with torch ops, as the reference (the tests' reference path).
 State-dict keys equal the reference's, including the modules it constructs but never uses (norm1, norm3, pos_emb,
 self_attn, self_attn2) and the cross attention's query / key, which cannot influence the result (see t2s.h).
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -106,9 +110,23 @@ class MLP(nn.Module):
         needs_grad = torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters()))
         if input.is_cuda and not needs_grad:
             return self._forward_hip(input, t, text_input)
+        if (input.is_cuda and len(self.layers) == L.MLP_LAYERS and tuple(input.shape[1:]) == (WIDTH, POSITIONS)
+                and os.environ.get("T2S_MLP_TORCH_AUTOGRAD", "0") in ("", "0")):
+            # training on a GPU: forward AND backward in the HIP kernels (t2s_mlp_forward / t2s_mlp_backward)
+            return _MlpFn.apply(self, input, t, text_input, *self._all_layer_params())
         for layer in self.layers:
             input = layer(input, t, text_input)
         return input
+
+    def _all_layer_params(self):
+        """The 14 tensors per layer the kernels read (t2s_mlp_layer_weights order), then cross_attn.query / key weight and bias
+        per layer: they cannot influence the forward, autograd hands them exact zeros."""
+        qk = []
+        for layer in self._modules["layers"]._modules.values():
+            ca = layer._modules["cross_attn"]._modules
+            qk += [ca["query"]._parameters["weight"], ca["query"]._parameters["bias"], ca["key"]._parameters["weight"],
+                   ca["key"]._parameters["bias"]]
+        return self._hip_tensors() + qk
 
     # -- the HIP path -------------------------------------------------------------------------------------------------
     def _hip_tensors(self):
@@ -171,6 +189,51 @@ class MLP(nn.Module):
                                             L.dev_ptr(_freqs_on(device)), L.dev_ptr(text, "text_input"), out.data_ptr(), B,
                                             L.stream_ptr(device)), "t2s_mlp_forward")
         return out
+
+
+class _MlpFn(torch.autograd.Function):
+    """MLP.forward under autograd with both directions in the HIP kernels.  Only the input, t and the text are saved: the
+    backward kernel recomputes the forward (the model is 6.5 MFLOP per series)."""
+
+    @staticmethod
+    def forward(ctx, model, input, t, text_input, *params):
+        with torch.no_grad():
+            out = model._forward_hip(input, t, text_input)
+        ctx.model = model
+        ctx.has_text = text_input is not None
+        ctx.save_for_backward(L.as_f32(input), L.as_f32(t.to(input.device).reshape(-1)),
+                              L.as_f32(text_input.to(input.device)) if text_input is not None else input.new_zeros(1))
+        ctx.n_params = len(params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, tf, text = ctx.saved_tensors
+        model, dev, B = ctx.model, x.device, x.shape[0]
+        packed = model._packed(dev)                                   # the forward's weights: no step happens in between
+        ts = model._hip_tensors()
+        keep, w, g = [], L.MlpWeights(), L.MlpGrads()
+        grads = [torch.empty_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for p in ts]
+        it, ig = iter(ts), iter(grads)
+        for i in range(L.MLP_LAYERS):
+            for field, _ in L.MLP_LAYER_FIELDS:
+                src = L.as_f32(next(it).detach())
+                keep.append(src)
+                setattr(w.layer[i], field, L.dev_ptr(src))
+                setattr(g.layer[i], field, next(ig).data_ptr())
+        need_dx = ctx.needs_input_grad[1]
+        dx = torch.empty_like(x) if need_dx else None
+        scratch = torch.empty(B * L.MLP_GRAD_PART_FLOATS, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            L.check(L.lib().t2s_mlp_backward(C.byref(w), packed.data_ptr(), L.dev_ptr(x), L.dev_ptr(tf), L.dev_ptr(_freqs_on(dev)),
+                                             L.dev_ptr(text) if ctx.has_text else None, L.dev_ptr(L.as_f32(dout)),
+                                             None if dx is None else dx.data_ptr(), C.byref(g), scratch.data_ptr(), scratch.numel(), B,
+                                             L.stream_ptr(dev)), "t2s_mlp_backward")
+        # without a text the cross attention is skipped (mlp.py:75): its parameters get NO gradient, as under torch autograd
+        n_f = len(L.MLP_LAYER_FIELDS)
+        out = [gr if p.requires_grad and (ctx.has_text or i % n_f >= 4) else None for i, (gr, p) in enumerate(zip(grads, ts))]
+        qk = [torch.zeros_like(p) if p.requires_grad and ctx.has_text else None for p in model._all_layer_params()[len(ts):]]
+        return (None, dx, None, None, *out, *qk)
 
 
 for _cls in (MLP, MLPlayer, TextToSeriesCrossAttention, TimeEmbedding):

@@ -261,7 +261,7 @@ class T2SAdamW(torch.optim.Optimizer):
 # ---------------------------------------------------------------------------- data parallel
 def allreduce_param_grads(params, dist, n_local: Optional[int] = None, n_global: Optional[int] = None,
                           loss: Optional[torch.Tensor] = None):
-    """The same collective for a plain torch module (the MLP denoiser of BASELINE configs[0]: torch autograd, no persistent
+    """The same collective for a plain torch module (the MLP denoiser of BASELINE configs[0]: gradients from t2s_mlp_backward or torch autograd, no persistent
     bucket): the gradients of `params` are flattened into ONE message, weighted n_local / n_global, summed over the ranks
     and scattered back; a parameter without a gradient (empty shard) contributes zeros.  Returns the global mean loss."""
     if dist is None:

@@ -80,7 +80,7 @@ def test_latent_cache_plumbing_cpu():
 @pytest.mark.gpu
 def test_config1_end_to_end_through_infer_driver(tmp_path, monkeypatch):
     """BASELINE configs[0] wired end to end: `infer.py --denoiser MLP` on L=24 series, B=32,
-    50-step DDPM with CFG -- HIP encoder -> `before` (32,64,6) -> torch MLP denoiser + HIP DDPM update on the 6-wide
+    50-step DDPM with CFG -- HIP encoder -> `before` (32,64,6) -> MLP denoiser (t2s_mlp_forward) + HIP DDPM update on the 6-wide
     latent -> HIP Decoder(length=24) -- against the CPU oracle run on the same rows, draws (Philox restated in numpy)
     and weights; the four .npy files keep the reference layout."""
     import infer as drv
@@ -123,7 +123,7 @@ def test_config1_end_to_end_through_infer_driver(tmp_path, monkeypatch):
 @pytest.mark.gpu
 def test_train_driver_mlp_denoiser_then_infer(tmp_path, monkeypatch):
     """`train.py --denoiser MLP` (reference train.py:16 selects it from the same dict as the DiT): fixed-length L = 24
-    data, HIP encoder -> `before` (B,64,6), HIP q_sample / MSE, torch MLP forward / backward, the reference checkpoint
+    data, HIP encoder -> `before` (B,64,6), HIP q_sample / MSE, MLP forward / backward (t2s_mlp_forward / t2s_mlp_backward), the reference checkpoint
     dict -- the first step's loss equals the oracle's on the same rows and draws, the loss goes down, and `infer.py
     --denoiser MLP --checkpoint_id` consumes the checkpoint.  Mixed-length training is refused with a clear message."""
     import infer as idrv
@@ -257,3 +257,54 @@ def test_hip_mlp_repacks_after_weight_changes_and_checks_extents():
     L.check(lib.t2s_mlp_forward(packed.data_ptr(), xa.data_ptr(), tz.data_ptr(), fr.data_ptr(), None, xa.data_ptr(), 4, None))
     torch.cuda.synchronize()
     assert torch.equal(xa, out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,with_text", [(1, True), (5, True), (33, False)])
+def test_hip_mlp_backward_vs_autograd(B, with_text):
+    """train.py --denoiser MLP: `MLP.forward` under autograd on a GPU = t2s_mlp_forward + t2s_mlp_backward.  All 112 parameter
+    gradients and the input gradient against torch autograd through the same mirror's torch-op layers on the CPU in float64;
+    cross_attn.query / key get exact zeros (autograd's own are rounding noise); bit-reproducible."""
+    import copy
+    m = _gpu_mlp(11)
+    ref = copy.deepcopy(m).cpu().double()
+    rs = np.random.RandomState(100 + B)
+    x = torch.from_numpy(rs.randn(B, 64, 6).astype(np.float32))
+    t = torch.from_numpy(rs.randint(0, 100, size=B))
+    text = synth.make_text_embeddings(13, B) if with_text else None
+    wgt = torch.from_numpy(rs.randn(B, 64, 6).astype(np.float32))
+
+    def run_gpu():
+        for p in m.parameters():
+            p.grad = None
+        xg = x.cuda().requires_grad_(True)
+        y = m(xg, t.cuda(), None if text is None else text.cuda())
+        assert type(y.grad_fn).__name__ == "_MlpFnBackward"
+        (y * wgt.cuda()).sum().backward()
+        return y.detach(), xg.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    y, dx, g = run_gpu()
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr, t, None if text is None else text.double())
+    (yr * wgt.double()).sum().backward()
+    scale = max(1.0, float(yr.detach().abs().max()))
+    assert float((y.cpu().double() - yr.detach()).abs().max()) < 2e-5 * scale
+    assert float((dx.cpu().double() - xr.grad).abs().max()) < 2e-4 * float(xr.grad.abs().max())
+    checked = 0
+    # (a layer's mlp2.2.bias adds one value to all 64 channels of a position, which the NEXT layer's LayerNorm removes: its
+    # true gradient is zero in layers 0..6 -- hence the absolute floor, relative to the largest gradient of the model)
+    floor = 1e-6 * max(float(pr.grad.abs().max()) for pr in ref.parameters() if pr.grad is not None)
+    for n, pr in ref.named_parameters():
+        if pr.grad is None:
+            assert n not in g, n                                   # the never-called modules get no gradient on either side
+            continue
+        got = g[n].cpu().double()
+        if ".cross_attn.query." in n or ".cross_attn.key." in n:
+            assert float(got.abs().max()) == 0.0 and float(pr.grad.abs().max()) < 1e-9 * scale, n
+            continue
+        tol = 2e-4 * float(pr.grad.abs().max()) + floor
+        assert float((got - pr.grad).abs().max()) < tol, (n, float((got - pr.grad).abs().max()), tol)
+        checked += 1
+    assert checked == (8 * 14 if with_text else 8 * 10)
+    y2, dx2, g2 = run_gpu()
+    assert torch.equal(y, y2) and torch.equal(dx, dx2) and all(torch.equal(g[n], g2[n]) for n in g)

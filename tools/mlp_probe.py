@@ -69,6 +69,22 @@ def main():
     with torch.no_grad():
         out["loop50_ms_hip"] = round(1e3 * timed(lambda: loop(m), 5), 2)
         out["loop50_ms_torch_ops"] = round(1e3 * timed(lambda: loop(torch_forward), 2), 2)
+    # one training forward + backward at B = 32 (train.py --denoiser MLP): HIP autograd node against torch-op autograd
+    B = 32
+    xg = torch.randn(B, 64, 6, device=dev)
+    tt = torch.randint(0, 100, (B,), device=dev)
+    wgt = torch.randn(B, 64, 6, device=dev)
+
+    def train_pass():
+        for p in m.parameters():
+            p.grad = None
+        (m(xg, tt, text) * wgt).sum().backward()
+    m.train()
+    out["fwd_bwd_ms_hip_B32"] = round(1e3 * timed(train_pass, 20), 3)
+    os.environ["T2S_MLP_TORCH_AUTOGRAD"] = "1"
+    out["fwd_bwd_ms_torch_ops_B32"] = round(1e3 * timed(train_pass, 5), 3)
+    os.environ.pop("T2S_MLP_TORCH_AUTOGRAD")
+    m.eval()
     out["series_per_s_hip"] = round(B / (out["loop50_ms_hip"] / 1e3), 1)
     out["series_per_s_torch_ops"] = round(B / (out["loop50_ms_torch_ops"] / 1e3), 1)
     print(json.dumps(out))

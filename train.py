@@ -99,7 +99,7 @@ def train_step(model, backbone, opt, dist, args, x_1, emb, device, rank, world, 
     loss = None
     is_mlp = getattr(args, "denoiser", "DiT") == "MLP"
     if n > 0 and is_mlp:
-        # BASELINE configs[0] in the runnable form SURVEY.md 8(d) prescribes: the MLP denoiser (a torch module) diffuses
+        # BASELINE configs[0] in the runnable form SURVEY.md 8(d) prescribes: the MLP denoiser (t2s_mlp_forward / t2s_mlp_backward behind its autograd node) diffuses
         # the PRE-interpolation latent `before` (B,64,L/4 = 6); encoder, q_sample and the loss are the HIP kernels
         emb = _h2d(emb[lo:hi].float(), device)
         with torch.no_grad():
@@ -196,7 +196,7 @@ def train(args):
     model.encoder = vae.encoder
     if args.bf16:
         if args.denoiser != "DiT":
-            raise ValueError("--bf16 selects the DiT training kernels' arithmetic; the MLP denoiser is a torch module")
+            raise ValueError("--bf16 selects the DiT training kernels' arithmetic; the MLP denoiser trains in fp32 (t2s_mlp_backward)")
         model.set_train_dtype("bf16")
     for name, p in model.named_parameters():
         if "encoder" in name:
