@@ -49,7 +49,9 @@ __device__ __forceinline__ unsigned long long x3_clk() {
 #else
 #define X3_STAMP_DECL
 #define X3_STAMP(k)
-#define X3_SYNC() wg_sync();
+// (explicit vmcnt(0): every weight DMA of this kernel is issued by untracked inline asm, the fence inside wg_sync() only covers
+// what hipcc tracks -- as ROWS_SYNC in t2s_rows.h)
+#define X3_SYNC() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); wg_sync(); }
 // the same, but the 16 YOUNGEST vector-memory operations of the wave may still be in flight (the tile's residual stream, issued
 // last on purpose: it is first needed after the proj chunks).  Not wg_sync(): its release fence waits for vmcnt(0).
 #define X3_SYNC_BUT16() { asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
