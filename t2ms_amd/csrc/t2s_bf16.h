@@ -307,8 +307,25 @@ __global__ __launch_bounds__(bg_threads(EPI)) T2S_NO_PK_F32 void bgemm_kernel(co
     // 5.6 TB/s of loads), so two 32-column n-tiles are gathered in LDS and leave as whole 128-byte lines, 16 bytes per
     // lane (q / k / v head tiles: 64-byte rows that are contiguous across tokens, one 2 KiB run per n-tile).
     char* stage = wl + (size_t)N * K * 2 + (size_t)N * 4 + (size_t)(threadIdx.x >> 6) * BG_STAGE_BYTES;
-    for (int c = threadIdx.x; c < N * K / 8; c += THREADS) wlds[c] = a.Wp[c];
-    for (int c = threadIdx.x; c < N; c += THREADS) blds[c] = a.bias != nullptr ? a.bias[c] : 0.f;
+    {   // the weights into LDS: every load first, then every ds_write -- as a load -> store loop hipcc waits vmcnt(0) in front of
+        // each store, 3 ... 8 serial L2 round trips per workgroup and launch (2-5 us of launches that take 50-280 us)
+        constexpr int ITER = (N * K / 8 + THREADS - 1) / THREADS;
+        bf16x8 wt[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int c = threadIdx.x + it * THREADS;
+            if (c < N * K / 8) wt[it] = a.Wp[c];
+        }
+        float bt = 0.f;
+        if (threadIdx.x < N && a.bias != nullptr) bt = a.bias[threadIdx.x];
+        static_assert(N <= THREADS, "one bias element per thread");
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int c = threadIdx.x + it * THREADS;
+            if (c < N * K / 8) wlds[c] = wt[it];
+        }
+        if (threadIdx.x < N) blds[threadIdx.x] = bt;
+    }
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
