@@ -72,6 +72,24 @@ __device__ __forceinline__ void load_rows16(const f32x4* __restrict__ tile_base,
         x[mt] = q ? f32x4{qa[1], qa[3], qb[1], qb[3]} : f32x4{qa[0], qa[2], qb[0], qb[2]};
     }
 }
+// the same in two halves -- the 16 loads now, the selection when the values are first needed -- so that the loads can stay in
+// flight across the kernel's first barrier (ROWS_SYNC_BUT16)
+template <int NB>
+__device__ __forceinline__ void load_rows16_raw(const f32x4* __restrict__ tile_base, int h, int row, f32x4 (&raw)[2 * NB]) {
+#pragma unroll
+    for (int mt = 0; mt < NB; ++mt) {
+        raw[2 * mt] = tile_base[(2 * mt) * 64 + 32 * h + row];
+        raw[2 * mt + 1] = tile_base[(2 * mt + 1) * 64 + 32 * h + row];
+    }
+}
+template <int NB>
+__device__ __forceinline__ void select_rows16(const f32x4 (&raw)[2 * NB], int q, f32x4 (&x)[NB]) {
+#pragma unroll
+    for (int mt = 0; mt < NB; ++mt) {
+        const f32x4 qa = raw[2 * mt], qb = raw[2 * mt + 1];
+        x[mt] = q ? f32x4{qa[1], qa[3], qb[1], qb[3]} : f32x4{qa[0], qa[2], qb[0], qb[2]};
+    }
+}
 // the reverse: lanes q = 0 end up with the whole second quad of a block, lanes q = 1 with the first, one 16-byte store each
 template <int NB>
 __device__ __forceinline__ void store_rows16(f32x4* __restrict__ tile_base, int h, int q, int row, const f32x4 (&x)[NB]) {
@@ -215,25 +233,47 @@ __global__ __launch_bounds__(256, 2) void dit_rows16_kernel(const RowArgs a) {
     // ---- per-feature constants in LDS, 16-layout order (element (f & ~15) | pos16(f & 15) holds feature f) ----
     float* cb = reinterpret_cast<float*>(wring + ROWS_SLOTS * ROWS_CHUNK_F4);
     float* cm = cb + ROWS_CB_FLOATS + wave * ROWS_CMF;
+    // Order of the prologue's vector-memory operations (round 5, as t2s_rows.h): the weight DMAs, the attention output (first:
+    // its round trip runs under the constants'), the constants as ONE batch of loads then one batch of ds_writes, and LAST the
+    // residual stream, which the first barrier leaves in flight (ROWS_SYNC_BUT16).  At the launch sizes this kernel serves a
+    // launch is a single round of waves: the prologue's serial round trips are not hidden by anything.
+    f32x4 araw[DO_MLP ? 16 : 1];
     if constexpr (DO_MLP) {
-        for (int i = threadIdx.x; i < 512; i += 256)
-            cb[(i & ~15) | pos16(i & 15)] = i < 128 ? a.bp[i] : (i < 384 ? a.b1[i - 128] : a.b2[i - 384]);
-        const float* src = modrow + a.blk * MODW;
-#pragma unroll
-        for (int i = 1; i < 3; ++i) {
-            const int f0 = (i * 64 + lane) * 4;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src + f0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) cm[((f0 + e) & ~15) | pos16((f0 + e) & 15)] = v[e];
-        }
+        load_rows16_raw<8>(reinterpret_cast<const f32x4*>(a.ao) + (size_t)tile * 16 * 64, h, row, araw);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (DO_QKV) {
-        for (int i = threadIdx.x; i < 384; i += 256) cb[512 + ((i & ~15) | pos16(i & 15))] = a.bq[i];
-        const float* src = modrow + a.qkv_blk * MODW;   // shift_msa | scale_msa
-        const int f0 = lane * 4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + f0);
+    {
+        const int t0 = threadIdx.x, t1 = t0 + 256;
+        float c0 = 0.f, c1 = 0.f, q0 = 0.f, q1 = 0.f;
+        f32x4 m1 = {}, m2 = {}, mq = {};
+        if constexpr (DO_MLP) {
+            c0 = t0 < 128 ? a.bp[t0] : a.b1[t0 - 128];
+            c1 = t1 < 384 ? a.b1[t1 - 128] : a.b2[t1 - 384];
+            const float* src = modrow + a.blk * MODW;
+            m1 = *reinterpret_cast<const f32x4*>(src + (64 + lane) * 4);
+            m2 = *reinterpret_cast<const f32x4*>(src + (128 + lane) * 4);
+        }
+        if constexpr (DO_QKV) {
+            q0 = a.bq[t0];
+            if (t1 < 384) q1 = a.bq[t1];
+            mq = *reinterpret_cast<const f32x4*>(modrow + a.qkv_blk * MODW + lane * 4);   // shift_msa | scale_msa
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        auto put4 = [&](float* base, int f0, const f32x4& v) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) cm[((f0 + e) & ~15) | pos16((f0 + e) & 15)] = v[e];
+            for (int e = 0; e < 4; ++e) base[((f0 + e) & ~15) | pos16((f0 + e) & 15)] = v[e];
+        };
+        if constexpr (DO_MLP) {
+            cb[(t0 & ~15) | pos16(t0 & 15)] = c0;
+            cb[(t1 & ~15) | pos16(t1 & 15)] = c1;
+            put4(cm, (64 + lane) * 4, m1);
+            put4(cm, (128 + lane) * 4, m2);
+        }
+        if constexpr (DO_QKV) {
+            cb[512 + ((t0 & ~15) | pos16(t0 & 15))] = q0;
+            if (t1 < 384) cb[512 + ((t1 & ~15) | pos16(t1 & 15))] = q1;
+            put4(cm, lane * 4, mq);
+        }
     }
     const float* c_bp = cb;
     const float* c_b1 = cb + 128;
@@ -274,22 +314,26 @@ __global__ __launch_bounds__(256, 2) void dit_rows16_kernel(const RowArgs a) {
             generated = true;
         }
     }
-    if (!generated) load_rows16<8>(reinterpret_cast<const f32x4*>(a.x_in) + (size_t)tile_src * 16 * 64, h, q, row, x);
+    if (!DO_MLP && !generated) load_rows16<8>(reinterpret_cast<const f32x4*>(a.x_in) + (size_t)tile_src * 16 * 64, h, q, row, x);
     int ci = 0;
 
     if constexpr (DO_MLP) {
         const float* mb = cm;   // [shift_msa, scale_msa of the qkv block | gate_msa, shift_mlp, scale_mlp, gate_mlp of a.blk]
         // ---------------- x += gate_msa * (proj(ao) + b) ----------------
         {
-            f32x4 bop[8];
-            load_rows16<8>(reinterpret_cast<const f32x4*>(a.ao) + (size_t)tile * 16 * 64, h, q, row, bop);
-            ROWS_SYNC();  // chunk 0 landed, constants visible
+            f32x4 bop[8], xraw[16];
+            __builtin_amdgcn_sched_barrier(0);
+            load_rows16_raw<8>(reinterpret_cast<const f32x4*>(a.x_in) + (size_t)tile_src * 16 * 64, h, row, xraw);
+            __builtin_amdgcn_sched_barrier(0);
+            select_rows16<8>(araw, q, bop);
+            ROWS_SYNC_BUT16();  // chunk 0 landed, ao and the constants here; the residual stream (16 loads) may still be on its way
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 prefetch(ci);
                 const f32x4* wb = wring + (ci % ROWS_SLOTS) * ROWS_CHUNK_F4 + lane;
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                 kchunk16<false>(wb, bop, acc0, acc1);
+                if (c == 0) select_rows16<8>(xraw, q, x);     // first use of the residual stream: it has landed behind the MFMAs
 #pragma unroll
                 for (int ml = 0; ml < 2; ++ml) {
                     const f32x4 bias = ldc16(c_bp, 2 * c + ml, g);

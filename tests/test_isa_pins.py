@@ -102,6 +102,7 @@ def test_x3_row_kernels_scratch_is_bounded(reports, kernel):
 
 # the <proj + MLP ...> row kernels (f32 and bf16x3) leave their residual stream in flight across the FIRST barrier
 BUT16 = [NS + "15dit_rows_kernelILb1ELb1EEEvNS_7RowArgsE", NS + "15dit_rows_kernelILb1ELb0EEEvNS_7RowArgsE",
+         NS + "17dit_rows16_kernelILb1ELb1EEEvNS_7RowArgsE", NS + "17dit_rows16_kernelILb1ELb0EEEvNS_7RowArgsE",
          NS + "18dit_rows_x3_kernelILb1ELb1EEEvNS_9RowArgsX3E", NS + "18dit_rows_x3_kernelILb1ELb0EEEvNS_9RowArgsX3E"]
 
 
