@@ -242,17 +242,22 @@ __device__ __forceinline__ void attn_packed_body(f32x4* ring, const f32x4* qg, c
     }
 }
 
+// PARTS = 2: two workgroups per (sequence, head), two query tiles per wave.  PARTS = 4 (launches too small to fill the chip
+// otherwise): four workgroups per head, ONE query tile per wave -- twice the waves per SIMD for the same matrix work, K / V
+// streamed four times per head from L2.  Tile 15 does not exist: the wave that would own it repeats tile 14 (same bits,
+// stored twice).
+template <int PARTS>
 __global__ __launch_bounds__(256, 2) void attn_fwd_packed_kernel(const float* __restrict__ q,
                                                                  const float* __restrict__ k,
                                                                  const float* __restrict__ vT,
                                                                  float* __restrict__ o, int BH) {
     extern __shared__ __attribute__((aligned(16))) f32x4 ring[];
-    // The two workgroups of a (sequence, head) stream the same K/V: give them ids r and r+8 of a
-    // 16-id group so that (round-robin XCD placement) they share an L2.  Speed only.
-    const int grp = blockIdx.x >> 4, rr = blockIdx.x & 15;
+    // The workgroups of a (sequence, head) stream the same K/V: give them ids r, r+8, ... of a
+    // (8 PARTS)-id group so that (round-robin XCD placement) they share an L2.  Speed only.
+    const int grp = blockIdx.x / (8 * PARTS), rr = blockIdx.x % (8 * PARTS);
     const int bh = grp * 8 + (rr & 7);
-    const int part = rr >> 3;                 // query tiles [8*part, 8*part+8)
-    if (bh >= BH) return;                     // whole workgroup (grid is padded to 16-id groups)
+    const int part = rr >> 3;                 // query tiles [8*part, 8*part+8) (PARTS = 2) / [4*part, 4*part+4) (PARTS = 4)
+    if (bh >= BH) return;                     // whole workgroup (grid is padded to whole groups)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const f32x4* qg = reinterpret_cast<const f32x4*>(q) + (size_t)bh * NKB * 256;
@@ -272,11 +277,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_packed_kernel(const float* __
         glds16_asm(kg + (2 * 4 + wave) * 64 + lane, slot2 + wave * 64);
         glds16_asm(vg + (2 * 4 + wave) * 64 + lane, slot2 + 256 + wave * 64);
     }
-    const int t0 = part * 8 + wave * 2;       // query tiles t0, t0+1 (tile 15 does not exist)
-    if (t0 + 1 < NKB)
-        attn_packed_body<2>(ring, qg, kg, vg, og, bh, t0, lane, wave);
-    else
-        attn_packed_body<1>(ring, qg, kg, vg, og, bh, t0, lane, wave);
+    if constexpr (PARTS == 2) {
+        const int t0 = part * 8 + wave * 2;       // query tiles t0, t0+1 (tile 15 does not exist)
+        if (t0 + 1 < NKB)
+            attn_packed_body<2>(ring, qg, kg, vg, og, bh, t0, lane, wave);
+        else
+            attn_packed_body<1>(ring, qg, kg, vg, og, bh, t0, lane, wave);
+    } else {
+        const int t = part * 4 + wave;
+        attn_packed_body<1>(ring, qg, kg, vg, og, bh, t < NKB ? t : NKB - 1, lane, wave);
+    }
 }
 
 // ------------------------------------------------------------------ persistent variant
@@ -467,7 +477,15 @@ int launch_attn_packed(const float* q, const float* k, const float* vT, float* o
         // persistent: one 8-wave workgroup per CU walks the heads
         attn_fwd_persistent_kernel<<<n_cu, PERSIST_THREADS, ATT_LDS_BYTES, st>>>(q, k, vT, o, BH);
     } else {
-        attn_fwd_packed_kernel<<<((BH + 7) / 8) * 16, 256, ATT_LDS_BYTES, st>>>(q, k, vT, o, BH);
+        // four workgroups per head while two per head would leave CUs without a workgroup of this launch (fewer than 128 heads:
+        // 16 sequences, i.e. 8 series with CFG): series/s at 8 series 27.5 against 22.8 (+20 %); from 128 heads on two per head
+        // are as good or better (32 series: 57.9 against 56.3) -- profiles/r05_attn_parts_ab.txt.  T2S_ATTN_PARTS=2 / 4 fixes it (A/B).
+        static const int parts_env = getenv("T2S_ATTN_PARTS") ? atoi(getenv("T2S_ATTN_PARTS")) : 0;
+        const int parts = parts_env == 2 || parts_env == 4 ? parts_env : (((BH + 7) / 8) * 16 < n_cu ? 4 : 2);
+        if (parts == 4)
+            attn_fwd_packed_kernel<4><<<((BH + 7) / 8) * 32, 256, ATT_LDS_BYTES, st>>>(q, k, vT, o, BH);
+        else
+            attn_fwd_packed_kernel<2><<<((BH + 7) / 8) * 16, 256, ATT_LDS_BYTES, st>>>(q, k, vT, o, BH);
     }
     T2S_LAUNCH_CHECK();
     return T2S_OK;

@@ -33,7 +33,8 @@ NS = "_ZN3t2s"
 # kernel -> (VGPR budget, scratch bytes allowed, [(mfma, lds_dma, loads, stores, scratch ops, vmcnt waits)] streaming loops)
 PINS = {
     # attention, 4-slot K / V^T ring (t2s_attn.hip): packed = one head per workgroup pair, persistent = one workgroup per CU
-    NS + "22attn_fwd_packed_kernelEPKfS1_S1_Pfi": (256, 0, [(32, 2, 0, 0, 0, (4,)), (64, 2, 0, 0, 0, (4,))]),
+    NS + "22attn_fwd_packed_kernelILi2EEEvPKfS2_S2_Pfi": (256, 0, [(32, 2, 0, 0, 0, (4,)), (64, 2, 0, 0, 0, (4,))]),
+    NS + "22attn_fwd_packed_kernelILi4EEEvPKfS2_S2_Pfi": (128, 0, [(32, 2, 0, 0, 0, (4,))]),   # one query tile per wave
     NS + "26attn_fwd_persistent_kernelEPKfS1_S1_Pfi": (256, 0, [(48, 1, 0, 0, 0, (2,)), (16, 1, 0, 8, 0, (10, 9, 10, 10, 8, 7, 2)),
                                                                  (96, 1, 0, 0, 0, (2,))]),
     # row chain, 3-slot weight ring two chunks ahead (t2s_rows.h): <DO_MLP, DO_QKV>
@@ -89,7 +90,8 @@ def test_f32_path_uses_the_f32_matrix_instruction(reports):
         dis = isa.disassemble(co)
     finally:
         shutil.rmtree(wd, ignore_errors=True)
-    for k in (NS + "22attn_fwd_packed_kernelEPKfS1_S1_Pfi", NS + "26attn_fwd_persistent_kernelEPKfS1_S1_Pfi"):
+    for k in (NS + "22attn_fwd_packed_kernelILi2EEEvPKfS2_S2_Pfi", NS + "22attn_fwd_packed_kernelILi4EEEvPKfS2_S2_Pfi",
+              NS + "26attn_fwd_persistent_kernelEPKfS1_S1_Pfi"):
         kinds = {mn for _, mn, _ in dis[k] if mn.startswith("v_mfma")}
         assert kinds == {"v_mfma_f32_32x32x2_f32"}, (k, kinds)
 
