@@ -170,32 +170,16 @@ __global__ __launch_bounds__(256) void patchify_kernel(
     const int tokg = tile * 32 + (l & 31);
     const int c4 = 2 * G + (l >> 5);  // float4 column index: cols 4*c4 .. 4*c4+3
     const int s = tokg / NTOK, n = tokg - s * NTOK;
-    const int hh = n >> 5, ww = n & 31;
-    const float* xin = x + (size_t)(s % B) * LAT;
-    float px[2][2];  // [i][j]
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) px[i][j] = xin[(2 * ww + j) * LATW + 2 * hh + i];
+    // the SAME helpers as the row kernels' patchify prologue (t2s_rows.h): explicit fmaf chains, so the two forms agree bit for
+    // bit whatever the compiler would contract on its own (tests/test_hip_contracts.py runs both)
+    struct { const float* p_lat; int p_B; const float *p_cw, *p_cb; } pa{x, B, cw, cb};
     float cv[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        float acc = cw[c * 4 + 0] * px[0][0];
-        acc += cw[c * 4 + 1] * px[0][1];
-        acc += cw[c * 4 + 2] * px[1][0];
-        acc += cw[c * 4 + 3] * px[1][1];
-        cv[c] = acc + cb[c];
-    }
+    patch_conv(pa, s, n, cv);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int d = c4 * 4 + e;
-        const f32x4 w = *reinterpret_cast<const f32x4*>(pw + d * 4);
-        float acc = w.x * cv[0];
-        acc += w.y * cv[1];
-        acc += w.z * cv[2];
-        acc += w.w * cv[3];
-        o[e] = acc + pb[d] + pos[n * D + d];
+        o[e] = patch_feature(cv, *reinterpret_cast<const f32x4*>(pw + d * 4), pb[d], pos[n * D + d]);
     }
     reinterpret_cast<f32x4*>(h)[gid] = o;
 }

@@ -1,6 +1,7 @@
 """Contracts of the C ABI and of the class-API mirror that round 5 closed at their cause:
 sizes behind the raw weight pointers, the handle-free time embedding, the stateless MSE reduction, and the limits of the
 class-API pairing (torch.inference_mode(), writes torch cannot see).  Needs a real MI355X (`pytest -m gpu`)."""
+import os
 import ctypes as C
 import threading
 
@@ -322,3 +323,44 @@ def test_infer_driver_at_its_shipped_default_math(dev, tmp_path, monkeypatch):
         assert float(np.abs(outs[tag]["x_t"][:, :, 0] - series.reshape(n, L_).numpy()).max()) < 1e-4 * scale, tag
     assert not np.array_equal(outs["default"]["x_t_latent_dec_array"], outs["f32"]["x_t_latent_dec_array"])   # two arithmetics...
     assert float(np.abs(outs["default"]["x_t_latent_dec_array"] - outs["f32"]["x_t_latent_dec_array"]).max()) < 1e-4 * scale   # ...one accuracy
+
+
+# ------------------------------------------------------------------------------------------------ patchify in the prologue
+_PATCH_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {repo!r})
+from t2ms_amd import synth
+from model.denoiser.transformer import Transformer
+dev = torch.device("cuda", 0)
+m = Transformer(); m.load_state_dict(synth.make_dit_state_dict(31337, gain=0.7), strict=True); m = m.to(dev).eval()
+out = {{}}
+for math in ("f32", "bf16x3"):
+    m.set_math(math)
+    for B in (3, 40):
+        x = synth.make_latents(5, B).to(dev); t = torch.arange(B, device=dev) % 50
+        text = synth.make_text_embeddings(9, B).to(dev)
+        with torch.no_grad():
+            out[f"{{math}}_{{B}}_c"] = m(input=x, t=t, text_input=text).cpu().numpy()
+            out[f"{{math}}_{{B}}_u"] = m(input=x, t=t, text_input=None).cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_patchify_in_the_row_kernels_prologue_is_bitwise_the_standalone_kernel(dev, tmp_path):
+    """Block 0's tokens are generated in the prologue of the <qkv only> row kernel (32-token f32, 16-token f32 and -- round 5 --
+    bf16x3) with the helpers `patchify_kernel` uses: T2S_PATCHIFY_KERNEL=1 (read once per process, hence two child processes)
+    brings the stand-alone launch back and must not change a bit, in either arithmetic, at a 16-token and a 32-token size."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "patch_ab.py"
+    script.write_text(_PATCH_SCRIPT.format(repo=repo))
+    outs = []
+    for flag in ("0", "1"):
+        dst = str(tmp_path / f"out_{flag}.npz")
+        env = dict(os.environ, T2S_PATCHIFY_KERNEL=flag)
+        subprocess.run([sys.executable, str(script), dst], check=True, env=env, cwd=repo, timeout=300)
+        outs.append(np.load(dst))
+    assert set(outs[0].files) == set(outs[1].files) and len(outs[0].files) == 8
+    for k in outs[0].files:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
