@@ -474,8 +474,10 @@ int launch_attn_packed(const float* q, const float* k, const float* vT, float* o
     // the switch sat there while the 32-series shard ran as one chain.)  T2S_ATTN_PERSIST_MIN=<heads> moves the switch.
     static const int persist_min = getenv("T2S_ATTN_PERSIST_MIN") ? atoi(getenv("T2S_ATTN_PERSIST_MIN")) : 0;
     if (BH >= (persist_min > 0 ? persist_min : 3 * n_cu)) {
-        // persistent: one 8-wave workgroup per CU walks the heads
-        attn_fwd_persistent_kernel<<<n_cu, PERSIST_THREADS, ATT_LDS_BYTES, st>>>(q, k, vT, o, BH);
+        // persistent: one 8-wave workgroup per CU walks the heads.  Never more workgroups than heads: a workgroup without a head
+        // of its own would start its K / V ring at a negative head index (the default switch keeps BH >= 3 n_cu; the A/B
+        // switch T2S_ATTN_PERSIST_MIN can put fewer heads than CUs here -- found by tests/test_hip_contracts.py in round 5)
+        attn_fwd_persistent_kernel<<<BH < n_cu ? BH : n_cu, PERSIST_THREADS, ATT_LDS_BYTES, st>>>(q, k, vT, o, BH);
     } else {
         // four workgroups per head while two per head would leave CUs without a workgroup of this launch (fewer than 128 heads:
         // 16 sequences, i.e. 8 series with CFG): series/s at 8 series 27.5 against 22.8 (+20 %); from 128 heads on two per head

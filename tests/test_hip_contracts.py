@@ -346,21 +346,26 @@ np.savez(sys.argv[1], **out)
 """
 
 
-def test_patchify_in_the_row_kernels_prologue_is_bitwise_the_standalone_kernel(dev, tmp_path):
-    """Block 0's tokens are generated in the prologue of the <qkv only> row kernel (32-token f32, 16-token f32 and -- round 5 --
-    bf16x3) with the helpers `patchify_kernel` uses: T2S_PATCHIFY_KERNEL=1 (read once per process, hence two child processes)
-    brings the stand-alone launch back and must not change a bit, in either arithmetic, at a 16-token and a 32-token size."""
+@pytest.mark.parametrize("var,values", [("T2S_PATCHIFY_KERNEL", ("0", "1")), ("T2S_ATTN_PARTS", ("2", "4")),
+                                        ("T2S_ATTN_PERSIST_MIN", ("1", "100000"))])
+def test_scheduling_switches_do_not_change_a_bit(dev, tmp_path, var, values):
+    """Switches that only choose a launch FORM, each read once per process (hence child processes), must not change a bit in either
+    arithmetic at a 16-token and a 32-token size:
+      T2S_PATCHIFY_KERNEL  block 0's tokens from the prologue of the <qkv only> row kernel (32-token f32, 16-token f32 and -- round
+                           5 -- bf16x3) or from the stand-alone patchify_kernel (same helpers);
+      T2S_ATTN_PARTS       two or four workgroups per head in the small-launch attention kernel (one or two query tiles per wave);
+      T2S_ATTN_PERSIST_MIN the persistent attention kernel from one head on / never (f32)."""
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = tmp_path / "patch_ab.py"
+    script = tmp_path / "switch_ab.py"
     script.write_text(_PATCH_SCRIPT.format(repo=repo))
     outs = []
-    for flag in ("0", "1"):
+    for flag in values:
         dst = str(tmp_path / f"out_{flag}.npz")
-        env = dict(os.environ, T2S_PATCHIFY_KERNEL=flag)
+        env = dict(os.environ, **{var: flag})
         subprocess.run([sys.executable, str(script), dst], check=True, env=env, cwd=repo, timeout=300)
         outs.append(np.load(dst))
     assert set(outs[0].files) == set(outs[1].files) and len(outs[0].files) == 8
     for k in outs[0].files:
-        assert np.array_equal(outs[0][k], outs[1][k]), k
+        assert np.array_equal(outs[0][k], outs[1][k]), (var, k)
