@@ -347,14 +347,15 @@ np.savez(sys.argv[1], **out)
 
 
 @pytest.mark.parametrize("var,values", [("T2S_PATCHIFY_KERNEL", ("0", "1")), ("T2S_ATTN_PARTS", ("2", "4")),
-                                        ("T2S_ATTN_PERSIST_MIN", ("1", "100000"))])
+                                        ("T2S_ATTN_PERSIST_MIN", ("1", "100000")), ("T2S_ROWS16_MAX_SEQS", ("0", "100000"))])
 def test_scheduling_switches_do_not_change_a_bit(dev, tmp_path, var, values):
     """Switches that only choose a launch FORM, each read once per process (hence child processes), must not change a bit in either
     arithmetic at a 16-token and a 32-token size:
       T2S_PATCHIFY_KERNEL  block 0's tokens from the prologue of the <qkv only> row kernel (32-token f32, 16-token f32 and -- round
                            5 -- bf16x3) or from the stand-alone patchify_kernel (same helpers);
       T2S_ATTN_PARTS       two or four workgroups per head in the small-launch attention kernel (one or two query tiles per wave);
-      T2S_ATTN_PERSIST_MIN the persistent attention kernel from one head on / never (f32)."""
+      T2S_ATTN_PERSIST_MIN the persistent attention kernel from one head on / never (f32);
+      T2S_ROWS16_MAX_SEQS  the 16-token row kernels never / always (f32)."""
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
