@@ -709,3 +709,49 @@ def test_train_driver_with_unfrozen_encoder(dev, tmp_path, monkeypatch):
     assert len(ck["optimizer"]["state"]) == 48 + 12
     # "False" is a non-empty string: frozen, exactly as the reference's argparse line behaves
     assert drv.get_args([a if a != "" or i == 0 or argv[i - 1] != "--usepretrainedvae" else "False" for i, a in enumerate(argv)]).usepretrainedvae
+
+
+_FLIP_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {repo!r})
+from t2ms_amd import synth
+from t2ms_amd.train import mse_loss
+from model.denoiser.transformer import Transformer
+dev = torch.device("cuda", 0)
+out = {{}}
+for dtype in ("f32", "bf16"):
+    m = Transformer(); m.load_state_dict(synth.make_dit_state_dict(2025), strict=True); m = m.to(dev).train().set_train_dtype(dtype)
+    B = 40
+    x = synth.make_latents(3, B).to(dev); t = (torch.arange(B, device=dev) * 7) % 100
+    text = synth.make_text_embeddings(5, B).to(dev); target = synth.make_latents(4, B).to(dev)
+    for rep in range(2):                                   # two steps: the flip parity restarts at the top of every forward
+        for p in m.parameters():
+            p.grad = None
+        pred = m(input=x, t=t, text_input=text)
+        mse_loss(pred, target).backward()
+    out[dtype + "_pred"] = pred.detach().cpu().numpy()
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            out[dtype + "_" + n] = p.grad.detach().cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_tile_walk_direction_changes_no_bit(dev, tmp_path):
+    """consecutive launches of the training step walk their tiles in OPPOSITE directions so that a consumer starts on what
+    the Infinity Cache still holds (T2S_TILE_FLIP, default on).  "Results do not depend on the order": tiles are independent and
+    every partial-sum slot keeps its slab index -- so the prediction and all 48 gradients must be the same BITS with the flip off,
+    in fp32 and in bf16 (child processes: the switch is read once)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "flip_ab.py"
+    script.write_text(_FLIP_SCRIPT.format(repo=repo))
+    outs = []
+    for flag in ("1", "0"):
+        dst = str(tmp_path / f"out_{flag}.npz")
+        subprocess.run([sys.executable, str(script), dst], check=True, env=dict(os.environ, T2S_TILE_FLIP=flag), cwd=repo, timeout=300)
+        outs.append(np.load(dst))
+    assert set(outs[0].files) == set(outs[1].files) and len(outs[0].files) == 2 * 49
+    for k in outs[0].files:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
