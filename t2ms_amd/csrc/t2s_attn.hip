@@ -306,16 +306,26 @@ __device__ __forceinline__ void attn_persistent_body(f32x4* ring, const f32x4* q
                                                      const f32x4* vall, f32x4* og, int BH, int lane, int wave) {
     const int stride = gridDim.x;
     const int t0 = wave * 2;
-    // this wave DMAs ONE fragment of every block: waves 0-3 the K fragments, 4-7 the V^T fragments.
     // `jb` may run past 14 into the following heads of this workgroup.
-    const f32x4* my_src = (wave < 4 ? kall : vall) + (wave & 3) * 64 + lane;
-    const int my_dst = (wave < 4 ? 0 : 256) + (wave & 3) * 64;
+    // The wave that owns only ONE query tile (wave 7, the only NT == 1 instance: its SIMD carries 3 tiles where the others
+    // carry 4) issues ALL eight fragments of a block; the two-tile waves issue none.  An LDS-DMA instruction costs ~100 issue
+    // cycles, and in this kernel vector issue does not overlap the f32 MFMAs: one per block and wave on the critical SIMDs was
+    // 2 % of the attention time (round 5: 500 against 509 us per launch, headline +0.7 %, profiles/r05_attn_dma_w7_ab.txt).
+    // Counted wait of wave 7: blocks j+2 and j+3 (2 x 8 instructions) may stay in flight.
     auto issue_block = [&](int bh, int jb, int gslot) {
-        if (jb >= NKB) { jb -= NKB; bh += stride; }
-        if (bh >= BH) { bh -= stride; jb = NKB - 1; }   // past the end: harmless re-fetch
-        glds16_asm(my_src + (size_t)bh * NKB * 256 + jb * 4 * 64,
-               ring + (gslot & (ATT_SLOTS - 1)) * ATT_SLOT_F4 + my_dst);
+        if constexpr (NT == 1) {
+            if (jb >= NKB) { jb -= NKB; bh += stride; }
+            if (bh >= BH) { bh -= stride; jb = NKB - 1; }   // past the end: harmless re-fetch
+            const size_t off = (size_t)bh * NKB * 256 + jb * 4 * 64 + lane;
+            f32x4* dst = ring + (gslot & (ATT_SLOTS - 1)) * ATT_SLOT_F4;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                glds16_asm(kall + off + f * 64, dst + f * 64);
+                glds16_asm(vall + off + f * 64, dst + 256 + f * 64);
+            }
+        }
     };
+#define ATT_PERSIST_WAIT() if constexpr (NT == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory")
     int bh = blockIdx.x;
     int gb = 0;                                      // global block counter -> ring slot
     issue_block(bh, 0, 0);
@@ -333,7 +343,7 @@ __device__ __forceinline__ void attn_persistent_body(f32x4* ring, const f32x4* q
             qnb[g] = qb[g];
         }
     }
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    ATT_PERSIST_WAIT();
     __builtin_amdgcn_s_barrier();
     issue_block(bh, 3, 3);
     f32x4 kf[4];
@@ -398,7 +408,7 @@ __device__ __forceinline__ void attn_persistent_body(f32x4* ring, const f32x4* q
                 }
             }
             // ---- make block gb+1 visible, keep the DMA three blocks ahead, fetch its K fragments
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            ATT_PERSIST_WAIT();
             __builtin_amdgcn_s_barrier();
             issue_block(bh, jb + 4, gb + 4);     // slot (gb+4)&3 == gb&3: all its reads are done
             {

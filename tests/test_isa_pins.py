@@ -35,8 +35,8 @@ PINS = {
     # attention, 4-slot K / V^T ring (t2s_attn.hip): packed = one head per workgroup pair, persistent = one workgroup per CU
     NS + "22attn_fwd_packed_kernelILi2EEEvPKfS2_S2_Pfi": (256, 0, [(32, 2, 0, 0, 0, (4,)), (64, 2, 0, 0, 0, (4,))]),
     NS + "22attn_fwd_packed_kernelILi4EEEvPKfS2_S2_Pfi": (128, 0, [(32, 2, 0, 0, 0, (4,))]),   # one query tile per wave
-    NS + "26attn_fwd_persistent_kernelEPKfS1_S1_Pfi": (256, 0, [(48, 1, 0, 0, 0, (2,)), (16, 1, 0, 8, 0, (10, 9, 10, 10, 8, 7, 2)),
-                                                                 (96, 1, 0, 0, 0, (2,))]),
+    # (round 5: the one-tile wave issues all 8 LDS-DMAs of a block and waits for vmcnt(16); the two-tile waves' loops hold none)
+    NS + "26attn_fwd_persistent_kernelEPKfS1_S1_Pfi": (256, 0, [(48, 8, 0, 0, 0, (16,))]),
     # row chain, 3-slot weight ring two chunks ahead (t2s_rows.h): <DO_MLP, DO_QKV>
     NS + "15dit_rows_kernelILb0ELb1EEEvNS_7RowArgsE": (256, 0, [(128, 4, 0, 6, 0, ())]),
     NS + "15dit_rows_kernelILb1ELb1EEEvNS_7RowArgsE": (256, 0, [(128, 8, 0, 0, 0, (4, 4)), (128, 4, 0, 6, 0, ())]),
