@@ -121,24 +121,26 @@ __device__ __forceinline__ void attn_x3_body(bf16x8* ring, const f32x4* qall, co
                                              f32x4* og, int BH, int lane, int wave) {
     const int stride = gridDim.x;
     const int t0 = wave * 2;
-    // 12 pieces of 1 KiB per key block (6 K planes/steps, 6 V^T): wave w DMAs piece w, waves 0-3 also 8+w.
-    // `jb` may run past 14 into the following heads of this workgroup.
+    // 12 pieces of 1 KiB per key block (6 K planes/steps, 6 V^T)
     auto issue_piece = [&](int bh, int jb, int gslot, int p) {
         const bf16x8* src = (p < 6 ? kall : vall) + ((size_t)(bh * NKB + jb) * 6 + (p < 6 ? p : p - 6)) * 64 + lane;
         glds16u(src, ring + (gslot & (X3_SLOTS - 1)) * X3_SLOT_UNITS + p * 64);
     };
+    // The one-tile wave (NT == 1: wave 7, whose SIMD carries 3 tiles where the others carry 4) issues all 12 pieces of a block,
+    // the two-tile waves none (round 5, as t2s_attn.hip: attention 350 against 360 us per launch, sampler +0.9 %,
+    // profiles/r05_x3_dma_w7_ab.txt).  `jb` may run past 14 into the following heads of this workgroup.
     auto issue_block = [&](int bh, int jb, int gslot) {
-        if (jb >= NKB) { jb -= NKB; bh += stride; }
-        if (bh >= BH) { bh -= stride; jb = NKB - 1; }   // past the end: harmless re-fetch
-        issue_piece(bh, jb, gslot, wave);
-        if (wave < 4) issue_piece(bh, jb, gslot, 8 + wave);
+        if constexpr (NT == 1) {
+            if (jb >= NKB) { jb -= NKB; bh += stride; }
+            if (bh >= BH) { bh -= stride; jb = NKB - 1; }   // past the end: harmless re-fetch
+#pragma unroll
+            for (int p = 0; p < 12; ++p) issue_piece(bh, jb, gslot, p);
+        }
     };
-    // counted waits: everything but the DMAs of the youngest one / two blocks has landed
+    // counted waits of the issuing wave: everything but the 12-piece DMAs of the youngest one / two blocks has landed
     auto wait_but = [&](int blocks) {
-        if (wave < 4) {
-            if (blocks == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else {
-            if (blocks == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        if constexpr (NT == 1) {
+            if (blocks == 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         }
     };
     auto load_k = [&](Split3 (&kf)[2], int gslot) {
